@@ -1,0 +1,55 @@
+"""CPU: pin oracle/rtdetr_oracle.py against the committed HF-generated fixtures (tests/golden)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rtdetr_oracle as orc
+from tests.util import load_case, match_detections, sample, weights_for
+
+FAST = ["t_tiny_160", "t_tiny_160x224", "t_tinyb_192x128", "c1_r18_640_bs1", "c1_r18_640_scene", "c1_r18_640_resize"]
+SLOW = ["c2_r50_640_scene_bs2"]
+
+
+@pytest.mark.parametrize("name", FAST + SLOW)
+def test_oracle_matches_golden(name):
+    torch.set_num_threads(8)
+    arch, wseed, input_size, frames, g = load_case(name)
+    w = weights_for(arch, wseed)
+    xs, sizes = zip(*[orc.preprocess(f, input_size) for f in frames])
+    x = torch.cat(xs, 0)
+    np.testing.assert_allclose(sample(x), g["input_sample"], atol=0, rtol=0)   # PIL preprocess is exact
+    col = {}
+    labels, boxes, scores = orc.model_forward(arch, w, x, list(sizes), collect=col)
+    for i in range(3):
+        np.testing.assert_allclose(sample(col[f"backbone{i}"]), g[f"s_backbone{i}"], atol=2e-4, rtol=1e-4)
+        np.testing.assert_allclose(sample(col[f"enc{i}"]), g[f"s_enc{i}"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(col["enc_cls_max"].numpy(), g["enc_cls_max"], atol=1e-4)
+    # same set of selected memory tokens; per-token heads equal
+    mine, gold = np.sort(col["topk"].numpy(), 1), np.sort(g["topk"], 1)
+    assert (mine == gold).mean() > 0.99
+    if np.array_equal(mine, gold):
+        om, og = np.argsort(col["topk"].numpy(), 1), np.argsort(g["topk"], 1)
+        for b in range(len(frames)):
+            np.testing.assert_allclose(col["logits"][b].numpy()[om[b]], g["logits"][b][og[b]], atol=1e-4)
+            np.testing.assert_allclose(col["pred_boxes"][b].numpy()[om[b]], g["pred_boxes"][b][og[b]], atol=1e-5)
+        # final outputs: 1e-3 on scores, 1e-2 px on boxes (BASELINE.json north_star), order-tolerant
+        for b in range(len(frames)):
+            m, n, ws, wb = match_detections(g["labels"][b], g["boxes"][b], g["scores"][b],
+                                            labels[b].numpy(), boxes[b].numpy(), scores[b].numpy(), 1e-3, 1e-2)
+            assert m == n, (m, n, ws, wb)
+
+
+def test_format_detections_schema():
+    """dict schema / threshold / wildlife / area truncation of src/rtdetr_detector.py:262-303."""
+    labels = np.array([0, 3, 14, 21, 15])
+    boxes = np.array([[1.5, 2.5, 11.9, 12.9], [0, 0, 5, 5], [3, 3, 4, 4], [10, 10, 20.7, 30.2], [1, 1, 2, 2]], np.float32)
+    scores = np.array([0.9, 0.8, 0.3, 0.25, 0.2], np.float32)
+    d = orc.format_detections(labels, boxes, scores, 0.25, True)
+    assert [x["class_id"] for x in d] == [0, 14, 21]
+    assert d[0]["class_name"] == "person" and d[2]["class_name"] == "bear"
+    assert d[0]["bbox"]["area"] == int((float(np.float32(11.9)) - 1.5) * (float(np.float32(12.9)) - 2.5))
+    assert isinstance(d[0]["bbox"]["area"], int) and isinstance(d[0]["confidence"], float)
+    d = orc.format_detections(labels, boxes, scores, 0.25, False)
+    assert [x["class_id"] for x in d] == [0, 3, 14, 21]
+    assert set(d[0]) == {"class_id", "class_name", "confidence", "bbox"}
+    assert set(d[0]["bbox"]) == {"x1", "y1", "x2", "y2", "area"}
