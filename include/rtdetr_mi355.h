@@ -1,0 +1,147 @@
+/*
+ * rtdetr_mi355.h - C ABI of libmi355rtdetr.so: RT-DETRv2 detection inference on MI355X (gfx950).
+ *
+ * Drop-in boundary.  The reference has no FFI or plugin registry; its boundary is the duck-typed
+ * Python class `RTDETRDetector` constructed by name in the inference engine
+ * (/root/reference/src/inference_engine_yolox.py:196-212, class body src/rtdetr_detector.py:26-425).
+ * This library is what the replacement class (telescope_cam_detection_amd/rtdetr_detector.py) binds
+ * with ctypes; every entry point below cites the reference interface it stands in for.
+ * Plain pointers and sizes only - no torch types cross this boundary.
+ *
+ * Threading: handles are independent; calls on one handle are serialised internally; every entry
+ * point selects the handle's device and uses the handle's own HIP stream (the reference runs one
+ * detector instance per camera thread, src/inference_engine_yolox.py:320-381).
+ */
+#ifndef RTDETR_MI355_H
+#define RTDETR_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtd_engine* rtd_handle;
+
+/* return codes; RTD_E_OOM is distinct so the Python shim can re-raise torch.cuda.OutOfMemoryError,
+ * which is the only exception the reference's degrade path reacts to
+ * (src/inference_engine_yolox.py:607-623). */
+enum {
+  RTD_OK = 0,
+  RTD_E_INVALID = 1, /* bad argument / unsupported shape */
+  RTD_E_OOM = 2,     /* hipMalloc / arena exhaustion */
+  RTD_E_HIP = 3,     /* any other HIP runtime error */
+  RTD_E_WEIGHTS = 4, /* blob malformed or tensor missing / wrong shape */
+  RTD_E_STATE = 5    /* call order (e.g. infer before load_weights) */
+};
+
+enum { RTD_PREC_BF16 = 0, RTD_PREC_FP32 = 1 };
+enum { RTD_LAYER_BASIC = 0, RTD_LAYER_BOTTLENECK = 1 };
+
+/* Constructor arguments of RTDETRDetector (src/rtdetr_detector.py:29-58) that matter to the device
+ * side, plus the network description the reference obtains from upstream's YAML config
+ * (src/rtdetr_detector.py:132).  Field order is ABI; struct_size guards it. */
+typedef struct rtd_config {
+  int32_t struct_size;      /* = sizeof(rtd_config) */
+  int32_t device;           /* HIP ordinal  <- `device="cuda:N"` (:33) */
+  int32_t precision;        /* RTD_PREC_* : storage/MFMA type of conv + large token GEMMs */
+  int32_t max_batch;        /* largest n accepted by rtd_infer* */
+  int32_t input_h, input_w; /* <- `input_size` (:35); must be multiples of 32 */
+  int32_t use_graph;        /* 1: capture one hipGraph per batch size and replay it */
+  /* architecture (HF:rt_detr/configuration_rt_detr_resnet.py, rt_detr_v2/configuration_rt_detr_v2.py) */
+  int32_t layer_type;       /* RTD_LAYER_* */
+  int32_t depths[4];
+  int32_t hidden_sizes[4];
+  int32_t embedding_size;
+  int32_t enc_dim, enc_ffn, enc_heads, csp_hidden;
+  int32_t d_model, dec_ffn, dec_heads, dec_layers;
+  int32_t num_queries, num_classes, n_levels, n_points;
+  float offset_scale;
+} rtd_config;
+
+/* One detection row: what the per-row loop of src/rtdetr_detector.py:267-303 emits before it
+ * becomes a Python dict (class_name / area are derived host-side from these). */
+typedef struct rtd_det {
+  int32_t class_id;
+  float score;
+  float x1, y1, x2, y2;
+} rtd_det;
+
+/* per-kernel timing record filled by rtd_profile */
+typedef struct rtd_layer_time {
+  char name[48];
+  char kernel[24];  /* kernel family: "conv_igemm", "layernorm", ... */
+  float ms;         /* mean HIP-event time over `reps` launches on the handle's stream */
+  double flops;     /* algorithmic flops of one launch (2 flop / MAC) */
+  double bytes;     /* algorithmic bytes of one launch (in + out + weights, unfused) */
+} rtd_layer_time;
+
+const char* rtd_version(void);
+
+/* RTDETRDetector.__init__ (src/rtdetr_detector.py:29-58): allocates nothing on the device yet. */
+int rtd_create(const rtd_config* cfg, rtd_handle* out);
+
+/* RTDETRDetector.load_model (src/rtdetr_detector.py:132-173: load_state_dict + .deploy() + .to(device)).
+ * `blob` is the flat container written by telescope_cam_detection_amd.weights.pack_blob (already
+ * BN-folded / RepVGG-fused fp32 tensors); it is copied, converted to the handle's precision and laid
+ * out for the kernels.  Builds the execution plan + activation arena for cfg.input_h x input_w. */
+int rtd_load_weights(rtd_handle h, const void* blob, size_t nbytes);
+
+/* RTDETRDetector.detect / detect_batch (src/rtdetr_detector.py:238-403) for n <= max_batch frames.
+ * frames[i] : HWC uint8 BGR, hw[2*i] rows x hw[2*i+1] cols (the capture contract,
+ *             src/stream_capture.py:228-239); host pointers, or device pointers if frames_on_device.
+ * Frames whose size differs from input_h x input_w are stretch-resized exactly as PIL's antialiased
+ * bilinear `T.Resize` does (src/rtdetr_detector.py:176-180).
+ * out[i*num_queries ...] receives counts[i] rows in descending score order after the confidence
+ * threshold (:271) and the wildlife filter {0,14,15,16,21} (:277, src/coco_constants.py:23-29).
+ * Blocks until the results are on the host (the reference's three .cpu() syncs, :263-265). */
+int rtd_infer(rtd_handle h, int32_t n, const uint8_t* const* frames_bgr_hwc, const int32_t* hw,
+              int32_t frames_on_device, float conf_threshold, int32_t wildlife_only,
+              rtd_det* out, int32_t* counts);
+
+/* The raw tuple `labels, boxes, scores = self.model(img, orig_size)` (src/rtdetr_detector.py:257):
+ * labels[n][Q] (int32), boxes[n][Q][4] xyxy in original-frame pixels, scores[n][Q], descending. */
+int rtd_infer_raw(rtd_handle h, int32_t n, const uint8_t* const* frames_bgr_hwc, const int32_t* hw,
+                  int32_t frames_on_device, int32_t* labels, float* boxes, float* scores);
+
+/* Asynchronous device-resident variant used by the multi-camera shard and the benchmark:
+ * enqueues preprocess + network + post-process on the handle's stream and returns.  The result block
+ * stays on the device: [n][Q][6] fp32 rows (label, score, x1, y1, x2, y2) - the fixed-size block each
+ * rank contributes to the all-gather.  frames must be device pointers. */
+int rtd_infer_async(rtd_handle h, int32_t n, const uint8_t* const* frames_dev, const int32_t* hw);
+int rtd_result_block(rtd_handle h, float** dev_ptr, int64_t* n_floats);
+int rtd_sync(rtd_handle h);
+void* rtd_stream(rtd_handle h); /* hipStream_t of the handle */
+
+/* mutable attribute `model.to(device)` / teardown (src/inference_engine_yolox.py:743-744) */
+void rtd_destroy(rtd_handle h);
+const char* rtd_last_error(rtd_handle h); /* h may be NULL: last error of a failed rtd_create */
+
+/* ---- introspection used by tests / bench (no reference counterpart) -------------------------- */
+/* copy a named intermediate tensor of the last forward to the host as fp32; shape = (n, h, w, c) */
+int rtd_debug_tensor(rtd_handle h, const char* name, float* out, int64_t capacity, int64_t shape[4]);
+/* force the encoder top-k selection of the next forwards (idx[n][Q] memory-token ids, NULL = off):
+ * lets stage-level parity tests separate selection flips from decoder arithmetic */
+int rtd_debug_force_topk(rtd_handle h, const int32_t* idx, int32_t n);
+/* time every kernel of one forward of batch n with HIP events on the handle's stream */
+int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int32_t capacity, int32_t* count);
+int64_t rtd_arena_bytes(rtd_handle h);
+
+/* ---- kernel-level test entry points (device pointers; dtype 0 = bf16, 1 = fp32) --------------- */
+int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* bias, const void* res,
+                void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                int act, int res_mode, int out_f32);
+int rtd_op_layernorm(int dtype, const void* x, const void* res, const float* g, const float* b,
+                     void* y, int rows, int dim, int out_f32);
+int rtd_op_attention(int dtype, const void* qk, const void* v, void* o, int B, int L, int heads, int hd);
+int rtd_op_msdeform(int dtype, const void* value, const float* offaw, const float* ref, float* out,
+                    int B, int Q, int heads, int hd, int n_levels, int n_points, const int32_t* level_hw,
+                    int value_ld, float offset_scale);
+int rtd_op_topk(const float* keys, int B, int N, int K, int32_t* idx_out, float* val_out);
+int rtd_op_resize(const uint8_t* src, int sh, int sw, void* dst, int dh, int dw, int dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTDETR_MI355_H */

@@ -1,0 +1,271 @@
+"""ctypes binding of libmi355rtdetr.so (include/rtdetr_mi355.h).  No compute happens in Python.
+
+The library is required: if it cannot be built / loaded this module raises - there is no CPU or
+PyTorch fallback for the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import build as _build
+from .arch import Arch
+
+RTD_OK, RTD_E_INVALID, RTD_E_OOM, RTD_E_HIP, RTD_E_WEIGHTS, RTD_E_STATE = range(6)
+PREC_BF16, PREC_FP32 = 0, 1
+DT_BF16, DT_F32 = 0, 1
+ACT = {"none": 0, "relu": 1, "silu": 2, "gelu": 3}
+
+
+class RtdConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("device", C.c_int32), ("precision", C.c_int32), ("max_batch", C.c_int32),
+        ("input_h", C.c_int32), ("input_w", C.c_int32), ("use_graph", C.c_int32),
+        ("layer_type", C.c_int32), ("depths", C.c_int32 * 4), ("hidden_sizes", C.c_int32 * 4),
+        ("embedding_size", C.c_int32),
+        ("enc_dim", C.c_int32), ("enc_ffn", C.c_int32), ("enc_heads", C.c_int32), ("csp_hidden", C.c_int32),
+        ("d_model", C.c_int32), ("dec_ffn", C.c_int32), ("dec_heads", C.c_int32), ("dec_layers", C.c_int32),
+        ("num_queries", C.c_int32), ("num_classes", C.c_int32), ("n_levels", C.c_int32), ("n_points", C.c_int32),
+        ("offset_scale", C.c_float),
+    ]
+
+
+class RtdDet(C.Structure):
+    _fields_ = [("class_id", C.c_int32), ("score", C.c_float), ("x1", C.c_float), ("y1", C.c_float),
+                ("x2", C.c_float), ("y2", C.c_float)]
+
+
+class RtdLayerTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("kernel", C.c_char * 24), ("ms", C.c_float), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+DET_DTYPE = np.dtype([("class_id", "<i4"), ("score", "<f4"), ("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4")])
+
+_lib: Optional[C.CDLL] = None
+
+# every symbol include/rtdetr_mi355.h declares
+EXPORTS = [
+    "rtd_version", "rtd_create", "rtd_load_weights", "rtd_infer", "rtd_infer_raw", "rtd_infer_async",
+    "rtd_result_block", "rtd_sync", "rtd_stream", "rtd_destroy", "rtd_last_error", "rtd_debug_tensor",
+    "rtd_debug_force_topk", "rtd_profile", "rtd_arena_bytes", "rtd_op_conv", "rtd_op_layernorm",
+    "rtd_op_attention", "rtd_op_msdeform", "rtd_op_topk", "rtd_op_resize",
+]
+
+
+def lib() -> C.CDLL:
+    """Load (building first if stale) the HIP library.  Raises if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if _build.needs_build():
+        try:
+            path = _build.build(verbose=False)
+        except Exception as e:  # no hipcc on this box: use the prebuilt library if it is there
+            if not os.path.exists(path):
+                raise RuntimeError(f"libmi355rtdetr.so is missing and cannot be built: {e}") from e
+    L = C.CDLL(path)
+    vp, i32, f32, i64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
+    L.rtd_version.restype = C.c_char_p
+    L.rtd_last_error.restype = C.c_char_p
+    L.rtd_last_error.argtypes = [vp]
+    L.rtd_create.argtypes = [C.POINTER(RtdConfig), C.POINTER(vp)]
+    L.rtd_load_weights.argtypes = [vp, vp, C.c_size_t]
+    L.rtd_infer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), i32, f32, i32, vp, C.POINTER(i32)]
+    L.rtd_infer_raw.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), i32, vp, vp, vp]
+    L.rtd_infer_async.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32)]
+    L.rtd_result_block.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    L.rtd_sync.argtypes = [vp]
+    L.rtd_stream.argtypes = [vp]
+    L.rtd_stream.restype = vp
+    L.rtd_destroy.argtypes = [vp]
+    L.rtd_destroy.restype = None
+    L.rtd_debug_tensor.argtypes = [vp, C.c_char_p, vp, i64, C.POINTER(i64)]
+    L.rtd_debug_force_topk.argtypes = [vp, vp, i32]
+    L.rtd_profile.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
+    L.rtd_arena_bytes.argtypes = [vp]
+    L.rtd_arena_bytes.restype = i64
+    L.rtd_op_conv.argtypes = [i32, vp, vp, vp, vp, vp] + [i32] * 12
+    L.rtd_op_layernorm.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32]
+    L.rtd_op_attention.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32]
+    L.rtd_op_msdeform.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(i32), i32, f32]
+    L.rtd_op_topk.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.rtd_op_resize.argtypes = [vp, i32, i32, vp, i32, i32, i32]
+    _lib = L
+    return L
+
+
+class RtdError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rtd error {code}: {msg}")
+        self.code = code
+
+
+def _raise(code: int, handle) -> None:
+    msg = (lib().rtd_last_error(handle) or b"").decode(errors="replace")
+    if code == RTD_E_OOM:
+        import torch
+        # the only exception the reference's degrade path reacts to (src/inference_engine_yolox.py:607)
+        raise torch.cuda.OutOfMemoryError(f"HIP out of memory in libmi355rtdetr: {msg}")
+    raise RtdError(code, msg)
+
+
+def make_config(arch: Arch, device: int, precision: int, max_batch: int, input_size, use_graph: bool) -> RtdConfig:
+    c = RtdConfig()
+    c.struct_size = C.sizeof(RtdConfig)
+    c.device, c.precision, c.max_batch = device, precision, max_batch
+    c.input_h, c.input_w = int(input_size[0]), int(input_size[1])
+    c.use_graph = 1 if use_graph else 0
+    c.layer_type = 1 if arch.layer_type == "bottleneck" else 0
+    c.depths = (C.c_int32 * 4)(*arch.depths)
+    c.hidden_sizes = (C.c_int32 * 4)(*arch.hidden_sizes)
+    c.embedding_size = arch.embedding_size
+    c.enc_dim, c.enc_ffn, c.enc_heads, c.csp_hidden = arch.enc_dim, arch.enc_ffn, arch.enc_heads, arch.csp_hidden
+    c.d_model, c.dec_ffn, c.dec_heads, c.dec_layers = arch.d_model, arch.dec_ffn, arch.dec_heads, arch.dec_layers
+    c.num_queries, c.num_classes, c.n_levels, c.n_points = arch.num_queries, arch.num_classes, arch.n_levels, arch.n_points
+    c.offset_scale = arch.offset_scale
+    return c
+
+
+class Engine:
+    """Thin RAII wrapper of one rtd_handle."""
+
+    def __init__(self, arch: Arch, blob: bytes, device: int = 0, precision: int = PREC_BF16, max_batch: int = 8,
+                 input_size=(640, 640), use_graph: bool = True):
+        self.arch = arch
+        self.num_queries = arch.num_queries
+        self.max_batch = max_batch
+        self._h = C.c_void_p()
+        cfg = make_config(arch, device, precision, max_batch, input_size, use_graph)
+        rc = lib().rtd_create(C.byref(cfg), C.byref(self._h))
+        if rc != RTD_OK:
+            self._h = C.c_void_p()
+            _raise(rc, None)
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        rc = lib().rtd_load_weights(self._h, buf, len(blob))
+        if rc != RTD_OK:
+            try:
+                _raise(rc, self._h)
+            finally:
+                self.close()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().rtd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers
+    @staticmethod
+    def _frame_args(frames, on_device: bool):
+        n = len(frames)
+        ptrs = (C.c_void_p * n)()
+        hw = (C.c_int32 * (2 * n))()
+        keep = []
+        for i, f in enumerate(frames):
+            if on_device:
+                assert f.dtype.__str__() == "torch.uint8" and f.is_contiguous() and f.dim() == 3 and f.shape[2] == 3
+                ptrs[i] = f.data_ptr()
+                hw[2 * i], hw[2 * i + 1] = int(f.shape[0]), int(f.shape[1])
+            else:
+                a = np.ascontiguousarray(f, dtype=np.uint8)
+                assert a.ndim == 3 and a.shape[2] == 3, "frames must be HxWx3 uint8 BGR"
+                keep.append(a)
+                ptrs[i] = a.ctypes.data
+                hw[2 * i], hw[2 * i + 1] = a.shape[0], a.shape[1]
+        return n, ptrs, hw, keep
+
+    def infer(self, frames, conf: float, wildlife_only: bool, on_device: bool = False):
+        n, ptrs, hw, keep = self._frame_args(frames, on_device)
+        out = np.zeros((n, self.num_queries), dtype=DET_DTYPE)
+        counts = (C.c_int32 * n)()
+        rc = lib().rtd_infer(self._h, n, ptrs, hw, int(on_device), float(conf), int(bool(wildlife_only)),
+                             out.ctypes.data, counts)
+        if rc != RTD_OK:
+            _raise(rc, self._h)
+        return [out[i, : counts[i]] for i in range(n)]
+
+    def infer_raw(self, frames, on_device: bool = False):
+        n, ptrs, hw, keep = self._frame_args(frames, on_device)
+        Q = self.num_queries
+        labels = np.zeros((n, Q), np.int32)
+        boxes = np.zeros((n, Q, 4), np.float32)
+        scores = np.zeros((n, Q), np.float32)
+        rc = lib().rtd_infer_raw(self._h, n, ptrs, hw, int(on_device), labels.ctypes.data, boxes.ctypes.data, scores.ctypes.data)
+        if rc != RTD_OK:
+            _raise(rc, self._h)
+        return labels, boxes, scores
+
+    def infer_async(self, frames_dev):
+        n, ptrs, hw, keep = self._frame_args(frames_dev, True)
+        rc = lib().rtd_infer_async(self._h, n, ptrs, hw)
+        if rc != RTD_OK:
+            _raise(rc, self._h)
+
+    def make_async_args(self, frames_dev):
+        """Pre-marshal (n, ptrs, hw) once so a benchmark loop does no Python work per step."""
+        return self._frame_args(frames_dev, True)
+
+    def infer_async_prepared(self, args):
+        rc = lib().rtd_infer_async(self._h, args[0], args[1], args[2])
+        if rc != RTD_OK:
+            _raise(rc, self._h)
+
+    def result_block(self):
+        p = C.c_void_p()
+        n = C.c_int64()
+        rc = lib().rtd_result_block(self._h, C.byref(p), C.byref(n))
+        if rc != RTD_OK:
+            _raise(rc, self._h)
+        return p.value, n.value
+
+    def sync(self):
+        rc = lib().rtd_sync(self._h)
+        if rc != RTD_OK:
+            _raise(rc, self._h)
+
+    def stream(self) -> int:
+        return lib().rtd_stream(self._h) or 0
+
+    def debug_tensor(self, name: str) -> np.ndarray:
+        shape = (C.c_int64 * 4)()
+        rc = lib().rtd_debug_tensor(self._h, name.encode(), None, 0, shape)
+        if rc != RTD_OK:
+            _raise(rc, self._h)
+        out = np.zeros(tuple(shape), np.float32)
+        rc = lib().rtd_debug_tensor(self._h, name.encode(), out.ctypes.data, out.size, shape)
+        if rc != RTD_OK:
+            _raise(rc, self._h)
+        return out
+
+    def force_topk(self, idx: Optional[np.ndarray]):
+        if idx is None:
+            rc = lib().rtd_debug_force_topk(self._h, None, 0)
+        else:
+            a = np.ascontiguousarray(idx, np.int32)
+            rc = lib().rtd_debug_force_topk(self._h, a.ctypes.data, a.shape[0])
+        if rc != RTD_OK:
+            _raise(rc, self._h)
+
+    def profile(self, n: int, reps: int = 5):
+        cnt = C.c_int32()
+        rc = lib().rtd_profile(self._h, n, reps, None, 0, C.byref(cnt))
+        if rc != RTD_OK:
+            _raise(rc, self._h)
+        arr = (RtdLayerTime * cnt.value)()
+        rc = lib().rtd_profile(self._h, n, reps, arr, cnt.value, C.byref(cnt))
+        if rc != RTD_OK:
+            _raise(rc, self._h)
+        return [dict(name=a.name.decode(), kernel=a.kernel.decode(), ms=a.ms, flops=a.flops, bytes=a.bytes) for a in arr]
+
+    def arena_bytes(self) -> int:
+        return lib().rtd_arena_bytes(self._h)

@@ -1,0 +1,69 @@
+"""Build libmi355rtdetr.so (gfx950) in-tree with hipcc.  `python -m telescope_cam_detection_amd.build`.
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box with the
+repo snapshot.  A rebuild happens only when a source is newer than the library.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libmi355rtdetr.so")
+SOURCES = ["conv_igemm.hip", "ops.hip", "engine.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(PKG), "include", "rtdetr_mi355.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (needs the ROCm toolchain)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = _hipcc()
+    os.makedirs(LIB_DIR, exist_ok=True)
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
+        if verbose and r.stderr.strip():
+            print(r.stderr[-2000:], file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    tmp = LIB_PATH + ".tmp"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    os.replace(tmp, LIB_PATH)
+    if verbose:
+        print(f"built {LIB_PATH}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

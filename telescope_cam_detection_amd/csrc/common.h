@@ -1,0 +1,113 @@
+// common.h - shared types for the gfx950 RT-DETR engine (host + device).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <stdexcept>
+#include <string>
+
+namespace rtd {
+
+enum DType : int { BF16 = 0, F32 = 1, U8 = 2, I32 = 3 };
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GELU = 3 };
+enum ResMode : int { RES_NONE = 0, RES_PRE = 1, RES_POST = 2 };
+
+inline size_t dtype_size(int dt) { return dt == BF16 ? 2 : (dt == U8 ? 1 : 4); }
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// An NHWC view.  `ld` is the element stride between consecutive pixels (>= c when the view is a
+// channel slice of a wider buffer), `bstride` the element stride between images.
+struct Tensor {
+  void* p = nullptr;
+  int dt = F32;
+  int n = 0, h = 0, w = 0, c = 0;
+  int64_t ld = 0;
+  int64_t bstride = 0;
+  int64_t pixels() const { return (int64_t)n * h * w; }
+  Tensor slice_c(int c0, int cn) const {
+    Tensor t = *this;
+    t.p = (char*)p + (size_t)c0 * dtype_size(dt);
+    t.c = cn;
+    return t;
+  }
+};
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define RTD_CHECK(cond, code, msg)                                                     \
+  do {                                                                                 \
+    if (!(cond)) throw ::rtd::Error((code), std::string(msg) + " [" #cond "] at " __FILE__ ":" + std::to_string(__LINE__)); \
+  } while (0)
+
+#define HIP_CHECK(expr)                                                                \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      int _c = (_e == hipErrorOutOfMemory) ? 2 : 3;                                    \
+      throw ::rtd::Error(_c, std::string(#expr) + ": " + hipGetErrorString(_e) + " at " __FILE__ ":" + std::to_string(__LINE__)); \
+    }                                                                                  \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// kernel launch wrappers (implemented in conv_igemm.hip / ops.hip)
+// ------------------------------------------------------------------------------------------
+struct ConvArgs {
+  Tensor x;            // input  [B,H,W,Cin] (view)
+  const void* w;       // filter [Npad][Kpad] in x.dt, K = KH*KW*Cin (tap-major, channel-minor)
+  const float* bias;   // [Npad] fp32
+  Tensor res;          // optional residual, indexed like y
+  Tensor y;            // output [B,OH,OW,N] (view)
+  int KH = 1, KW = 1, stride = 1, pad = 0;
+  int Kpad = 0, Npad = 0;
+  int act = ACT_NONE, res_mode = RES_NONE;
+};
+void launch_conv(const ConvArgs& a, hipStream_t s);
+int conv_kpad(int K);                 // padded filter row length the kernels expect
+int conv_npad(int N);
+
+void launch_layernorm(const Tensor& x, const Tensor* res, const float* g, const float* b, const Tensor& y,
+                      float eps, hipStream_t s);
+// y = a + b (b broadcast over batch when b.n == 1)
+void launch_add(const Tensor& a, const Tensor& b, const Tensor& y, hipStream_t s);
+void launch_maxpool3x3s2(const Tensor& x, const Tensor& y, hipStream_t s);
+void launch_upsample2x(const Tensor& x, const Tensor& y, hipStream_t s);
+// qk: [B,L,2*D] (q | k), v: [B,L,D] -> o [B,L,D]; softmax(q k^T / sqrt(hd)) v per head
+void launch_attention(const Tensor& qk, const Tensor& v, const Tensor& o, int heads, hipStream_t s);
+void launch_set_rows(const Tensor& y, const int32_t* rows, int nrows, int rows_per_image, const float* vec,
+                     hipStream_t s);
+void launch_rowmax(const Tensor& x, float* out, hipStream_t s);
+void launch_topk(const float* keys, int B, int N, int K, int32_t* idx, float* vals, hipStream_t s);
+void launch_gather_rows(const Tensor& src, const int32_t* idx, int rows_per_image, const Tensor& dst, hipStream_t s);
+// dst[b,q,0:4] = src[b, idx[b,q], 0:4] + anchors[idx[b,q]] ; dst rows are 8 floats (4..7 = 0)
+void launch_ref_init(const Tensor& boxdelta, const float* anchors, const int32_t* idx, int S, float* ref_unact8,
+                     float* ref8, hipStream_t s);
+void launch_msdeform(const Tensor& value, int value_coff, const Tensor& offaw, const float* ref8, const Tensor& out,
+                     int heads, int hd, int n_levels, int n_points, const int32_t* level_hw_start, float offset_scale,
+                     hipStream_t s);
+void launch_box_refine(const Tensor& delta, float* ref8, hipStream_t s);
+void launch_postprocess_scores(const Tensor& logits, float* scores, hipStream_t s);
+void launch_postprocess_gather(const float* topv, const int32_t* topi, const float* ref8, const float* scale_wh,
+                               int B, int Q, int C, float* block6, hipStream_t s);
+void launch_preprocess_identity(const uint8_t* const* frames, int n, int H, int W, const Tensor& y, hipStream_t s);
+// device-resident coefficient tables of one (src size -> dst size) PIL resize
+struct ResizeCoef {
+  const int32_t* hb;  // [dw][2] xmin, count
+  const int32_t* hk;  // [dw][hks]
+  const int32_t* vb;  // [dh][2]
+  const int32_t* vk;  // [dh][vks]
+  int hks, vks;
+};
+void launch_resize_pil(const uint8_t* src, int sh, int sw, uint8_t* tmp, const Tensor& y, int image, const ResizeCoef& coef,
+                       hipStream_t s);
+void launch_f32_to(const float* src, void* dst, int dt, int64_t n, hipStream_t s);
+void launch_to_f32(const void* src, int dt, float* dst, int64_t n, hipStream_t s);
+
+}  // namespace rtd

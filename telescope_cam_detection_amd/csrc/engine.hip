@@ -1,0 +1,1141 @@
+// engine.hip - host side of libmi355rtdetr.so: weight container, execution plan, hipGraph, C ABI.
+//
+// The engine owns, per handle: the device copy of the (BN-folded, RepVGG-fused) weights in the
+// handle's precision, one activation arena + execution plan per batch size, a HIP stream and
+// (optionally) one captured hipGraph per plan.  The graph of layers below is the RT-DETRv2 graph of
+// HF:rt_detr_v2/modeling_rt_detr_v2.py / rt_detr/modeling_rt_detr_resnet.py (see oracle/rtdetr_oracle.py
+// for the line-by-line CPU restatement it is tested against).
+#include <math.h>
+#include <string.h>
+
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "../../include/rtdetr_mi355.h"
+#include "common.h"
+
+using namespace rtd;
+
+void launch_force_idx(int32_t* dst, const int32_t* src, const int32_t* flag, int n, hipStream_t s);
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HostTensor {
+  const float* data = nullptr;
+  std::vector<int64_t> shape;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto d : shape) n *= d;
+    return n;
+  }
+};
+
+struct DevWeight {
+  void* w = nullptr;
+  float* bias = nullptr;
+  int N = 0, K = 0, Kpad = 0, Npad = 0, dt = F32;
+};
+
+struct Op {
+  std::string name;
+  const char* kernel;
+  double flops, bytes;
+  std::function<void(hipStream_t)> run;
+};
+
+struct Plan {
+  int n = 0;
+  void* arena = nullptr;
+  size_t arena_bytes = 0;
+  std::vector<Op> ops;
+  std::map<std::string, Tensor> named;
+  Tensor input;            // [n,H,W,8]
+  float* block6 = nullptr; // [n,Q,6]
+  float* scale_wh = nullptr;
+  int32_t* tk_idx = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+struct ResizeTables {
+  ResizeCoef coef;
+  std::vector<void*> dev;
+};
+
+}  // namespace
+
+struct rtd_engine {
+  rtd_config cfg;
+  std::mutex mu;
+  std::string err;
+  hipStream_t stream = nullptr;
+  bool loaded = false;
+  int P = BF16;  // storage / MFMA type of the conv trunk
+  std::vector<char> blob;
+  std::map<std::string, HostTensor> host;
+  std::map<std::string, DevWeight> wcache;
+  std::map<std::string, float*> vcache;
+  std::vector<void*> allocs;
+  std::map<int, std::unique_ptr<Plan>> plans;
+  std::map<std::pair<int, int>, ResizeTables> resize;
+  // per-call staging
+  uint8_t* frame_stage = nullptr; size_t frame_stage_bytes = 0;
+  uint8_t* resize_tmp = nullptr; size_t resize_tmp_bytes = 0;
+  const uint8_t** ptrs_dev = nullptr; const uint8_t** ptrs_host = nullptr;
+  float* scale_host = nullptr;
+  float* block_host = nullptr;
+  int32_t* forced_idx = nullptr; int32_t* force_flag = nullptr;
+  // geometry
+  int lvl_h[3], lvl_w[3], lvl_start[3], S = 0;
+  float* anchors_dev = nullptr; int32_t* invalid_rows_dev = nullptr; int n_invalid = 0;
+  int32_t* lvl_dev = nullptr;
+  float* pos_dev = nullptr;
+  int last_n = 0;
+
+  void* dmalloc(size_t bytes) {
+    void* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+    allocs.push_back(p);
+    return p;
+  }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ blob
+void parse_blob(rtd_engine* e) {
+  const char* b = e->blob.data();
+  const size_t n = e->blob.size();
+  RTD_CHECK(n >= 12 && memcmp(b, "RTDW", 4) == 0, RTD_E_WEIGHTS, "weight blob: bad magic");
+  uint32_t ver, count;
+  memcpy(&ver, b + 4, 4);
+  memcpy(&count, b + 8, 4);
+  RTD_CHECK(ver == 1, RTD_E_WEIGHTS, "weight blob: unsupported version");
+  size_t p = 12;
+  for (uint32_t i = 0; i < count; ++i) {
+    RTD_CHECK(p + 2 <= n, RTD_E_WEIGHTS, "weight blob: truncated table");
+    uint16_t nl;
+    memcpy(&nl, b + p, 2); p += 2;
+    RTD_CHECK(p + nl + 4 <= n, RTD_E_WEIGHTS, "weight blob: truncated table");
+    std::string name(b + p, nl); p += nl;
+    uint32_t nd;
+    memcpy(&nd, b + p, 4); p += 4;
+    RTD_CHECK(nd <= 8 && p + 4 * nd + 16 <= n, RTD_E_WEIGHTS, "weight blob: truncated table");
+    HostTensor t;
+    for (uint32_t d = 0; d < nd; ++d) {
+      uint32_t v;
+      memcpy(&v, b + p, 4); p += 4;
+      t.shape.push_back(v);
+    }
+    uint64_t off, nb;
+    memcpy(&off, b + p, 8); p += 8;
+    memcpy(&nb, b + p, 8); p += 8;
+    RTD_CHECK(off % 4 == 0 && off + nb <= n && (int64_t)nb == t.numel() * 4, RTD_E_WEIGHTS, "weight blob: bad tensor extent: " + name);
+    t.data = (const float*)(b + off);
+    e->host[name] = t;
+  }
+}
+
+const HostTensor& host_tensor(rtd_engine* e, const std::string& name) {
+  auto it = e->host.find(name);
+  RTD_CHECK(it != e->host.end(), RTD_E_WEIGHTS, "weight blob: missing tensor " + name);
+  return it->second;
+}
+
+// filter [N][K] fp32 -> device [Npad][Kpad] in dt (zero padded), bias -> fp32 [Npad]
+DevWeight get_weight(rtd_engine* e, const std::string& name, int dt, int N, int K) {
+  const std::string key = name + (dt == BF16 ? "#bf16" : "#f32");
+  auto it = e->wcache.find(key);
+  if (it != e->wcache.end()) return it->second;
+  const HostTensor& w = host_tensor(e, name + ".w");
+  const HostTensor& b = host_tensor(e, name + ".b");
+  RTD_CHECK(!w.shape.empty() && w.shape[0] == N && w.numel() == (int64_t)N * K, RTD_E_WEIGHTS, "weight shape mismatch: " + name);
+  RTD_CHECK(b.numel() == N, RTD_E_WEIGHTS, "bias shape mismatch: " + name);
+  DevWeight d;
+  d.N = N; d.K = K; d.Kpad = conv_kpad(K); d.Npad = conv_npad(N); d.dt = dt;
+  std::vector<float> pad((size_t)d.Npad * d.Kpad, 0.f);
+  for (int r = 0; r < N; ++r) memcpy(&pad[(size_t)r * d.Kpad], w.data + (size_t)r * K, (size_t)K * 4);
+  float* tmp = nullptr;
+  HIP_CHECK(hipMalloc((void**)&tmp, pad.size() * 4));
+  hipError_t er = hipMemcpy(tmp, pad.data(), pad.size() * 4, hipMemcpyHostToDevice);
+  if (er == hipSuccess) {
+    if (dt == F32) {
+      d.w = tmp;
+      e->allocs.push_back(tmp);
+      tmp = nullptr;
+    } else {
+      d.w = e->dmalloc(pad.size() * 2);
+      launch_f32_to(tmp, d.w, BF16, (int64_t)pad.size(), e->stream);
+      er = hipStreamSynchronize(e->stream);
+    }
+  }
+  if (tmp) (void)hipFree(tmp);
+  HIP_CHECK(er);
+  std::vector<float> bp(d.Npad, 0.f);
+  memcpy(bp.data(), b.data, (size_t)N * 4);
+  d.bias = (float*)e->dmalloc(bp.size() * 4);
+  HIP_CHECK(hipMemcpy(d.bias, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+  e->wcache[key] = d;
+  return d;
+}
+
+float* get_vec(rtd_engine* e, const std::string& name, int n) {
+  auto it = e->vcache.find(name);
+  if (it != e->vcache.end()) return it->second;
+  const HostTensor& t = host_tensor(e, name);
+  RTD_CHECK(t.numel() == n, RTD_E_WEIGHTS, "vector shape mismatch: " + name);
+  float* d = (float*)e->dmalloc((size_t)n * 4);
+  HIP_CHECK(hipMemcpy(d, t.data, (size_t)n * 4, hipMemcpyHostToDevice));
+  e->vcache[name] = d;
+  return d;
+}
+
+// ------------------------------------------------------------------------------------------ geometry
+int down2(int n) { return (n + 2 - 3) / 2 + 1; }  // k=3, s=2, p=1
+
+// 2D sin-cos position embedding, HF:v2.py:955-1000 : [sin_h | cos_h | sin_w | cos_w], float64 math
+std::vector<float> sincos_pos(int h, int w, int dim) {
+  const int pd = dim / 4;
+  std::vector<float> out((size_t)h * w * dim);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      float* o = &out[((size_t)y * w + x) * dim];
+      for (int i = 0; i < pd; ++i) {
+        const double omega = 1.0 / pow(10000.0, (double)i / pd);
+        o[i] = (float)sin(y * omega);
+        o[pd + i] = (float)cos(y * omega);
+        o[2 * pd + i] = (float)sin(x * omega);
+        o[3 * pd + i] = (float)cos(x * omega);
+      }
+    }
+  return out;
+}
+
+// anchors + valid mask, HF:v2.py:1423-1449 in fp32 arithmetic; invalid -> FLT_MAX
+void make_anchors(rtd_engine* e, std::vector<float>& anchors, std::vector<int32_t>& invalid) {
+  anchors.assign((size_t)e->S * 4, 0.f);
+  invalid.clear();
+  for (int l = 0; l < 3; ++l) {
+    const int h = e->lvl_h[l], w = e->lvl_w[l];
+    const float wh = 0.05f * (float)(1 << l);
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        const int t = e->lvl_start[l] + y * w + x;
+        float a[4] = {((float)x + 0.5f) / (float)w, ((float)y + 0.5f) / (float)h, wh, wh};
+        bool valid = true;
+        for (int k = 0; k < 4; ++k) valid = valid && (a[k] > 1e-2f) && (a[k] < 1.f - 1e-2f);
+        for (int k = 0; k < 4; ++k) anchors[(size_t)t * 4 + k] = valid ? logf(a[k] / (1.f - a[k])) : 3.402823466e+38f;
+        if (!valid) invalid.push_back(t);
+      }
+  }
+}
+
+// Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bilinear filter (support 1.0),
+// box = the whole source; the published algorithm of ImagingResample (Pillow src/libImaging/Resample.c).
+void pil_coeffs(int in_size, int out_size, std::vector<int32_t>& bounds, std::vector<int32_t>& kk, int& ksize) {
+  const double scale = (double)in_size / out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 1.0 * filterscale;
+  ksize = (int)ceil(support) * 2 + 1;
+  bounds.assign((size_t)out_size * 2, 0);
+  kk.assign((size_t)out_size * ksize, 0);
+  std::vector<double> k(ksize);
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = (xx + 0.5) * scale;
+    const double ss = 1.0 / filterscale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) {
+      double t = (x + xmin - center + 0.5) * ss;
+      if (t < 0.0) t = -t;
+      const double wv = t < 1.0 ? 1.0 - t : 0.0;
+      k[x] = wv;
+      ww += wv;
+    }
+    for (int x = 0; x < xmax; ++x) {
+      if (ww != 0.0) k[x] /= ww;
+      const double v = k[x] * (double)(1 << 22);
+      kk[(size_t)xx * ksize + x] = v < 0 ? (int)(-0.5 + v) : (int)(0.5 + v);
+    }
+    bounds[(size_t)xx * 2] = xmin;
+    bounds[(size_t)xx * 2 + 1] = xmax;
+  }
+}
+
+const ResizeCoef& resize_tables(rtd_engine* e, int sh, int sw) {
+  auto key = std::make_pair(sh, sw);
+  auto it = e->resize.find(key);
+  if (it != e->resize.end()) return it->second.coef;
+  std::vector<int32_t> hb, hk, vb, vk;
+  int hks, vks;
+  pil_coeffs(sw, e->cfg.input_w, hb, hk, hks);
+  pil_coeffs(sh, e->cfg.input_h, vb, vk, vks);
+  ResizeTables t;
+  auto up = [&](const std::vector<int32_t>& v) {
+    void* d = e->dmalloc(v.size() * 4);
+    HIP_CHECK(hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    return (const int32_t*)d;
+  };
+  t.coef.hb = up(hb); t.coef.hk = up(hk); t.coef.vb = up(vb); t.coef.vk = up(vk);
+  t.coef.hks = hks; t.coef.vks = vks;
+  e->resize[key] = t;
+  return e->resize[key].coef;
+}
+
+// ------------------------------------------------------------------------------------------ plan builder
+struct Builder {
+  rtd_engine* e;
+  Plan* plan;
+  bool dry;
+  size_t off = 0;
+
+  void* alloc(size_t bytes) {
+    off = (off + 255) / 256 * 256;
+    void* p = dry ? nullptr : (char*)plan->arena + off;
+    off += bytes;
+    return p;
+  }
+  Tensor act(int dt, int n, int h, int w, int c, const std::string& name = "") {
+    Tensor t;
+    t.dt = dt; t.n = n; t.h = h; t.w = w; t.c = c; t.ld = c; t.bstride = (int64_t)h * w * c;
+    t.p = alloc((size_t)n * h * w * c * dtype_size(dt));
+    if (!name.empty()) plan->named[name] = t;
+    return t;
+  }
+  void push(const std::string& name, const char* kernel, double flops, double bytes, std::function<void(hipStream_t)> f) {
+    if (dry) return;
+    plan->ops.push_back(Op{name, kernel, flops, bytes, std::move(f)});
+  }
+  static double tbytes(const Tensor& t) { return (double)t.pixels() * t.c * dtype_size(t.dt); }
+
+  // conv / linear.  `y` may be a channel-slice view of a wider buffer.
+  void conv(const std::string& name, const Tensor& x, const Tensor& y, int k, int stride, int pad, int act,
+            const Tensor* res = nullptr, int res_mode = RES_NONE, int real_cin = 0) {
+    const int K = k * k * x.c;
+    DevWeight w;
+    if (!dry) w = get_weight(e, name, x.dt, y.c, K);
+    else { w.Kpad = conv_kpad(K); w.Npad = conv_npad(y.c); }
+    ConvArgs a;
+    a.x = x; a.y = y; a.w = w.w; a.bias = w.bias;
+    a.KH = k; a.KW = k; a.stride = stride; a.pad = pad; a.Kpad = w.Kpad; a.Npad = w.Npad;
+    a.act = act; a.res_mode = res ? res_mode : RES_NONE;
+    if (res) a.res = *res;
+    const double M = (double)y.pixels();
+    const double kreal = (double)k * k * (real_cin ? real_cin : x.c);
+    const double flops = 2.0 * M * y.c * kreal;
+    const double bytes = (double)x.pixels() * x.c * dtype_size(x.dt) + tbytes(y) + (double)y.c * K * dtype_size(x.dt) +
+                         (res ? tbytes(*res) : 0.0);
+    push(name, "conv_igemm", flops, bytes, [a](hipStream_t s) { launch_conv(a, s); });
+  }
+  Tensor linear(const std::string& name, const Tensor& x, int N, int odt, int act, const Tensor* res = nullptr,
+                const std::string& tname = "") {
+    Tensor y = this->act(odt, x.n, x.h, x.w, N, tname);
+    conv(name, x, y, 1, 1, 0, act, res, RES_PRE);
+    return y;
+  }
+  Tensor layernorm(const std::string& name, const Tensor& x, int odt, const std::string& tname = "") {
+    Tensor y = act(odt, x.n, x.h, x.w, x.c, tname);
+    if (dry) return y;
+    const float* g = get_vec(e, name + ".g", x.c);
+    const float* b = get_vec(e, name + ".b", x.c);
+    push(name, "layernorm", 8.0 * x.pixels() * x.c, tbytes(x) + tbytes(y),
+         [x, y, g, b](hipStream_t s) { launch_layernorm(x, nullptr, g, b, y, 1e-5f, s); });
+    return y;
+  }
+};
+
+void build_graph(rtd_engine* e, Builder& B, int n) {
+  const rtd_config& c = e->cfg;
+  const int P = e->P;
+  const int H = c.input_h, W = c.input_w;
+  Plan* plan = B.plan;
+  auto nm = [](const char* fmt, int a = 0, int b = 0) {
+    char buf[96];
+    snprintf(buf, sizeof buf, fmt, a, b);
+    return std::string(buf);
+  };
+
+  // ---- input + stem (HF:rt_detr_resnet.py:71-114) ----------------------------------------------
+  Tensor x = B.act(P, n, H, W, 8, "input");
+  plan->input = x;
+  const int eh = c.embedding_size / 2;
+  int h = down2(H), w = down2(W);
+  Tensor s0 = B.act(P, n, h, w, eh);
+  B.conv("backbone.stem.0", x, s0, 3, 2, 1, ACT_RELU, nullptr, RES_NONE, 3);
+  Tensor s1 = B.act(P, n, h, w, eh);
+  B.conv("backbone.stem.1", s0, s1, 3, 1, 1, ACT_RELU);
+  Tensor s2 = B.act(P, n, h, w, c.embedding_size);
+  B.conv("backbone.stem.2", s1, s2, 3, 1, 1, ACT_RELU);
+  h = down2(h); w = down2(w);
+  Tensor cur = B.act(P, n, h, w, c.embedding_size, "stem");
+  B.push("backbone.pool", "maxpool", 9.0 * cur.pixels() * cur.c, Builder::tbytes(s2) + Builder::tbytes(cur),
+         [s2, cur](hipStream_t s) { launch_maxpool3x3s2(s2, cur, s); });
+
+  // ---- residual stages (HF:rt_detr_resnet.py:135-310) ------------------------------------------
+  Tensor feats[3];
+  int cin = c.embedding_size;
+  for (int si = 0; si < 4; ++si) {
+    const int cout = c.hidden_sizes[si];
+    for (int bi = 0; bi < c.depths[si]; ++bi) {
+      const int stride = (si > 0 && bi == 0) ? 2 : 1;
+      const std::string pfx = nm("backbone.s%d.b%d", si, bi);
+      const int oh = stride == 2 ? down2(h) : h, ow = stride == 2 ? down2(w) : w;
+      const bool last = bi == c.depths[si] - 1;
+      const std::string oname = (last && si >= 1) ? nm("backbone%d", si - 1) : std::string();
+      Tensor res = cur;
+      bool has_sc;
+      if (c.layer_type == RTD_LAYER_BOTTLENECK) has_sc = (cin != cout) || stride != 1;
+      else has_sc = (bi == 0);
+      if (has_sc) {
+        res = B.act(P, n, oh, ow, cout);
+        // stride 2: AvgPool2d(2,2) + 1x1 folded into one 2x2 stride-2 filter (weights.py fold_weights)
+        if (stride == 2) B.conv(pfx + ".sc", cur, res, 2, 2, 0, ACT_NONE);
+        else B.conv(pfx + ".sc", cur, res, 1, 1, 0, ACT_NONE);
+      }
+      Tensor out = B.act(P, n, oh, ow, cout, oname);
+      if (c.layer_type == RTD_LAYER_BOTTLENECK) {
+        const int mid = cout / 4;
+        Tensor t1 = B.act(P, n, h, w, mid);
+        B.conv(pfx + ".c1", cur, t1, 1, 1, 0, ACT_RELU);
+        Tensor t2 = B.act(P, n, oh, ow, mid);
+        B.conv(pfx + ".c2", t1, t2, 3, stride, 1, ACT_RELU);
+        B.conv(pfx + ".c3", t2, out, 1, 1, 0, ACT_RELU, &res, RES_PRE);
+      } else {
+        Tensor t1 = B.act(P, n, oh, ow, cout);
+        B.conv(pfx + ".c1", cur, t1, 3, stride, 1, ACT_RELU);
+        B.conv(pfx + ".c2", t1, out, 3, 1, 1, ACT_RELU, &res, RES_PRE);
+      }
+      cur = out; h = oh; w = ow; cin = cout;
+    }
+    if (si >= 1) feats[si - 1] = cur;
+  }
+
+  // ---- hybrid encoder (HF:v2.py:1348-1360 input proj, :1041-1095 AIFI, :1183-1209 FPN/PAN) ------
+  const int d = c.enc_dim, hh = c.csp_hidden;
+  const int* lh = e->lvl_h; const int* lw = e->lvl_w;
+  Tensor cat1 = B.act(P, n, lh[0], lw[0], 2 * d);   // [up(lat1) | proj0]
+  Tensor cat0 = B.act(P, n, lh[1], lw[1], 2 * d);   // [up(lat0) | proj1]
+  Tensor pcat0 = B.act(P, n, lh[1], lw[1], 2 * d);  // [down0 | lat1]
+  Tensor pcat1 = B.act(P, n, lh[2], lw[2], 2 * d);  // [down1 | lat0]
+  B.conv("enc.proj.0", feats[0], cat1.slice_c(d, d), 1, 1, 0, ACT_NONE);
+  B.conv("enc.proj.1", feats[1], cat0.slice_c(d, d), 1, 1, 0, ACT_NONE);
+  const int L = lh[2] * lw[2];
+  Tensor t0 = B.act(F32, n, L, 1, d, "aifi_in");
+  {
+    Tensor t0v = t0; t0v.h = lh[2]; t0v.w = lw[2];
+    B.conv("enc.proj.2", feats[2], t0v, 1, 1, 0, ACT_NONE);
+  }
+  // AIFI in fp32 (0.5 % of the FLOPs; keeps the only global-mixing layer of the encoder exact)
+  Tensor pos;
+  pos.p = e->pos_dev; pos.dt = F32; pos.n = 1; pos.h = L; pos.w = 1; pos.c = d; pos.ld = d; pos.bstride = (int64_t)L * d;
+  Tensor xp = B.act(F32, n, L, 1, d);
+  B.push("enc.aifi.addpos", "add", (double)xp.pixels() * d, 3 * Builder::tbytes(xp), [t0, pos, xp](hipStream_t s) { launch_add(t0, pos, xp, s); });
+  Tensor qk = B.linear("enc.aifi.qk", xp, 2 * d, F32, ACT_NONE);
+  Tensor vv = B.linear("enc.aifi.v", t0, d, F32, ACT_NONE);
+  Tensor att = B.act(F32, n, L, 1, d);
+  {
+    const int heads = c.enc_heads;
+    B.push("enc.aifi.attn", "attention", 4.0 * n * (double)L * L * d, Builder::tbytes(qk) + 2 * Builder::tbytes(vv),
+           [qk, vv, att, heads](hipStream_t s) { launch_attention(qk, vv, att, heads, s); });
+  }
+  Tensor ao = B.linear("enc.aifi.o", att, d, F32, ACT_NONE, &t0);
+  Tensor t1 = B.layernorm("enc.aifi.ln1", ao, F32);
+  Tensor f1 = B.linear("enc.aifi.fc1", t1, c.enc_ffn, F32, ACT_GELU);
+  Tensor f2 = B.linear("enc.aifi.fc2", f1, d, F32, ACT_NONE, &t1);
+  Tensor t2 = B.layernorm("enc.aifi.ln2", f2, P, "aifi_out");
+  t2.h = lh[2]; t2.w = lw[2];
+
+  auto csp = [&](const std::string& pfx, const Tensor& cat, const std::string& oname) {
+    Tensor h12 = B.act(P, cat.n, cat.h, cat.w, 2 * hh);
+    B.conv(pfx + ".c12", cat, h12, 1, 1, 0, ACT_SILU);
+    Tensor r0 = B.act(P, cat.n, cat.h, cat.w, hh);
+    B.conv(pfx + ".rep0", h12.slice_c(0, hh), r0, 3, 1, 1, ACT_SILU);
+    Tensor r1 = B.act(P, cat.n, cat.h, cat.w, hh);
+    B.conv(pfx + ".rep1", r0, r1, 3, 1, 1, ACT_SILU);
+    Tensor h2 = h12.slice_c(hh, hh);
+    if (hh == d) {
+      Tensor r2 = B.act(P, cat.n, cat.h, cat.w, hh, oname);
+      B.conv(pfx + ".rep2", r1, r2, 3, 1, 1, ACT_SILU, &h2, RES_POST);
+      return r2;
+    }
+    Tensor r2 = B.act(P, cat.n, cat.h, cat.w, hh);
+    B.conv(pfx + ".rep2", r1, r2, 3, 1, 1, ACT_SILU, &h2, RES_POST);
+    Tensor o = B.act(P, cat.n, cat.h, cat.w, d, oname);
+    B.conv(pfx + ".c3", r2, o, 1, 1, 0, ACT_SILU);
+    return o;
+  };
+  auto upsample = [&](const std::string& name, const Tensor& src, const Tensor& dst) {
+    B.push(name, "upsample2x", 0.0, Builder::tbytes(src) + 4 * Builder::tbytes(src), [src, dst](hipStream_t s) { launch_upsample2x(src, dst, s); });
+  };
+  // FPN top-down
+  Tensor lat0 = pcat1.slice_c(d, d);
+  B.conv("enc.lat.0", t2, lat0, 1, 1, 0, ACT_SILU);
+  upsample("enc.up.0", lat0, cat0.slice_c(0, d));
+  Tensor F0 = csp("enc.fpn.0", cat0, "");
+  Tensor lat1 = pcat0.slice_c(d, d);
+  B.conv("enc.lat.1", F0, lat1, 1, 1, 0, ACT_SILU);
+  upsample("enc.up.1", lat1, cat1.slice_c(0, d));
+  Tensor F1 = csp("enc.fpn.1", cat1, "enc0");
+  // PAN bottom-up
+  B.conv("enc.down.0", F1, pcat0.slice_c(0, d), 3, 2, 1, ACT_SILU);
+  Tensor P1 = csp("enc.pan.0", pcat0, "enc1");
+  B.conv("enc.down.1", P1, pcat1.slice_c(0, d), 3, 2, 1, ACT_SILU);
+  Tensor P2 = csp("enc.pan.1", pcat1, "enc2");
+  Tensor pan[3] = {F1, P1, P2};
+
+  // ---- decoder input + query selection (HF:v2.py:1533-1623) ------------------------------------
+  const int dm = c.d_model, S = e->S, Q = c.num_queries, C = c.num_classes, NL = c.dec_layers;
+  Tensor mem = B.act(P, n, S, 1, dm, "memory");
+  for (int l = 0; l < 3; ++l) {
+    Tensor v = mem;
+    v.p = B.dry ? nullptr : (char*)mem.p + (size_t)e->lvl_start[l] * dm * dtype_size(P);
+    v.h = lh[l]; v.w = lw[l];
+    B.conv(nm("dec.proj.%d", l), pan[l], v, 1, 1, 0, ACT_NONE);
+  }
+  // value_proj of every decoder layer in ONE GEMM (they all read `mem`, HF:v2.py:177)
+  Tensor vall = B.linear("dec.vp_all", mem, NL * dm, P, ACT_NONE, nullptr, "value_all");
+  // enc_output on masked memory, fp32 from here on (selection + decoder are exact fp32)
+  Tensor eo = B.linear("dec.enc_out.fc", mem, dm, F32, ACT_NONE);
+  if (!B.dry && e->n_invalid > 0) {
+    const float* bias = get_weight(e, "dec.enc_out.fc", P, dm, dm).bias;
+    const int32_t* rows = e->invalid_rows_dev;
+    const int nr = e->n_invalid;
+    B.push("dec.mask_rows", "set_rows", 0.0, (double)n * nr * dm * 4, [eo, rows, nr, S, bias](hipStream_t s) { launch_set_rows(eo, rows, nr, S, bias, s); });
+  }
+  Tensor om = B.layernorm("dec.enc_out.ln", eo, F32, "output_memory");
+  Tensor cls = B.linear("dec.enc_score", om, C, F32, ACT_NONE);
+  float* mx = (float*)B.alloc((size_t)n * S * 4);
+  {
+    Tensor t; t.p = mx; t.dt = F32; t.n = n; t.h = S; t.w = 1; t.c = 1; t.ld = 1; t.bstride = S;
+    plan->named["enc_cls_max"] = t;
+  }
+  B.push("dec.enc_rowmax", "rowmax", (double)n * S * C, (double)n * S * C * 4, [cls, mx](hipStream_t s) { launch_rowmax(cls, mx, s); });
+  int32_t* tk = (int32_t*)B.alloc((size_t)n * Q * 4);
+  plan->tk_idx = tk;
+  {
+    const int32_t* forced = e->forced_idx; const int32_t* flag = e->force_flag;
+    B.push("dec.enc_topk", "topk", 0.0, (double)n * S * 4 * 6, [mx, n, S, Q, tk](hipStream_t s) { launch_topk(mx, n, S, Q, tk, nullptr, s); });
+    B.push("dec.force_topk", "select", 0.0, 0.0, [tk, forced, flag, n, Q](hipStream_t s) {
+      launch_force_idx(tk, forced, flag, n * Q, s);
+    });
+  }
+  Tensor target = B.act(F32, n, Q, 1, dm, "target");
+  B.push("dec.gather_target", "gather", 0.0, 2.0 * n * Q * dm * 4, [om, tk, S, target](hipStream_t s) { launch_gather_rows(om, tk, S, target, s); });
+  Tensor b0 = B.linear("dec.enc_bbox.0", target, dm, F32, ACT_RELU);
+  Tensor b1 = B.linear("dec.enc_bbox.1", b0, dm, F32, ACT_RELU);
+  Tensor b2 = B.linear("dec.enc_bbox.2", b1, 4, F32, ACT_NONE);
+  float* ref_unact8 = (float*)B.alloc((size_t)n * Q * 8 * 4);
+  float* ref8 = (float*)B.alloc((size_t)n * Q * 8 * 4);
+  Tensor ref8t; ref8t.p = ref8; ref8t.dt = F32; ref8t.n = n; ref8t.h = Q; ref8t.w = 1; ref8t.c = 8; ref8t.ld = 8; ref8t.bstride = (int64_t)Q * 8;
+  plan->named["ref"] = ref8t;
+  {
+    Tensor ru = ref8t; ru.p = ref_unact8;
+    plan->named["ref_unact"] = ru;
+    const float* anchors = e->anchors_dev;
+    B.push("dec.ref_init", "ref_init", 0.0, (double)n * Q * 64, [b2, anchors, tk, S, ref_unact8, ref8](hipStream_t s) { launch_ref_init(b2, anchors, tk, S, ref_unact8, ref8, s); });
+  }
+
+  // ---- decoder layers (HF:v2.py:603-661, layer :339-431) ---------------------------------------
+  Tensor hs = target;
+  const int npts = c.dec_heads * c.n_levels * c.n_points;
+  for (int i = 0; i < NL; ++i) {
+    const std::string p = nm("dec.l%d", i);
+    Tensor qp0 = B.linear("dec.qpos.0", ref8t, 2 * dm, F32, ACT_RELU);
+    Tensor qpos = B.linear("dec.qpos.1", qp0, dm, F32, ACT_NONE);
+    Tensor hp = B.act(F32, n, Q, 1, dm);
+    B.push(p + ".addpos1", "add", (double)n * Q * dm, 3.0 * n * Q * dm * 4, [hs, qpos, hp](hipStream_t s) { launch_add(hs, qpos, hp, s); });
+    Tensor sqk = B.linear(p + ".sa.qk", hp, 2 * dm, F32, ACT_NONE);
+    Tensor sv = B.linear(p + ".sa.v", hs, dm, F32, ACT_NONE);
+    Tensor sa = B.act(F32, n, Q, 1, dm);
+    {
+      const int heads = c.dec_heads;
+      B.push(p + ".sa.attn", "attention", 4.0 * n * (double)Q * Q * dm, Builder::tbytes(sqk) + 2 * Builder::tbytes(sv),
+             [sqk, sv, sa, heads](hipStream_t s) { launch_attention(sqk, sv, sa, heads, s); });
+    }
+    Tensor so = B.linear(p + ".sa.o", sa, dm, F32, ACT_NONE, &hs);
+    Tensor hs1 = B.layernorm(p + ".ln1", so, F32);
+    Tensor hp2 = B.act(F32, n, Q, 1, dm);
+    B.push(p + ".addpos2", "add", (double)n * Q * dm, 3.0 * n * Q * dm * 4, [hs1, qpos, hp2](hipStream_t s) { launch_add(hs1, qpos, hp2, s); });
+    Tensor offaw = B.linear(p + ".ca.offaw", hp2, 3 * npts, F32, ACT_NONE);
+    Tensor samp = B.act(F32, n, Q, 1, dm);
+    {
+      const int heads = c.dec_heads, hd = dm / c.dec_heads, nl = c.n_levels, np = c.n_points, coff = i * dm;
+      const int32_t* lvl = e->lvl_dev;
+      const float osc = c.offset_scale;
+      B.push(p + ".ca.sample", "msdeform", 2.0 * n * Q * dm * nl * np * 4, (double)n * Q * heads * nl * np * 4 * hd * dtype_size(P),
+             [vall, coff, offaw, ref8, samp, heads, hd, nl, np, lvl, osc](hipStream_t s) {
+               launch_msdeform(vall, coff, offaw, ref8, samp, heads, hd, nl, np, lvl, osc, s);
+             });
+    }
+    Tensor co = B.linear(p + ".ca.op", samp, dm, F32, ACT_NONE, &hs1);
+    Tensor hs2 = B.layernorm(p + ".ln2", co, F32);
+    Tensor g1 = B.linear(p + ".fc1", hs2, c.dec_ffn, F32, ACT_RELU);
+    Tensor g2 = B.linear(p + ".fc2", g1, dm, F32, ACT_NONE, &hs2);
+    Tensor hs3 = B.layernorm(p + ".ln3", g2, F32, nm("dec%d.hs", i));
+    Tensor d0 = B.linear(nm("dec.bbox.%d.0", i), hs3, dm, F32, ACT_RELU);
+    Tensor d1 = B.linear(nm("dec.bbox.%d.1", i), d0, dm, F32, ACT_RELU);
+    Tensor d2 = B.linear(nm("dec.bbox.%d.2", i), d1, 4, F32, ACT_NONE);
+    B.push(p + ".refine", "box_refine", 0.0, (double)n * Q * 48, [d2, ref8](hipStream_t s) { launch_box_refine(d2, ref8, s); });
+    hs = hs3;
+  }
+  // ---- heads + post-processor (HF:v2.py:1880-1881; image_processing_rt_detr.py:510-533) ---------
+  Tensor logits = B.linear("dec.cls", hs, C, F32, ACT_NONE, nullptr, "logits");
+  float* scores = (float*)B.alloc((size_t)n * Q * C * 4);
+  float* topv = (float*)B.alloc((size_t)n * Q * 4);
+  int32_t* topi = (int32_t*)B.alloc((size_t)n * Q * 4);
+  plan->block6 = (float*)B.alloc((size_t)n * Q * 6 * 4);
+  plan->scale_wh = (float*)B.alloc((size_t)n * 2 * 4);
+  {
+    float* block6 = plan->block6; float* scale = plan->scale_wh;
+    B.push("post.sigmoid", "postprocess", (double)n * Q * C, 2.0 * n * Q * C * 4, [logits, scores](hipStream_t s) { launch_postprocess_scores(logits, scores, s); });
+    B.push("post.topk", "topk", 0.0, (double)n * Q * C * 4 * 6, [scores, n, Q, C, topi, topv](hipStream_t s) { launch_topk(scores, n, Q * C, Q, topi, topv, s); });
+    B.push("post.gather", "postprocess", 0.0, (double)n * Q * 64, [topv, topi, ref8, scale, n, Q, C, block6](hipStream_t s) {
+      launch_postprocess_gather(topv, topi, ref8, scale, n, Q, C, block6, s);
+    });
+  }
+}
+
+Plan* get_plan(rtd_engine* e, int n) {
+  auto it = e->plans.find(n);
+  if (it != e->plans.end()) return it->second.get();
+  std::unique_ptr<Plan> plan(new Plan());
+  plan->n = n;
+  Builder dry{e, plan.get(), true};
+  build_graph(e, dry, n);
+  plan->arena_bytes = dry.off + 4096;
+  HIP_CHECK(hipMalloc(&plan->arena, plan->arena_bytes));
+  e->allocs.push_back(plan->arena);
+  HIP_CHECK(hipMemsetAsync(plan->arena, 0, plan->arena_bytes, e->stream));
+  plan->named.clear();
+  Builder real{e, plan.get(), false};
+  build_graph(e, real, n);
+  HIP_CHECK(hipStreamSynchronize(e->stream));
+  Plan* p = plan.get();
+  e->plans[n] = std::move(plan);
+  return p;
+}
+
+void run_plan(rtd_engine* e, Plan* p) {
+  if (e->cfg.use_graph) {
+    if (!p->exec) {
+      // one eager pass first: faults and shape errors surface outside capture
+      for (auto& op : p->ops) op.run(e->stream);
+      HIP_CHECK(hipStreamSynchronize(e->stream));
+      HIP_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+      try {
+        for (auto& op : p->ops) op.run(e->stream);
+      } catch (...) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(e->stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        throw;
+      }
+      HIP_CHECK(hipStreamEndCapture(e->stream, &p->graph));
+      HIP_CHECK(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
+    }
+    HIP_CHECK(hipGraphLaunch(p->exec, e->stream));
+  } else {
+    for (auto& op : p->ops) op.run(e->stream);
+  }
+}
+
+// preprocess n frames into plan->input and set the post-processor's (w,h) scale
+void enqueue_frames(rtd_engine* e, Plan* p, int n, const uint8_t* const* frames, const int32_t* hw, bool on_device) {
+  const int H = e->cfg.input_h, W = e->cfg.input_w;
+  size_t total = 0, max_tmp = 0;
+  for (int i = 0; i < n; ++i) {
+    RTD_CHECK(frames[i] != nullptr && hw[2 * i] > 0 && hw[2 * i + 1] > 0 && hw[2 * i] <= 16384 && hw[2 * i + 1] <= 16384,
+              RTD_E_INVALID, "frame pointer / size");
+    total += ((size_t)hw[2 * i] * hw[2 * i + 1] * 3 + 255) / 256 * 256;
+    if (hw[2 * i] != H || hw[2 * i + 1] != W) max_tmp = std::max(max_tmp, (size_t)hw[2 * i] * W * 3);
+  }
+  if (!on_device && total > e->frame_stage_bytes) {
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (e->frame_stage) (void)hipFree(e->frame_stage);
+    e->frame_stage = nullptr; e->frame_stage_bytes = 0;
+    HIP_CHECK(hipMalloc((void**)&e->frame_stage, total));
+    e->frame_stage_bytes = total;
+  }
+  if (max_tmp > e->resize_tmp_bytes) {
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (e->resize_tmp) (void)hipFree(e->resize_tmp);
+    e->resize_tmp = nullptr; e->resize_tmp_bytes = 0;
+    HIP_CHECK(hipMalloc((void**)&e->resize_tmp, max_tmp));
+    e->resize_tmp_bytes = max_tmp;
+  }
+  size_t off = 0;
+  bool all_identity = true;
+  for (int i = 0; i < n; ++i) {
+    const size_t bytes = (size_t)hw[2 * i] * hw[2 * i + 1] * 3;
+    const uint8_t* dev = frames[i];
+    if (!on_device) {
+      HIP_CHECK(hipMemcpyAsync(e->frame_stage + off, frames[i], bytes, hipMemcpyHostToDevice, e->stream));
+      dev = e->frame_stage + off;
+      off += (bytes + 255) / 256 * 256;
+    }
+    e->ptrs_host[i] = dev;
+    e->scale_host[2 * i] = (float)hw[2 * i + 1];   // orig_size = [w, h]  (src/rtdetr_detector.py:234)
+    e->scale_host[2 * i + 1] = (float)hw[2 * i];
+    if (hw[2 * i] != H || hw[2 * i + 1] != W) all_identity = false;
+  }
+  HIP_CHECK(hipMemcpyAsync(p->scale_wh, e->scale_host, (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
+  if (all_identity) {
+    HIP_CHECK(hipMemcpyAsync((void*)e->ptrs_dev, e->ptrs_host, (size_t)n * sizeof(void*), hipMemcpyHostToDevice, e->stream));
+    launch_preprocess_identity(e->ptrs_dev, n, H, W, p->input, e->stream);
+  } else {
+    for (int i = 0; i < n; ++i) {
+      // the same resampler handles an identity-sized frame exactly (1-tap coefficients of 1.0)
+      const ResizeCoef& rc = resize_tables(e, hw[2 * i], hw[2 * i + 1]);
+      launch_resize_pil(e->ptrs_host[i], hw[2 * i], hw[2 * i + 1], e->resize_tmp, p->input, i, rc, e->stream);
+    }
+  }
+}
+
+void check_n(rtd_engine* e, int n) {
+  RTD_CHECK(e->loaded, RTD_E_STATE, "rtd_load_weights has not succeeded on this handle");
+  RTD_CHECK(n >= 1 && n <= e->cfg.max_batch, RTD_E_INVALID, "batch size out of range");
+}
+
+void forward(rtd_engine* e, int n, const uint8_t* const* frames, const int32_t* hw, bool on_device) {
+  check_n(e, n);
+  HIP_CHECK(hipSetDevice(e->cfg.device));
+  Plan* p = get_plan(e, n);
+  enqueue_frames(e, p, n, frames, hw, on_device);
+  run_plan(e, p);
+  e->last_n = n;
+}
+
+template <typename F>
+int guarded(rtd_engine* e, F&& f) {
+  if (!e) return RTD_E_INVALID;
+  std::lock_guard<std::mutex> lk(e->mu);
+  try {
+    f();
+    return RTD_OK;
+  } catch (const Error& er) {
+    e->err = er.what();
+    return er.code;
+  } catch (const std::bad_alloc&) {
+    e->err = "host allocation failed";
+    return RTD_E_OOM;
+  } catch (const std::exception& ex) {
+    e->err = ex.what();
+    return RTD_E_HIP;
+  }
+}
+
+}  // namespace
+
+namespace rtd {
+__global__ void k_force_idx(int32_t* dst, const int32_t* src, const int32_t* flag, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && *flag) dst[i] = src[i];
+}
+}  // namespace rtd
+void launch_force_idx(int32_t* dst, const int32_t* src, const int32_t* flag, int n, hipStream_t s) {
+  hipLaunchKernelGGL(rtd::k_force_idx, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, flag, n);
+}
+
+template <typename F>
+static int op_guard(F&& f) {
+  try {
+    f();
+    HIP_CHECK(hipDeviceSynchronize());
+    return RTD_OK;
+  } catch (const Error& er) {
+    g_create_error = er.what();
+    return er.code;
+  } catch (const std::exception& ex) {
+    g_create_error = ex.what();
+    return RTD_E_HIP;
+  }
+}
+static Tensor mk(const void* p, int dt, int n, int h, int w, int c) {
+  Tensor t;
+  t.p = (void*)p; t.dt = dt; t.n = n; t.h = h; t.w = w; t.c = c; t.ld = c; t.bstride = (int64_t)h * w * c;
+  return t;
+}
+
+
+// =========================================================================================== C ABI
+extern "C" {
+
+const char* rtd_version(void) { return "mi355-rtdetr 0.1 (gfx950)"; }
+
+const char* rtd_last_error(rtd_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int rtd_create(const rtd_config* cfg, rtd_handle* out) {
+  if (!cfg || !out) { g_create_error = "null argument"; return RTD_E_INVALID; }
+  try {
+    RTD_CHECK(cfg->struct_size == (int32_t)sizeof(rtd_config), RTD_E_INVALID, "rtd_config.struct_size mismatch");
+    RTD_CHECK(cfg->precision == RTD_PREC_BF16 || cfg->precision == RTD_PREC_FP32, RTD_E_INVALID, "precision");
+    RTD_CHECK(cfg->max_batch >= 1 && cfg->max_batch <= 64, RTD_E_INVALID, "max_batch must be in [1,64]");
+    // the FPN concatenates a 2x-upsampled map with the next level: every level must halve exactly
+    RTD_CHECK(cfg->input_h >= 64 && cfg->input_w >= 64 && cfg->input_h % 32 == 0 && cfg->input_w % 32 == 0 &&
+                  cfg->input_h <= 4096 && cfg->input_w <= 4096, RTD_E_INVALID, "input size must be a multiple of 32 in [64,4096]");
+    RTD_CHECK(cfg->n_levels == 3 && cfg->n_points >= 1 && cfg->n_points <= 8, RTD_E_INVALID, "n_levels must be 3");
+    RTD_CHECK(cfg->d_model % cfg->dec_heads == 0 && cfg->d_model / cfg->dec_heads == 32, RTD_E_INVALID, "decoder head dim must be 32");
+    RTD_CHECK(cfg->enc_dim % cfg->enc_heads == 0 && cfg->enc_dim % 8 == 0 && cfg->csp_hidden % 8 == 0, RTD_E_INVALID, "encoder dims");
+    RTD_CHECK(cfg->embedding_size % 16 == 0, RTD_E_INVALID, "embedding_size must be a multiple of 16");
+    for (int i = 0; i < 4; ++i) RTD_CHECK(cfg->depths[i] >= 1 && cfg->hidden_sizes[i] % 32 == 0, RTD_E_INVALID, "stage config");
+    RTD_CHECK(cfg->num_queries >= 1 && cfg->num_queries <= 1024 && cfg->num_classes % 4 == 0, RTD_E_INVALID, "num_queries <= 1024, num_classes % 4 == 0");
+    RTD_CHECK((cfg->dec_heads * cfg->n_levels * cfg->n_points * 3) % 4 == 0, RTD_E_INVALID, "sampling head width");
+    rtd_engine* e = new rtd_engine();
+    e->cfg = *cfg;
+    e->P = cfg->precision == RTD_PREC_BF16 ? BF16 : F32;
+    *out = e;
+    return RTD_OK;
+  } catch (const Error& er) {
+    g_create_error = er.what();
+    return er.code;
+  } catch (const std::exception& ex) {
+    g_create_error = ex.what();
+    return RTD_E_INVALID;
+  }
+}
+
+int rtd_load_weights(rtd_handle h, const void* blob, size_t nbytes) {
+  return guarded(h, [&] {
+    rtd_engine* e = h;
+    RTD_CHECK(!e->loaded, RTD_E_STATE, "weights already loaded on this handle");
+    RTD_CHECK(blob && nbytes >= 12, RTD_E_WEIGHTS, "empty weight blob");
+    int ndev = 0;
+    HIP_CHECK(hipGetDeviceCount(&ndev));
+    RTD_CHECK(e->cfg.device >= 0 && e->cfg.device < ndev, RTD_E_INVALID, "device ordinal out of range");
+    HIP_CHECK(hipSetDevice(e->cfg.device));
+    if (!e->stream) HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->blob.assign((const char*)blob, (const char*)blob + nbytes);
+    parse_blob(e);
+    const rtd_config& c = e->cfg;
+    // level geometry (strides 8/16/32)
+    int hh = down2(down2(c.input_h)), ww = down2(down2(c.input_w));
+    e->S = 0;
+    for (int l = 0; l < 3; ++l) {
+      hh = down2(hh); ww = down2(ww);
+      e->lvl_h[l] = hh; e->lvl_w[l] = ww; e->lvl_start[l] = e->S;
+      e->S += hh * ww;
+    }
+    RTD_CHECK(e->lvl_h[0] == 2 * e->lvl_h[1] && e->lvl_h[1] == 2 * e->lvl_h[2] && e->lvl_w[0] == 2 * e->lvl_w[1] && e->lvl_w[1] == 2 * e->lvl_w[2],
+              RTD_E_INVALID, "feature pyramid does not halve exactly");
+    RTD_CHECK(c.num_queries <= e->S, RTD_E_INVALID, "num_queries exceeds the number of memory tokens");
+    std::vector<float> anchors; std::vector<int32_t> invalid;
+    make_anchors(e, anchors, invalid);
+    e->anchors_dev = (float*)e->dmalloc(anchors.size() * 4);
+    HIP_CHECK(hipMemcpy(e->anchors_dev, anchors.data(), anchors.size() * 4, hipMemcpyHostToDevice));
+    e->n_invalid = (int)invalid.size();
+    e->invalid_rows_dev = (int32_t*)e->dmalloc(invalid.size() * 4 + 16);
+    if (!invalid.empty()) HIP_CHECK(hipMemcpy(e->invalid_rows_dev, invalid.data(), invalid.size() * 4, hipMemcpyHostToDevice));
+    int32_t lv[9];
+    for (int l = 0; l < 3; ++l) { lv[l * 3] = e->lvl_h[l]; lv[l * 3 + 1] = e->lvl_w[l]; lv[l * 3 + 2] = e->lvl_start[l]; }
+    e->lvl_dev = (int32_t*)e->dmalloc(sizeof lv);
+    HIP_CHECK(hipMemcpy(e->lvl_dev, lv, sizeof lv, hipMemcpyHostToDevice));
+    std::vector<float> pos = sincos_pos(e->lvl_h[2], e->lvl_w[2], c.enc_dim);
+    e->pos_dev = (float*)e->dmalloc(pos.size() * 4);
+    HIP_CHECK(hipMemcpy(e->pos_dev, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+    e->forced_idx = (int32_t*)e->dmalloc((size_t)c.max_batch * c.num_queries * 4);
+    e->force_flag = (int32_t*)e->dmalloc(16);
+    HIP_CHECK(hipMemset(e->force_flag, 0, 16));
+    e->ptrs_dev = (const uint8_t**)e->dmalloc((size_t)c.max_batch * sizeof(void*));
+    HIP_CHECK(hipHostMalloc((void**)&e->ptrs_host, (size_t)c.max_batch * sizeof(void*), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void**)&e->scale_host, (size_t)c.max_batch * 8, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void**)&e->block_host, (size_t)c.max_batch * c.num_queries * 6 * 4, hipHostMallocDefault));
+    e->loaded = true;
+    // build the bs=1 plan now: validates every tensor name / shape of the blob against the graph
+    try {
+      get_plan(e, 1);
+    } catch (...) {
+      e->loaded = false;
+      throw;
+    }
+    e->blob.clear(); e->blob.shrink_to_fit(); e->host.clear();
+  });
+}
+
+static void copy_block(rtd_engine* e, Plan* p, int n) {
+  HIP_CHECK(hipMemcpyAsync(e->block_host, p->block6, (size_t)n * e->cfg.num_queries * 24, hipMemcpyDeviceToHost, e->stream));
+  HIP_CHECK(hipStreamSynchronize(e->stream));
+}
+
+int rtd_infer(rtd_handle h, int32_t n, const uint8_t* const* frames, const int32_t* hw, int32_t on_device,
+              float conf, int32_t wildlife_only, rtd_det* out, int32_t* counts) {
+  return guarded(h, [&] {
+    RTD_CHECK(frames && hw && out && counts, RTD_E_INVALID, "null argument");
+    forward(h, n, frames, hw, on_device != 0);
+    copy_block(h, h->plans[n].get(), n);
+    const int Q = h->cfg.num_queries;
+    for (int i = 0; i < n; ++i) {
+      int cnt = 0;
+      for (int q = 0; q < Q; ++q) {
+        const float* r = h->block_host + ((size_t)i * Q + q) * 6;
+        const float score = r[1];
+        if (score < conf) continue;                       // src/rtdetr_detector.py:271
+        const int cid = (int)r[0];
+        if (wildlife_only && !(cid == 0 || cid == 14 || cid == 15 || cid == 16 || cid == 21)) continue;  // :277
+        rtd_det& d = out[(size_t)i * Q + cnt++];
+        d.class_id = cid; d.score = score; d.x1 = r[2]; d.y1 = r[3]; d.x2 = r[4]; d.y2 = r[5];
+      }
+      counts[i] = cnt;
+    }
+  });
+}
+
+int rtd_infer_raw(rtd_handle h, int32_t n, const uint8_t* const* frames, const int32_t* hw, int32_t on_device,
+                  int32_t* labels, float* boxes, float* scores) {
+  return guarded(h, [&] {
+    RTD_CHECK(frames && hw && labels && boxes && scores, RTD_E_INVALID, "null argument");
+    forward(h, n, frames, hw, on_device != 0);
+    copy_block(h, h->plans[n].get(), n);
+    const int Q = h->cfg.num_queries;
+    for (size_t t = 0; t < (size_t)n * Q; ++t) {
+      const float* r = h->block_host + t * 6;
+      labels[t] = (int32_t)r[0];
+      scores[t] = r[1];
+      memcpy(boxes + t * 4, r + 2, 16);
+    }
+  });
+}
+
+int rtd_infer_async(rtd_handle h, int32_t n, const uint8_t* const* frames_dev, const int32_t* hw) {
+  return guarded(h, [&] {
+    RTD_CHECK(frames_dev && hw, RTD_E_INVALID, "null argument");
+    forward(h, n, frames_dev, hw, true);
+  });
+}
+
+int rtd_result_block(rtd_handle h, float** dev_ptr, int64_t* n_floats) {
+  return guarded(h, [&] {
+    RTD_CHECK(dev_ptr && n_floats && h->last_n > 0, RTD_E_STATE, "no forward has run");
+    *dev_ptr = h->plans[h->last_n]->block6;
+    *n_floats = (int64_t)h->last_n * h->cfg.num_queries * 6;
+  });
+}
+
+int rtd_sync(rtd_handle h) {
+  return guarded(h, [&] {
+    if (h->stream) HIP_CHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+void* rtd_stream(rtd_handle h) { return h ? (void*)h->stream : nullptr; }
+
+int64_t rtd_arena_bytes(rtd_handle h) {
+  if (!h) return 0;
+  std::lock_guard<std::mutex> lk(h->mu);
+  int64_t t = 0;
+  for (auto& kv : h->plans) t += (int64_t)kv.second->arena_bytes;
+  return t;
+}
+
+void rtd_destroy(rtd_handle h) {
+  if (!h) return;
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& kv : h->plans) {
+      if (kv.second->exec) (void)hipGraphExecDestroy(kv.second->exec);
+      if (kv.second->graph) (void)hipGraphDestroy(kv.second->graph);
+    }
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->frame_stage) (void)hipFree(h->frame_stage);
+    if (h->resize_tmp) (void)hipFree(h->resize_tmp);
+    if (h->ptrs_host) (void)hipHostFree((void*)h->ptrs_host);
+    if (h->scale_host) (void)hipHostFree(h->scale_host);
+    if (h->block_host) (void)hipHostFree(h->block_host);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+  }
+  delete h;
+}
+
+int rtd_debug_tensor(rtd_handle h, const char* name, float* out, int64_t capacity, int64_t shape[4]) {
+  return guarded(h, [&] {
+    RTD_CHECK(name && shape && h->last_n > 0, RTD_E_STATE, "no forward has run");
+    Plan* p = h->plans[h->last_n].get();
+    auto it = p->named.find(name);
+    RTD_CHECK(it != p->named.end(), RTD_E_INVALID, std::string("unknown debug tensor ") + name);
+    const Tensor& t = it->second;
+    shape[0] = t.n; shape[1] = t.h; shape[2] = t.w; shape[3] = t.c;
+    const int64_t numel = t.pixels() * t.c;
+    if (!out) return;
+    RTD_CHECK(capacity >= numel, RTD_E_INVALID, "debug tensor: output capacity too small");
+    RTD_CHECK(t.bstride == (int64_t)t.h * t.w * t.ld, RTD_E_INVALID, "debug tensor: non-dense batch stride");
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    const size_t es = dtype_size(t.dt);
+    void* dense = nullptr;
+    float* f32 = nullptr;
+    HIP_CHECK(hipMalloc(&dense, (size_t)numel * es));
+    hipError_t er = hipMalloc((void**)&f32, (size_t)numel * 4);
+    if (er == hipSuccess) er = hipMemcpy2DAsync(dense, (size_t)t.c * es, t.p, (size_t)t.ld * es, (size_t)t.c * es, (size_t)t.pixels(), hipMemcpyDeviceToDevice, h->stream);
+    if (er == hipSuccess) {
+      launch_to_f32(dense, t.dt, f32, numel, h->stream);
+      er = hipMemcpyAsync(out, f32, (size_t)numel * 4, hipMemcpyDeviceToHost, h->stream);
+    }
+    if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
+    (void)hipFree(dense);
+    if (f32) (void)hipFree(f32);
+    HIP_CHECK(er);
+  });
+}
+
+int rtd_debug_force_topk(rtd_handle h, const int32_t* idx, int32_t n) {
+  return guarded(h, [&] {
+    RTD_CHECK(h->loaded, RTD_E_STATE, "weights not loaded");
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    int32_t flag = 0;
+    if (idx) {
+      RTD_CHECK(n >= 1 && n <= h->cfg.max_batch, RTD_E_INVALID, "batch size");
+      for (int64_t i = 0; i < (int64_t)n * h->cfg.num_queries; ++i)
+        RTD_CHECK(idx[i] >= 0 && idx[i] < h->S, RTD_E_INVALID, "forced token index out of range");
+      HIP_CHECK(hipMemcpyAsync(h->forced_idx, idx, (size_t)n * h->cfg.num_queries * 4, hipMemcpyHostToDevice, h->stream));
+      flag = 1;
+    }
+    HIP_CHECK(hipMemcpyAsync(h->force_flag, &flag, 4, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int32_t capacity, int32_t* count) {
+  return guarded(h, [&] {
+    check_n(h, n);
+    RTD_CHECK(count && reps >= 1, RTD_E_INVALID, "arguments");
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    Plan* p = get_plan(h, n);
+    const int nops = (int)p->ops.size();
+    *count = nops;
+    if (!out) return;
+    RTD_CHECK(capacity >= nops, RTD_E_INVALID, "profile: capacity too small");
+    std::vector<hipEvent_t> ev((size_t)nops + 1);
+    for (auto& x : ev) HIP_CHECK(hipEventCreate(&x));
+    std::vector<double> acc(nops, 0.0);
+    for (auto& op : p->ops) op.run(h->stream);   // warm-up
+    for (int r = 0; r < reps; ++r) {
+      HIP_CHECK(hipEventRecord(ev[0], h->stream));
+      for (int i = 0; i < nops; ++i) {
+        p->ops[i].run(h->stream);
+        HIP_CHECK(hipEventRecord(ev[i + 1], h->stream));
+      }
+      HIP_CHECK(hipStreamSynchronize(h->stream));
+      for (int i = 0; i < nops; ++i) {
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        acc[i] += ms;
+      }
+    }
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    for (int i = 0; i < nops; ++i) {
+      rtd_layer_time& t = out[i];
+      memset(&t, 0, sizeof t);
+      strncpy(t.name, p->ops[i].name.c_str(), sizeof(t.name) - 1);
+      strncpy(t.kernel, p->ops[i].kernel, sizeof(t.kernel) - 1);
+      t.ms = (float)(acc[i] / reps);
+      t.flops = p->ops[i].flops;
+      t.bytes = p->ops[i].bytes;
+    }
+  });
+}
+
+// ---- kernel-level test entry points ---------------------------------------------------------------
+int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* bias, const void* res, void* y, int B, int H,
+                int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int act, int res_mode, int out_f32) {
+  return op_guard([&] {
+    RTD_CHECK(KH == KW, RTD_E_INVALID, "square filters only");
+    const int K = KH * KW * Cin, Kpad = conv_kpad(K), Npad = conv_npad(Cout);
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    float* wpad = nullptr; void* wdev = nullptr; float* bpad = nullptr;
+    HIP_CHECK(hipMalloc((void**)&wpad, (size_t)Npad * Kpad * 4));
+    HIP_CHECK(hipMemset(wpad, 0, (size_t)Npad * Kpad * 4));
+    HIP_CHECK(hipMemcpy2D(wpad, (size_t)Kpad * 4, w_ohwi_f32, (size_t)K * 4, (size_t)K * 4, Cout, hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipMalloc((void**)&bpad, (size_t)Npad * 4));
+    HIP_CHECK(hipMemset(bpad, 0, (size_t)Npad * 4));
+    HIP_CHECK(hipMemcpy(bpad, bias, (size_t)Cout * 4, hipMemcpyDeviceToDevice));
+    if (dtype == BF16) {
+      HIP_CHECK(hipMalloc(&wdev, (size_t)Npad * Kpad * 2));
+      launch_f32_to(wpad, wdev, BF16, (int64_t)Npad * Kpad, nullptr);
+    } else wdev = wpad;
+    ConvArgs a;
+    a.x = mk(x, dtype, B, H, W, Cin);
+    a.y = mk(y, out_f32 ? F32 : dtype, B, OH, OW, Cout);
+    a.w = wdev; a.bias = bpad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.Npad = Npad;
+    a.act = act; a.res_mode = res ? res_mode : RES_NONE;
+    if (res) a.res = mk(res, dtype, B, OH, OW, Cout);
+    launch_conv(a, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    if (wdev != wpad) (void)hipFree(wdev);
+    (void)hipFree(wpad); (void)hipFree(bpad);
+  });
+}
+
+int rtd_op_layernorm(int dtype, const void* x, const void* res, const float* g, const float* b, void* y, int rows, int dim, int out_f32) {
+  return op_guard([&] {
+    Tensor tx = mk(x, dtype, 1, rows, 1, dim), ty = mk(y, out_f32 ? F32 : dtype, 1, rows, 1, dim), tr = mk(res, dtype, 1, rows, 1, dim);
+    launch_layernorm(tx, res ? &tr : nullptr, g, b, ty, 1e-5f, nullptr);
+  });
+}
+
+int rtd_op_attention(int dtype, const void* qk, const void* v, void* o, int B, int L, int heads, int hd) {
+  return op_guard([&] {
+    const int D = heads * hd;
+    launch_attention(mk(qk, dtype, B, L, 1, 2 * D), mk(v, dtype, B, L, 1, D), mk(o, dtype, B, L, 1, D), heads, nullptr);
+  });
+}
+
+int rtd_op_msdeform(int dtype, const void* value, const float* offaw, const float* ref, float* out, int B, int Q, int heads, int hd,
+                    int n_levels, int n_points, const int32_t* level_hw, int value_ld, float offset_scale) {
+  return op_guard([&] {
+    RTD_CHECK(n_levels >= 1 && n_levels <= 8, RTD_E_INVALID, "n_levels");
+    int32_t lv[24]; int S = 0;
+    for (int l = 0; l < n_levels; ++l) { lv[l * 3] = level_hw[2 * l]; lv[l * 3 + 1] = level_hw[2 * l + 1]; lv[l * 3 + 2] = S; S += level_hw[2 * l] * level_hw[2 * l + 1]; }
+    int32_t* lvd = nullptr; float* ref8 = nullptr;
+    HIP_CHECK(hipMalloc((void**)&lvd, sizeof lv));
+    HIP_CHECK(hipMemcpy(lvd, lv, sizeof lv, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMalloc((void**)&ref8, (size_t)B * Q * 32));
+    HIP_CHECK(hipMemset(ref8, 0, (size_t)B * Q * 32));
+    HIP_CHECK(hipMemcpy2D(ref8, 32, ref, 16, 16, (size_t)B * Q, hipMemcpyDeviceToDevice));
+    Tensor tv = mk(value, dtype, B, S, 1, heads * hd);
+    tv.ld = value_ld; tv.bstride = (int64_t)S * value_ld;
+    launch_msdeform(tv, 0, mk(offaw, F32, B, Q, 1, heads * n_levels * n_points * 3), ref8, mk(out, F32, B, Q, 1, heads * hd), heads, hd,
+                    n_levels, n_points, lvd, offset_scale, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    (void)hipFree(lvd); (void)hipFree(ref8);
+  });
+}
+
+int rtd_op_topk(const float* keys, int B, int N, int K, int32_t* idx_out, float* val_out) {
+  return op_guard([&] { launch_topk(keys, B, N, K, idx_out, val_out, nullptr); });
+}
+
+int rtd_op_resize(const uint8_t* src, int sh, int sw, void* dst, int dh, int dw, int dtype) {
+  return op_guard([&] {
+    std::vector<int32_t> hb, hk, vb, vk;
+    int hks, vks;
+    pil_coeffs(sw, dw, hb, hk, hks);
+    pil_coeffs(sh, dh, vb, vk, vks);
+    std::vector<void*> tmp;
+    auto up = [&](const std::vector<int32_t>& v) {
+      void* d = nullptr;
+      HIP_CHECK(hipMalloc(&d, v.size() * 4));
+      tmp.push_back(d);
+      HIP_CHECK(hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+      return (const int32_t*)d;
+    };
+    ResizeCoef c;
+    c.hb = up(hb); c.hk = up(hk); c.vb = up(vb); c.vk = up(vk); c.hks = hks; c.vks = vks;
+    uint8_t* t = nullptr;
+    HIP_CHECK(hipMalloc((void**)&t, (size_t)sh * dw * 3));
+    tmp.push_back(t);
+    launch_resize_pil(src, sh, sw, t, mk(dst, dtype, 1, dh, dw, 8), 0, c, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    for (void* p : tmp) (void)hipFree(p);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,721 @@
+// ops.hip - every non-GEMM kernel of the RT-DETRv2 path for gfx950 (wave = 64 lanes).
+//
+// These are HBM/L2-bound byte-moving or small fp32 kernels: coalesced 16-byte accesses along the
+// NHWC channel dimension, fp32 arithmetic regardless of the storage type, no MFMA reshaping.
+#include <float.h>
+
+#include "common.h"
+
+namespace rtd {
+
+// ------------------------------------------------------------------------------------------ helpers
+template <typename T> __device__ __forceinline__ float ldf(const T* p) { return (float)(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v) { *p = (T)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+#define DISPATCH_T(dt, ...)                     \
+  do {                                          \
+    if ((dt) == BF16) { typedef bf16 T; __VA_ARGS__; } \
+    else { typedef float T; __VA_ARGS__; }      \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------ dtype conversion
+template <typename T>
+__global__ void k_f32_to(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (T)src[i];
+}
+template <typename T>
+__global__ void k_to_f32(const T* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+void launch_f32_to(const float* src, void* dst, int dt, int64_t n, hipStream_t s) {
+  if (n == 0) return;
+  DISPATCH_T(dt, hipLaunchKernelGGL(k_f32_to<T>, dim3(blocks_for(n, 256)), dim3(256), 0, s, src, (T*)dst, n));
+  HIP_CHECK(hipGetLastError());
+}
+void launch_to_f32(const void* src, int dt, float* dst, int64_t n, hipStream_t s) {
+  if (n == 0) return;
+  DISPATCH_T(dt, hipLaunchKernelGGL(k_to_f32<T>, dim3(blocks_for(n, 256)), dim3(256), 0, s, (const T*)src, dst, n));
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ layer norm
+// y = LN(x (+ res)) * g + b over the last dim; one wave per row.  torch.nn.functional.layer_norm
+// semantics (biased variance, eps inside the sqrt).  HF:v2.py:861,886 (post-norm residual blocks).
+template <typename TX, typename TR, typename TY>
+__global__ __launch_bounds__(256) void k_layernorm(const TX* __restrict__ x, int64_t ldx, const TR* __restrict__ r,
+                                                    int64_t ldr, const float* __restrict__ g,
+                                                    const float* __restrict__ bta, TY* __restrict__ y, int64_t ldy,
+                                                    int rows, int dim, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  constexpr int MAXE = 16;  // dim <= 1024
+  float v[MAXE];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXE; ++i) {
+    const int c = lane + i * 64;
+    float t = 0.f;
+    if (c < dim) {
+      t = ldf(x + (int64_t)row * ldx + c);
+      if (r) t += ldf(r + (int64_t)row * ldr + c);
+    }
+    v[i] = t;
+    sum += t;
+  }
+  const float mean = wave_sum(sum) / (float)dim;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXE; ++i) {
+    const int c = lane + i * 64;
+    const float d = (c < dim) ? (v[i] - mean) : 0.f;
+    sq += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)dim + eps);
+#pragma unroll
+  for (int i = 0; i < MAXE; ++i) {
+    const int c = lane + i * 64;
+    if (c < dim) stf(y + (int64_t)row * ldy + c, (v[i] - mean) * rstd * g[c] + bta[c]);
+  }
+}
+
+void launch_layernorm(const Tensor& x, const Tensor* res, const float* g, const float* b, const Tensor& y, float eps,
+                      hipStream_t s) {
+  const int rows = (int)x.pixels(), dim = x.c;
+  RTD_CHECK(dim <= 1024 && y.c == dim && y.pixels() == rows, 1, "layernorm: shape");
+  RTD_CHECK(x.bstride == (int64_t)x.h * x.w * x.ld && y.bstride == (int64_t)y.h * y.w * y.ld, 1, "layernorm: dense rows");
+  if (res) RTD_CHECK(res->c == dim && res->pixels() == rows && res->bstride == (int64_t)res->h * res->w * res->ld, 1, "layernorm: residual");
+  const dim3 grid((rows + 3) / 4), blk(256);
+#define LN_GO(TX, TR, TY)                                                                                   \
+  hipLaunchKernelGGL((k_layernorm<TX, TR, TY>), grid, blk, 0, s, (const TX*)x.p, x.ld,                       \
+                     (const TR*)(res ? res->p : nullptr), res ? res->ld : 0, g, b, (TY*)y.p, y.ld, rows, dim, eps)
+  const int rdt = res ? res->dt : x.dt;
+  const int key = (x.dt == F32) * 4 + (rdt == F32) * 2 + (y.dt == F32);
+  switch (key) {
+    case 0: LN_GO(bf16, bf16, bf16); break;
+    case 1: LN_GO(bf16, bf16, float); break;
+    case 2: LN_GO(bf16, float, bf16); break;
+    case 3: LN_GO(bf16, float, float); break;
+    case 4: LN_GO(float, bf16, bf16); break;
+    case 5: LN_GO(float, bf16, float); break;
+    case 6: LN_GO(float, float, bf16); break;
+    default: LN_GO(float, float, float); break;
+  }
+#undef LN_GO
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ add (x + pos)
+// y[b,p,c] = a[b,p,c] + pos[(b or 0),p,c]   - the "(hidden + position_embeddings)" of HF:v2.py:319
+template <typename TA, typename TB, typename TY>
+__global__ void k_add(const TA* __restrict__ a, const TB* __restrict__ b, TY* __restrict__ y, int64_t per_image,
+                      int64_t total, int b_broadcast) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t j = b_broadcast ? (i % per_image) : i;
+  y[i] = (TY)((float)a[i] + (float)b[j]);
+}
+void launch_add(const Tensor& a, const Tensor& b, const Tensor& y, hipStream_t s) {
+  RTD_CHECK(a.ld == a.c && b.ld == b.c && y.ld == y.c && a.c == b.c && a.c == y.c, 1, "add: dense tensors");
+  const int64_t per = (int64_t)a.h * a.w * a.c, total = per * a.n;
+  RTD_CHECK((b.n == 1 || b.n == a.n) && (int64_t)b.h * b.w * b.c == per && y.pixels() == a.pixels(), 1, "add: shape");
+  const dim3 grid(blocks_for(total, 256)), blk(256);
+  const int bb = (b.n == 1 && a.n != 1);
+#define ADD_GO(TA, TB, TY) hipLaunchKernelGGL((k_add<TA, TB, TY>), grid, blk, 0, s, (const TA*)a.p, (const TB*)b.p, (TY*)y.p, per, total, bb)
+  const int key = (a.dt == F32) * 4 + (b.dt == F32) * 2 + (y.dt == F32);
+  switch (key) {
+    case 0: ADD_GO(bf16, bf16, bf16); break;
+    case 1: ADD_GO(bf16, bf16, float); break;
+    case 2: ADD_GO(bf16, float, bf16); break;
+    case 3: ADD_GO(bf16, float, float); break;
+    case 4: ADD_GO(float, bf16, bf16); break;
+    case 5: ADD_GO(float, bf16, float); break;
+    case 6: ADD_GO(float, float, bf16); break;
+    default: ADD_GO(float, float, float); break;
+  }
+#undef ADD_GO
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ max-pool 3x3 s2 p1
+// HF:rt_detr_resnet.py:103 nn.MaxPool2d(3, 2, 1); padding counts as -inf.  4 channels per thread.
+template <typename T>
+__global__ void k_maxpool(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int64_t ldx, int OH,
+                          int OW, int64_t ldy) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C / 4;
+  const int64_t total = (int64_t)B * OH * OW * c4;
+  if (i >= total) return;
+  const int cc = (int)(i % c4) * 4;
+  int64_t p = i / c4;
+  const int ox = (int)(p % OW); p /= OW;
+  const int oy = (int)(p % OH);
+  const int b = (int)(p / OH);
+  float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = oy * 2 - 1 + dy;
+    if ((unsigned)iy >= (unsigned)H) continue;
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = ox * 2 - 1 + dx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const T* q = x + (((int64_t)b * H + iy) * W + ix) * ldx + cc;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], (float)q[k]);
+    }
+  }
+  T* o = y + (((int64_t)b * OH + oy) * OW + ox) * ldy + cc;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (T)m[k];
+}
+void launch_maxpool3x3s2(const Tensor& x, const Tensor& y, hipStream_t s) {
+  RTD_CHECK(x.dt == y.dt && x.c == y.c && x.c % 4 == 0 && x.n == y.n, 1, "maxpool: dtype/channels");
+  RTD_CHECK(y.h == (x.h + 2 - 3) / 2 + 1 && y.w == (x.w + 2 - 3) / 2 + 1, 1, "maxpool: shape");
+  RTD_CHECK(x.bstride == (int64_t)x.h * x.w * x.ld && y.bstride == (int64_t)y.h * y.w * y.ld, 1, "maxpool: dense images");
+  const int64_t total = (int64_t)y.n * y.h * y.w * (y.c / 4);
+  DISPATCH_T(x.dt, hipLaunchKernelGGL(k_maxpool<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const T*)x.p, (T*)y.p,
+                                      x.n, x.h, x.w, x.c, x.ld, y.h, y.w, y.ld));
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ nearest 2x upsample
+// F.interpolate(scale_factor=2, mode="nearest") (HF:v2.py:1191), written straight into the first
+// channel half of the FPN concat buffer (y is a channel-slice view).
+template <typename T>
+__global__ void k_upsample2x(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int64_t ldx,
+                             int64_t ldy) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C / 4;
+  const int OH = 2 * H, OW = 2 * W;
+  const int64_t total = (int64_t)B * OH * OW * c4;
+  if (i >= total) return;
+  const int cc = (int)(i % c4) * 4;
+  int64_t p = i / c4;
+  const int ox = (int)(p % OW); p /= OW;
+  const int oy = (int)(p % OH);
+  const int b = (int)(p / OH);
+  const T* q = x + (((int64_t)b * H + (oy >> 1)) * W + (ox >> 1)) * ldx + cc;
+  T* o = y + (((int64_t)b * OH + oy) * OW + ox) * ldy + cc;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = q[k];
+}
+void launch_upsample2x(const Tensor& x, const Tensor& y, hipStream_t s) {
+  RTD_CHECK(x.dt == y.dt && x.c == y.c && x.c % 4 == 0 && y.h == 2 * x.h && y.w == 2 * x.w && x.n == y.n, 1, "upsample: shape");
+  RTD_CHECK(x.bstride == (int64_t)x.h * x.w * x.ld && y.bstride == (int64_t)y.h * y.w * y.ld, 1, "upsample: dense images");
+  const int64_t total = (int64_t)y.n * y.h * y.w * (y.c / 4);
+  DISPATCH_T(x.dt, hipLaunchKernelGGL(k_upsample2x<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const T*)x.p,
+                                      (T*)y.p, x.n, x.h, x.w, x.c, x.ld, y.ld));
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ multi-head attention
+// HF:v2.py:246-270 eager attention: softmax(q k^T * hd^-0.5) v, no mask.  One thread owns one query
+// row (q and the output accumulator live in registers, fp32), keys/values are staged through LDS in
+// tiles of 64 and read as wave-wide broadcasts; online softmax.  L is 300..1600 here, so the whole
+// problem is a few GFLOP - fp32 VALU keeps the decoder in exact-fp32 territory.
+template <typename T, int HD>
+__global__ __launch_bounds__(128) void k_attention(const T* __restrict__ qk, int64_t ldqk, const T* __restrict__ v,
+                                                    int64_t ldv, T* __restrict__ o, int64_t ldo, int L, int D) {
+  constexpr int KT = 64;
+  __shared__ float Ks[KT * HD];
+  __shared__ float Vs[KT * HD];
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int qi = blockIdx.x * 128 + threadIdx.x;
+  const bool active = qi < L;
+  const float scale = rsqrtf((float)HD);
+  float q[HD], acc[HD];
+  const T* qrow = qk + ((int64_t)b * L + (active ? qi : 0)) * ldqk + head * HD;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    q[d] = (float)qrow[d] * scale;
+    acc[d] = 0.f;
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int k0 = 0; k0 < L; k0 += KT) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < KT * HD; e += 128) {
+      const int j = e / HD, d = e - j * HD;
+      const int kj = k0 + j;
+      float kv = 0.f, vv = 0.f;
+      if (kj < L) {
+        kv = (float)qk[((int64_t)b * L + kj) * ldqk + D + head * HD + d];
+        vv = (float)v[((int64_t)b * L + kj) * ldv + head * HD + d];
+      }
+      Ks[e] = kv;
+      Vs[e] = vv;
+    }
+    __syncthreads();
+    const int jn = min(KT, L - k0);
+    for (int j = 0; j < jn; ++j) {
+      float sc = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) sc = fmaf(q[d], Ks[j * HD + d], sc);
+      if (sc > m) {
+        const float f = __expf(m - sc);
+        l *= f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] *= f;
+        m = sc;
+      }
+      const float p = __expf(sc - m);
+      l += p;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) acc[d] = fmaf(p, Vs[j * HD + d], acc[d]);
+    }
+  }
+  if (active) {
+    const float inv = 1.f / l;
+    T* orow = o + ((int64_t)b * L + qi) * ldo + head * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) orow[d] = (T)(acc[d] * inv);
+  }
+}
+
+void launch_attention(const Tensor& qk, const Tensor& v, const Tensor& o, int heads, hipStream_t s) {
+  const int B = qk.n, L = qk.h * qk.w, D = v.c;
+  RTD_CHECK(qk.c == 2 * D && o.c == D && v.n == B && o.n == B && v.h * v.w == L && o.h * o.w == L, 1, "attention: shape");
+  RTD_CHECK(qk.dt == v.dt && qk.dt == o.dt, 1, "attention: dtype");
+  RTD_CHECK(D % heads == 0, 1, "attention: heads");
+  const int hd = D / heads;
+  const dim3 grid((L + 127) / 128, heads, B), blk(128);
+#define ATT_GO(HD) DISPATCH_T(qk.dt, hipLaunchKernelGGL((k_attention<T, HD>), grid, blk, 0, s, (const T*)qk.p, qk.ld, (const T*)v.p, v.ld, (T*)o.p, o.ld, L, D))
+  if (hd == 32) ATT_GO(32);
+  else if (hd == 48) ATT_GO(48);
+  else if (hd == 64) ATT_GO(64);
+  else RTD_CHECK(false, 1, "attention: head dim must be 32, 48 or 64");
+#undef ATT_GO
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ masked-anchor rows
+// memory = valid_mask * src  (HF:v2.py:1583): a masked row makes enc_output's Linear return its bias.
+template <typename T>
+__global__ void k_set_rows(T* __restrict__ y, int64_t ld, int C, const int32_t* __restrict__ rows, int nrows,
+                           int rows_per_image, const float* __restrict__ vec, int B) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * nrows * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int64_t t = i / C;
+  const int r = rows[t % nrows];
+  const int b = (int)(t / nrows);
+  y[((int64_t)b * rows_per_image + r) * ld + c] = (T)vec[c];
+}
+void launch_set_rows(const Tensor& y, const int32_t* rows, int nrows, int rows_per_image, const float* vec, hipStream_t s) {
+  if (nrows == 0) return;
+  const int64_t total = (int64_t)y.n * nrows * y.c;
+  DISPATCH_T(y.dt, hipLaunchKernelGGL(k_set_rows<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (T*)y.p, y.ld, y.c, rows,
+                                      nrows, rows_per_image, vec, y.n));
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ row max
+// enc_outputs_class.max(-1).values (HF:v2.py:1590); 16 lanes per row.
+__global__ void k_rowmax(const float* __restrict__ x, int64_t ld, int C, int64_t rows, float* __restrict__ out) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = gid >> 4;
+  const int j = (int)(gid & 15);
+  float m = -INFINITY;
+  if (row < rows)
+    for (int c = j; c < C; c += 16) m = fmaxf(m, x[row * ld + c]);
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (row < rows && j == 0) out[row] = m;
+}
+void launch_rowmax(const Tensor& x, float* out, hipStream_t s) {
+  RTD_CHECK(x.dt == F32, 1, "rowmax: fp32 logits expected");
+  const int64_t rows = x.pixels();
+  hipLaunchKernelGGL(k_rowmax, dim3(blocks_for(rows * 16, 256)), dim3(256), 0, s, (const float*)x.p, x.ld, x.c, rows, out);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ exact top-k
+// torch.topk(keys, K, dim=1) for K <= 1024 (HF:v2.py:1590 and image_processing_rt_detr.py:527):
+// one workgroup per image; 4-pass 8-bit radix select of the K-th largest key, deterministic
+// compaction (ties: lowest index first), bitonic sort of the K survivors by (key desc, index asc).
+__device__ __forceinline__ unsigned f2key(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+  const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+__global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ keys, int N, int K, int32_t* __restrict__ idx_out,
+                                                float* __restrict__ val_out) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned long long sel[1024];
+  __shared__ unsigned s_prefix, s_krem, s_cnt_gt, s_cnt_eq;
+  __shared__ unsigned wave_cnt[16];
+  const int tid = threadIdx.x;
+  const float* kb = keys + (int64_t)blockIdx.x * N;
+  if (tid == 0) { s_prefix = 0; s_krem = (unsigned)K; s_cnt_gt = 0; s_cnt_eq = 0; }
+  __syncthreads();
+  // ---- radix select: after the loop s_prefix is the key of the K-th largest element ------------
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    const unsigned mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+    for (int i = tid; i < N; i += 1024) {
+      const unsigned k = f2key(kb[i]);
+      if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned rem = s_krem, d = 255;
+      for (;; --d) {
+        const unsigned c = hist[d];
+        if (c >= rem || d == 0) break;
+        rem -= c;
+      }
+      s_krem = rem;                     // rank of the target inside bucket d (1-based)
+      s_prefix = prefix | (d << shift);
+    }
+    __syncthreads();
+  }
+  const unsigned T = s_prefix;
+  const unsigned need_eq = s_krem;      // how many elements equal to T are taken (lowest indices)
+  for (int i = tid; i < 1024; i += 1024) sel[i] = 0ull;
+  __syncthreads();
+  // ---- compaction: strictly greater (any order), then equal in index order ---------------------
+  for (int i = tid; i < N; i += 1024) {
+    const unsigned k = f2key(kb[i]);
+    if (k > T) {
+      const unsigned pos = atomicAdd(&s_cnt_gt, 1u);
+      if (pos < 1024) sel[pos] = ((unsigned long long)k << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+    }
+  }
+  __syncthreads();
+  const unsigned n_gt = s_cnt_gt;       // == K - need_eq
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int base = 0; base < N; base += 1024) {
+    const int i = base + tid;
+    const bool eq = (i < N) && (f2key(kb[i]) == T);
+    const unsigned long long bal = __ballot(eq);
+    if (lane == 0) wave_cnt[wv] = (unsigned)__popcll(bal);
+    __syncthreads();
+    unsigned before = s_cnt_eq;
+    for (int w = 0; w < wv; ++w) before += wave_cnt[w];
+    const unsigned my = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+    if (eq && my < need_eq && n_gt + my < 1024)
+      sel[n_gt + my] = ((unsigned long long)T << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+    __syncthreads();
+    if (tid == 0) {
+      unsigned tot = 0;
+      for (int w = 0; w < 16; ++w) tot += wave_cnt[w];
+      s_cnt_eq += tot;
+    }
+    __syncthreads();
+    if (s_cnt_eq >= need_eq) break;
+  }
+  __syncthreads();
+  // ---- bitonic sort, descending, 1024 slots (unused slots are 0 and sink to the end) -----------
+  for (int k = 2; k <= 1024; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int ixj = tid ^ j;
+      if (ixj > tid) {
+        const unsigned long long a = sel[tid], b = sel[ixj];
+        const bool desc = (tid & k) == 0;
+        if (desc ? (a < b) : (a > b)) { sel[tid] = b; sel[ixj] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid < K) {
+    const unsigned long long e = sel[tid];
+    idx_out[(int64_t)blockIdx.x * K + tid] = (int32_t)(0xffffffffu - (unsigned)(e & 0xffffffffu));
+    if (val_out) val_out[(int64_t)blockIdx.x * K + tid] = key2f((unsigned)(e >> 32));
+  }
+}
+void launch_topk(const float* keys, int B, int N, int K, int32_t* idx, float* vals, hipStream_t s) {
+  RTD_CHECK(K >= 1 && K <= 1024 && K <= N, 1, "topk: K must be in [1, min(1024, N)]");
+  hipLaunchKernelGGL(k_topk, dim3(B), dim3(1024), 0, s, keys, N, K, idx, vals);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ gather rows
+// target = output_memory.gather(topk_ind) (HF:v2.py:1609)
+template <typename TS, typename TD>
+__global__ void k_gather_rows(const TS* __restrict__ src, int64_t lds_, int rows_per_image, const int32_t* __restrict__ idx,
+                              int Q, int C, TD* __restrict__ dst, int64_t ldd, int B) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * Q * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int64_t t = i / C;
+  const int b = (int)(t / Q);
+  int r = idx[t];
+  r = min(max(r, 0), rows_per_image - 1);
+  dst[t * ldd + c] = (TD)(float)src[((int64_t)b * rows_per_image + r) * lds_ + c];
+}
+void launch_gather_rows(const Tensor& src, const int32_t* idx, int rows_per_image, const Tensor& dst, hipStream_t s) {
+  const int B = dst.n, Q = dst.h * dst.w, C = dst.c;
+  RTD_CHECK(src.c == C && src.n == B && src.h * src.w == rows_per_image, 1, "gather: shape");
+  const int64_t total = (int64_t)B * Q * C;
+  const dim3 grid(blocks_for(total, 256)), blk(256);
+#define G_GO(TS, TD) hipLaunchKernelGGL((k_gather_rows<TS, TD>), grid, blk, 0, s, (const TS*)src.p, src.ld, rows_per_image, idx, Q, C, (TD*)dst.p, dst.ld, B)
+  if (src.dt == BF16 && dst.dt == BF16) G_GO(bf16, bf16);
+  else if (src.dt == BF16) G_GO(bf16, float);
+  else if (dst.dt == BF16) G_GO(float, bf16);
+  else G_GO(float, float);
+#undef G_GO
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ reference boxes
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float inv_sigmoid(float x) {   // HF:v2.py:548-552, eps 1e-5
+  x = fminf(fmaxf(x, 0.f), 1.f);
+  const float x1 = fmaxf(x, 1e-5f), x2 = fmaxf(1.f - x, 1e-5f);
+  return __logf(x1 / x2);
+}
+// reference_points_unact = enc_bbox_head(target) + anchors[topk] ; reference = sigmoid(.)  (HF:v2.py:1588-1599,609)
+__global__ void k_ref_init(const float* __restrict__ delta, int64_t ldd, const float* __restrict__ anchors,
+                           const int32_t* __restrict__ idx, int S, float* __restrict__ ref_unact8, float* __restrict__ ref8,
+                           int64_t total) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  int r = idx[t];
+  r = min(max(r, 0), S - 1);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float u = delta[t * ldd + k] + anchors[(int64_t)r * 4 + k];
+    ref_unact8[t * 8 + k] = u;
+    ref8[t * 8 + k] = sigmoidf_(u);
+    ref_unact8[t * 8 + 4 + k] = 0.f;
+    ref8[t * 8 + 4 + k] = 0.f;
+  }
+}
+void launch_ref_init(const Tensor& boxdelta, const float* anchors, const int32_t* idx, int S, float* ref_unact8, float* ref8,
+                     hipStream_t s) {
+  RTD_CHECK(boxdelta.dt == F32 && boxdelta.c == 4, 1, "ref_init: fp32 [.,4] deltas expected");
+  const int64_t total = boxdelta.pixels();
+  hipLaunchKernelGGL(k_ref_init, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const float*)boxdelta.p, boxdelta.ld, anchors,
+                     idx, S, ref_unact8, ref8, total);
+  HIP_CHECK(hipGetLastError());
+}
+// new_reference = sigmoid(bbox_embed(hs) + inverse_sigmoid(reference))   (HF:v2.py:636-639)
+__global__ void k_box_refine(const float* __restrict__ delta, int64_t ldd, float* __restrict__ ref8, int64_t total) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ref8[t * 8 + k] = sigmoidf_(delta[t * ldd + k] + inv_sigmoid(ref8[t * 8 + k]));
+}
+void launch_box_refine(const Tensor& delta, float* ref8, hipStream_t s) {
+  RTD_CHECK(delta.dt == F32 && delta.c == 4, 1, "box_refine: fp32 [.,4] deltas expected");
+  const int64_t total = delta.pixels();
+  hipLaunchKernelGGL(k_box_refine, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const float*)delta.p, delta.ld, ref8, total);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ MS-deformable sampling
+// HF:v2.py:44-115,186-221 (method "default"): for each (b, query, head): softmax over the
+// n_levels*n_points attention logits, sampling location = ref_xy + off/n_points * ref_wh * offset_scale,
+// grid_sample(bilinear, padding zeros, align_corners=False) of that head's 32-channel value rows.
+// 32 lanes = the 32 channels of one (b, q, head): each bilinear tap is one coalesced 64/128-byte row read.
+template <typename TV, typename TO>
+__global__ __launch_bounds__(256) void k_msdeform(const TV* __restrict__ value, int64_t ldv, int64_t v_bstride,
+                                                   const float* __restrict__ offaw, int64_t ldoa,
+                                                   const float* __restrict__ ref8, TO* __restrict__ out, int64_t ldo,
+                                                   int Q, int heads, int n_levels, int n_points,
+                                                   const int32_t* __restrict__ lvl, float offset_scale, int64_t items) {
+  const int64_t item = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);   // (b, q, head)
+  const int ch = threadIdx.x & 31;
+  if (item >= items) return;
+  const int head = (int)(item % heads);
+  const int64_t bq = item / heads;
+  const int b = (int)(bq / Q);
+  const int LP = n_levels * n_points;
+  const float* oa = offaw + bq * ldoa;
+  const float* offs = oa + (int64_t)head * LP * 2;
+  const float* awl = oa + (int64_t)heads * LP * 2 + (int64_t)head * LP;
+  float mx = -INFINITY;
+  for (int i = 0; i < LP; ++i) mx = fmaxf(mx, awl[i]);
+  float den = 0.f;
+  for (int i = 0; i < LP; ++i) den += __expf(awl[i] - mx);
+  const float inv_den = 1.f / den;
+  const float rx = ref8[bq * 8 + 0], ry = ref8[bq * 8 + 1], rw = ref8[bq * 8 + 2], rh = ref8[bq * 8 + 3];
+  const float pscale = 1.f / (float)n_points;
+  const TV* vb = value + (int64_t)b * v_bstride + head * 32 + ch;
+  float acc = 0.f;
+  for (int l = 0; l < n_levels; ++l) {
+    const int H = lvl[l * 3 + 0], W = lvl[l * 3 + 1], start = lvl[l * 3 + 2];
+    for (int p = 0; p < n_points; ++p) {
+      const int i = l * n_points + p;
+      const float aw = __expf(awl[i] - mx) * inv_den;
+      const float lx = rx + offs[i * 2 + 0] * pscale * rw * offset_scale;
+      const float ly = ry + offs[i * 2 + 1] * pscale * rh * offset_scale;
+      const float gx = 2.f * lx - 1.f, gy = 2.f * ly - 1.f;                 // sampling_grids = 2*loc - 1
+      const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;                // align_corners=False unnormalise
+      const float iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+      const float wx1 = ix - fx, wy1 = iy - fy, wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy;
+      float sv = 0.f;
+      const bool okx0 = (unsigned)x0 < (unsigned)W, okx1 = (unsigned)x1 < (unsigned)W;
+      const bool oky0 = (unsigned)y0 < (unsigned)H, oky1 = (unsigned)y1 < (unsigned)H;
+      if (oky0 && okx0) sv += (float)vb[(int64_t)(start + y0 * W + x0) * ldv] * (wx0 * wy0);
+      if (oky0 && okx1) sv += (float)vb[(int64_t)(start + y0 * W + x1) * ldv] * (wx1 * wy0);
+      if (oky1 && okx0) sv += (float)vb[(int64_t)(start + y1 * W + x0) * ldv] * (wx0 * wy1);
+      if (oky1 && okx1) sv += (float)vb[(int64_t)(start + y1 * W + x1) * ldv] * (wx1 * wy1);
+      acc += sv * aw;
+    }
+  }
+  out[bq * ldo + head * 32 + ch] = (TO)acc;
+}
+void launch_msdeform(const Tensor& value, int value_coff, const Tensor& offaw, const float* ref8, const Tensor& out, int heads,
+                     int hd, int n_levels, int n_points, const int32_t* level_hw_start, float offset_scale, hipStream_t s) {
+  RTD_CHECK(hd == 32, 1, "msdeform: head dim must be 32");
+  RTD_CHECK(offaw.dt == F32 && offaw.c == heads * n_levels * n_points * 3, 1, "msdeform: offsets|weights layout");
+  RTD_CHECK(out.c == heads * hd && out.pixels() == offaw.pixels(), 1, "msdeform: output shape");
+  const int B = out.n, Q = out.h * out.w;
+  const int64_t items = (int64_t)B * Q * heads;
+  const dim3 grid(blocks_for(items, 8)), blk(256);
+  const char* vp = (const char*)value.p + (size_t)value_coff * dtype_size(value.dt);
+#define MS_GO(TV, TO) hipLaunchKernelGGL((k_msdeform<TV, TO>), grid, blk, 0, s, (const TV*)vp, value.ld, value.bstride, (const float*)offaw.p, offaw.ld, ref8, (TO*)out.p, out.ld, Q, heads, n_levels, n_points, level_hw_start, offset_scale, items)
+  if (value.dt == BF16 && out.dt == BF16) MS_GO(bf16, bf16);
+  else if (value.dt == BF16) MS_GO(bf16, float);
+  else if (out.dt == BF16) MS_GO(float, bf16);
+  else MS_GO(float, float);
+#undef MS_GO
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ post-process
+// RTDETRPostProcessor (deploy) == HF:rt_detr/image_processing_rt_detr.py:510-533
+__global__ void k_pp_scores(const float* __restrict__ logits, int64_t ld, int C, int64_t rows, float* __restrict__ scores) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  const int64_t r = i / C;
+  const int c = (int)(i - r * C);
+  scores[i] = sigmoidf_(logits[r * ld + c]);
+}
+void launch_postprocess_scores(const Tensor& logits, float* scores, hipStream_t s) {
+  RTD_CHECK(logits.dt == F32, 1, "postprocess: fp32 logits expected");
+  const int64_t rows = logits.pixels();
+  hipLaunchKernelGGL(k_pp_scores, dim3(blocks_for(rows * logits.c, 256)), dim3(256), 0, s, (const float*)logits.p, logits.ld,
+                     logits.c, rows, scores);
+  HIP_CHECK(hipGetLastError());
+}
+// labels = index % C ; query = index // C ; boxes = cxcywh->xyxy * (w,h,w,h) of the ORIGINAL frame
+__global__ void k_pp_gather(const float* __restrict__ topv, const int32_t* __restrict__ topi, const float* __restrict__ ref8,
+                            const float* __restrict__ scale_wh, int Q, int C, float* __restrict__ block6, int64_t total) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int b = (int)(t / Q);
+  const int idx = topi[t];
+  const int label = idx % C;
+  int q = idx / C;
+  q = min(max(q, 0), Q - 1);
+  const float* r = ref8 + ((int64_t)b * Q + q) * 8;
+  const float cx = r[0], cy = r[1], w = r[2], h = r[3];
+  const float sw = scale_wh[b * 2 + 0], sh = scale_wh[b * 2 + 1];
+  float* o = block6 + t * 6;
+  o[0] = (float)label;
+  o[1] = topv[t];
+  o[2] = (cx - 0.5f * w) * sw;
+  o[3] = (cy - 0.5f * h) * sh;
+  o[4] = (cx + 0.5f * w) * sw;
+  o[5] = (cy + 0.5f * h) * sh;
+}
+void launch_postprocess_gather(const float* topv, const int32_t* topi, const float* ref8, const float* scale_wh, int B, int Q,
+                               int C, float* block6, hipStream_t s) {
+  const int64_t total = (int64_t)B * Q;
+  hipLaunchKernelGGL(k_pp_gather, dim3(blocks_for(total, 256)), dim3(256), 0, s, topv, topi, ref8, scale_wh, Q, C, block6, total);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ pre-process
+// src/rtdetr_detector.py:224-231 for a frame that already has the network's input size: BGR->RGB,
+// ToTensor (uint8 / 255), written as NHWC with the 3 channels padded to 8 (one 16-byte bf16 chunk).
+template <typename T>
+__global__ void k_preprocess_identity(const uint8_t* const* __restrict__ frames, int H, int W, T* __restrict__ y, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t hw = (int64_t)H * W;
+  const int b = (int)(i / hw);
+  const int64_t p = i - (int64_t)b * hw;
+  const uint8_t* f = frames[b] + p * 3;
+  const float bl = (float)f[0], g = (float)f[1], r = (float)f[2];
+  T* o = y + i * 8;
+  o[0] = (T)(r / 255.0f);
+  o[1] = (T)(g / 255.0f);
+  o[2] = (T)(bl / 255.0f);
+#pragma unroll
+  for (int k = 3; k < 8; ++k) o[k] = (T)0.f;
+}
+void launch_preprocess_identity(const uint8_t* const* frames, int n, int H, int W, const Tensor& y, hipStream_t s) {
+  RTD_CHECK(y.c == 8 && y.ld == 8 && y.h == H && y.w == W && y.n >= n, 1, "preprocess: output must be [n,H,W,8]");
+  const int64_t total = (int64_t)n * H * W;
+  DISPATCH_T(y.dt, hipLaunchKernelGGL(k_preprocess_identity<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, frames, H, W, (T*)y.p, total));
+  HIP_CHECK(hipGetLastError());
+}
+
+// PIL's antialiased bilinear stretch-resize (ImagingResample, 8 bits per channel): two separable
+// passes with fixed-point coefficients (22 fractional bits) and a uint8 intermediate - the exact
+// arithmetic of `T.Resize` on a PIL image (src/rtdetr_detector.py:176-180).  The coefficient
+// tables are computed on the host (engine.hip: pil_coeffs) the way Pillow's precompute_coeffs does.
+__device__ __forceinline__ int clip8(int v) {
+  v >>= 22;
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+__global__ void k_resize_h(const uint8_t* __restrict__ src, int sh, int sw, uint8_t* __restrict__ tmp, int dw, ResizeCoef c) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)sh * dw) return;
+  const int y = (int)(i / dw), x = (int)(i - (int64_t)y * dw);
+  const int xmin = c.hb[x * 2], cnt = c.hb[x * 2 + 1];
+  const int32_t* k = c.hk + (int64_t)x * c.hks;
+  int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+  const uint8_t* row = src + ((int64_t)y * sw + xmin) * 3;
+  for (int j = 0; j < cnt; ++j) {
+    s0 += (int)row[j * 3 + 0] * k[j];
+    s1 += (int)row[j * 3 + 1] * k[j];
+    s2 += (int)row[j * 3 + 2] * k[j];
+  }
+  uint8_t* o = tmp + i * 3;
+  o[0] = (uint8_t)clip8(s0); o[1] = (uint8_t)clip8(s1); o[2] = (uint8_t)clip8(s2);
+}
+template <typename T>
+__global__ void k_resize_v(const uint8_t* __restrict__ tmp, int sh, int dw, T* __restrict__ y, int dh, ResizeCoef c) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)dh * dw) return;
+  const int yy = (int)(i / dw), x = (int)(i - (int64_t)yy * dw);
+  const int ymin = c.vb[yy * 2], cnt = c.vb[yy * 2 + 1];
+  const int32_t* k = c.vk + (int64_t)yy * c.vks;
+  int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+  for (int j = 0; j < cnt; ++j) {
+    const uint8_t* p = tmp + ((int64_t)(ymin + j) * dw + x) * 3;
+    s0 += (int)p[0] * k[j];
+    s1 += (int)p[1] * k[j];
+    s2 += (int)p[2] * k[j];
+  }
+  T* o = y + i * 8;
+  o[0] = (T)((float)clip8(s2) / 255.0f);   // BGR -> RGB
+  o[1] = (T)((float)clip8(s1) / 255.0f);
+  o[2] = (T)((float)clip8(s0) / 255.0f);
+#pragma unroll
+  for (int q = 3; q < 8; ++q) o[q] = (T)0.f;
+}
+void launch_resize_pil(const uint8_t* src, int sh, int sw, uint8_t* tmp, const Tensor& y, int image, const ResizeCoef& c,
+                       hipStream_t s) {
+  const int dh = y.h, dw = y.w;
+  RTD_CHECK(y.c == 8 && y.ld == 8 && image < y.n, 1, "resize: output must be [n,H,W,8]");
+  hipLaunchKernelGGL(k_resize_h, dim3(blocks_for((int64_t)sh * dw, 256)), dim3(256), 0, s, src, sh, sw, tmp, dw, c);
+  char* yp = (char*)y.p + (size_t)image * y.bstride * dtype_size(y.dt);
+  DISPATCH_T(y.dt, hipLaunchKernelGGL(k_resize_v<T>, dim3(blocks_for((int64_t)dh * dw, 256)), dim3(256), 0, s, tmp, sh, dw, (T*)yp, dh, c));
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace rtd

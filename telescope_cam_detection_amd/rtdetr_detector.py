@@ -1,0 +1,222 @@
+"""Drop-in `RTDETRDetector` backed by the MI355X-native HIP engine (libmi355rtdetr.so).
+
+Mirrors the reference class /root/reference/src/rtdetr_detector.py:26-425 - same constructor
+arguments, method names, return schemas and error behaviour - so that the reference's
+`InferenceEngine` (src/inference_engine_yolox.py:196-212, :554) and
+`SharedInferenceCoordinator` (src/shared_inference_coordinator.py:250) can use it unchanged
+(see INTEGRATION.md for the two-line wiring).  All arithmetic runs in the HIP library; there is no
+PyTorch or CPU fallback: on a machine without the library or without a GPU `load_model()` logs the
+reason and returns False, exactly like the reference does when upstream RT-DETR is missing (:73-76).
+"""
+from __future__ import annotations
+
+import logging
+import time
+from typing import Any, Dict, List, Optional, Union
+
+import numpy as np
+
+from . import _capi
+from .arch import ARCHS, Arch, arch_from_config_path
+from .coco_constants import COCO_CLASSES, MAMMAL_CLASS_IDS, WILDLIFE_CLASSES
+from .weights import fold_weights, pack_blob, synth_weights
+
+logger = logging.getLogger(__name__)
+
+
+class _DeviceModel:
+    """Stands in for `detector.model` (an nn.Module in the reference): the engine only ever calls
+    `.to(device)` on it (src/inference_engine_yolox.py:744) and checks it for None (:248)."""
+
+    def __init__(self, engine: "_capi.Engine", device: str):
+        self.engine = engine
+        self.device = device
+
+    def to(self, device):
+        if str(device) != str(self.device):
+            raise RuntimeError(f"the MI355X-native RT-DETR engine cannot move to {device!r}; it has no CPU path")
+        return self
+
+    def eval(self):
+        return self
+
+
+def _device_index(device: str) -> int:
+    s = str(device)
+    if s.startswith("cuda") or s.startswith("hip"):
+        return int(s.split(":")[1]) if ":" in s else 0
+    raise ValueError(f"unsupported device {device!r}: this detector only runs on an AMD GPU ('cuda:N')")
+
+
+def load_state(model_path: str):
+    """`torch.load(model_path)['ema']['module']` else `['model']` (src/rtdetr_detector.py:134-141).
+
+    `synthetic:<arch>:<seed>` produces the seeded benchmark weights instead of reading a file.
+    Returns (state dict in this build's un-fused naming, arch name or None).
+    """
+    if str(model_path).startswith("synthetic:"):
+        _, arch_name, seed = str(model_path).split(":")
+        return synth_weights(ARCHS[arch_name], int(seed)), arch_name
+    import torch
+
+    ckpt = torch.load(model_path, map_location="cpu", weights_only=True)
+    state = ckpt["ema"]["module"] if "ema" in ckpt else ckpt["model"]
+    return state, ckpt.get("arch")
+
+
+class RTDETRDetector:
+    """RT-DETRv2 detector for Stage 1 detection, MI355X-native."""
+
+    def __init__(
+        self,
+        config_path: str = "RT-DETR/rtdetrv2_pytorch/configs/rtdetrv2/rtdetrv2_r18vd_120e_coco.yml",
+        model_path: str = "models/rtdetr/rtdetrv2_r18vd.pth",
+        device: str = "cuda:0",
+        conf_threshold: float = 0.25,
+        input_size: tuple = (640, 640),
+        wildlife_only: bool = True,
+        # build-specific knobs (keyword-only in spirit; the reference never passes them)
+        precision: str = "bf16",
+        max_batch: int = 8,
+        use_graph: bool = True,
+    ):
+        self.config_path = config_path
+        self.model_path = model_path
+        self.device = device
+        self.conf_threshold = conf_threshold
+        self.nms_threshold = None           # written by update_settings (src/inference_engine_yolox.py:684); RT-DETR has no NMS
+        self.input_size = input_size
+        self.wildlife_only = wildlife_only
+        self.precision = precision
+        self.max_batch = max_batch
+        self.use_graph = use_graph
+
+        self.model: Optional[_DeviceModel] = None
+        self.postprocessor = None
+        self.transforms = None
+        self.arch: Optional[Arch] = None
+
+    # ------------------------------------------------------------------ load
+    def load_model(self, max_retries: int = 3) -> bool:
+        """Never raises; False on failure (contract of src/rtdetr_detector.py:60-204)."""
+        try:
+            dev = _device_index(self.device)
+        except ValueError as e:
+            logger.error(str(e))
+            return False
+        for attempt in range(max_retries):
+            try:
+                logger.info("Loading RT-DETRv2 model (MI355X-native HIP engine)")
+                logger.info(f"Config: {self.config_path}")
+                logger.info(f"Weights: {self.model_path}")
+                state, arch_name = load_state(self.model_path)
+                arch = ARCHS[arch_name] if arch_name else arch_from_config_path(self.config_path)
+                blob = pack_blob(fold_weights(arch, state))
+                prec = _capi.PREC_FP32 if str(self.precision).lower() in ("fp32", "f32", "float32") else _capi.PREC_BF16
+                engine = _capi.Engine(arch, blob, device=dev, precision=prec, max_batch=self.max_batch,
+                                      input_size=tuple(self.input_size), use_graph=self.use_graph)
+                self.arch = arch
+                self.model = _DeviceModel(engine, self.device)
+                logger.info("RT-DETRv2 loaded successfully")
+                logger.info(f"  Input size: {self.input_size}")
+                logger.info("  Num classes: 80 (COCO)")
+                logger.info(f"  Confidence threshold: {self.conf_threshold}")
+                return True
+            except (RuntimeError, OSError, IOError) as e:   # same retry set as the reference (:190-198)
+                if attempt < max_retries - 1:
+                    wait_time = 2 ** attempt
+                    logger.warning(f"Model load failed (attempt {attempt + 1}/{max_retries}): {e}")
+                    logger.warning(f"Retrying in {wait_time}s...")
+                    time.sleep(wait_time)
+                else:
+                    logger.error(f"Failed to load RT-DETR model after {max_retries} attempts: {e}", exc_info=True)
+                    return False
+            except Exception as e:
+                logger.error(f"Failed to load RT-DETR model: {e}", exc_info=True)
+                return False
+        return False
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _as_frame(img):
+        """HWC uint8 BGR ndarray, or a torch tensor (host or device) - src/rtdetr_detector.py:216-222."""
+        if isinstance(img, np.ndarray):
+            return img, False
+        import torch
+
+        if isinstance(img, torch.Tensor):
+            if img.is_cuda:
+                return img.contiguous(), True
+            return img.numpy(), False
+        raise TypeError(f"unsupported frame type {type(img)}")
+
+    def _format(self, rows: np.ndarray) -> List[Dict[str, Any]]:
+        """rows -> the dict schema of src/rtdetr_detector.py:290-301 (threshold / wildlife filter were
+        applied in the library in the same order as :271,:277)."""
+        detections = []
+        for r in rows:
+            class_id = int(r["class_id"])
+            x1, y1, x2, y2 = float(r["x1"]), float(r["y1"]), float(r["x2"]), float(r["y2"])
+            class_name = COCO_CLASSES[class_id] if class_id < len(COCO_CLASSES) else f"class_{class_id}"
+            detections.append({
+                "class_id": class_id,
+                "class_name": class_name,
+                "confidence": float(r["score"]),
+                "bbox": {"x1": x1, "y1": y1, "x2": x2, "y2": y2, "area": int((x2 - x1) * (y2 - y1))},
+            })
+        return detections
+
+    def _infer(self, frames: list) -> List[np.ndarray]:
+        arrs, on_dev = [], []
+        for f in frames:
+            a, d = self._as_frame(f)
+            arrs.append(a)
+            on_dev.append(d)
+        if any(on_dev) and not all(on_dev):
+            arrs = [a.cpu().numpy() if d else a for a, d in zip(arrs, on_dev)]
+            on_dev = [False] * len(arrs)
+        eng = self.model.engine
+        out: List[np.ndarray] = []
+        for i in range(0, len(arrs), eng.max_batch):     # larger lists run as several device batches
+            out += eng.infer(arrs[i:i + eng.max_batch], self.conf_threshold, self.wildlife_only, on_device=all(on_dev))
+        return out
+
+    # ------------------------------------------------------------------ API of the reference class
+    def preprocess(self, img: Union[np.ndarray, "torch.Tensor"]) -> tuple:
+        """(preprocessed [1,3,H,W] fp32 tensor on the device, [[w, h]] tensor) - src/rtdetr_detector.py:206-236.
+        Provided for interface parity; `detect` does not call it (the library fuses this step)."""
+        import torch
+
+        a, on_dev = self._as_frame(img)
+        eng = self.model.engine
+        eng.infer_raw([a], on_device=on_dev)
+        x = torch.from_numpy(eng.debug_tensor("input")[:, :, :, :3]).permute(0, 3, 1, 2).contiguous().to(self.device)
+        h, w = a.shape[:2]
+        return x, torch.tensor([[w, h]], device=self.device)
+
+    def detect(self, frame: Union[np.ndarray, "torch.Tensor"]) -> List[Dict[str, Any]]:
+        if self.model is None:
+            logger.error("Model not loaded")
+            return []
+        return self._format(self._infer([frame])[0])
+
+    def detect_batch(self, frames: List[Union[np.ndarray, "torch.Tensor"]]) -> List[List[Dict[str, Any]]]:
+        if self.model is None:
+            logger.error("Model not loaded")
+            return [[] for _ in frames]
+        if not frames:
+            return []
+        return [self._format(rows) for rows in self._infer(list(frames))]
+
+    def is_wildlife_relevant(self, class_id: int) -> bool:
+        return class_id in WILDLIFE_CLASSES
+
+    def get_class_category(self, class_id: int) -> str:
+        if class_id == 0:
+            return "person"
+        elif class_id == 14:
+            return "bird"
+        elif class_id in MAMMAL_CLASS_IDS:
+            return "mammal"
+        else:
+            return "other"

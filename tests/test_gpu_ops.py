@@ -1,0 +1,213 @@
+"""GPU: every HIP kernel, called through the C ABI's kernel-level entry points, against a plain
+PyTorch fp32 reference of the same op computed on the CPU (integer / index kernels: bit-exact)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {"bf16": (0, torch.bfloat16), "f32": (1, torch.float32)}
+
+
+@pytest.fixture(scope="module")
+def L():
+    from telescope_cam_detection_amd import _capi
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _capi.lib()
+
+
+def ck(L, rc):
+    assert rc == 0, (rc, L.rtd_last_error(None))
+
+
+def nhwc(x, dt):
+    return x.permute(0, 2, 3, 1).contiguous().to(dt).cuda()
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, act, res_mode
+    (2, 20, 20, 64, 64, 1, 1, 0, "relu", 0),
+    (1, 33, 29, 32, 96, 3, 1, 1, "silu", 0),       # ragged M, Cout not a tile multiple
+    (2, 40, 40, 64, 128, 3, 2, 1, "relu", 1),      # stride 2, pre-activation residual
+    (1, 16, 16, 128, 256, 1, 1, 0, "none", 2),     # post-activation residual
+    (2, 32, 32, 8, 32, 3, 2, 1, "relu", 0),        # stem-like: Cin 8 (small-C path), K=72 padded to 96
+    (1, 24, 24, 16, 32, 3, 1, 1, "relu", 0),       # Cin 16 small-C path
+    (2, 16, 16, 64, 256, 2, 2, 0, "none", 0),      # the folded AvgPool+1x1 shortcut (2x2 stride 2)
+    (1, 300, 1, 256, 80, 1, 1, 0, "none", 0),      # token GEMM N=80
+    (1, 300, 1, 256, 4, 1, 1, 0, "none", 0),       # token GEMM N=4
+    (1, 300, 1, 8, 512, 1, 1, 0, "relu", 0),       # K=8 (query_pos layer 0)
+    (1, 64, 64, 256, 256, 3, 1, 1, "gelu", 0),     # big enough for the 128x128 tile path
+    (4, 80, 80, 128, 128, 3, 1, 1, "silu", 1),     # 128x128 tile, many blocks
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv(L, dt, case):
+    B, H, W, Cin, Cout, k, stride, pad, act, res_mode = case
+    if dt == "bf16" and Cin % 8:
+        pytest.skip("bf16 needs Cin % 8 == 0")
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(100 + CONV_CASES.index(case))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Cout, OH, OW, generator=g) if res_mode else None
+    # reference on the values the kernel actually sees (inputs rounded to the storage type)
+    xq, wq = x.to(tdt).float(), w.to(tdt).float()
+    rq = res.to(tdt).float() if res is not None else None
+    y = F.conv2d(xq.double(), wq.double(), b.double(), stride=stride, padding=pad)
+    if res_mode == 1:
+        y = y + rq.double()
+    y = {"none": lambda t: t, "relu": F.relu, "silu": F.silu, "gelu": F.gelu}[act](y)
+    if res_mode == 2:
+        y = y + rq.double()
+    y = y.float()
+    xd = nhwc(x, tdt)
+    wd = w.permute(0, 2, 3, 1).contiguous().cuda()      # OHWI fp32
+    bd = b.cuda()
+    rd = nhwc(res, tdt) if res is not None else None
+    for out_f32 in ((1,) if dt == "f32" else (0, 1)):
+        yd = torch.full((B, OH, OW, Cout), float("nan"), dtype=torch.float32 if out_f32 else tdt, device="cuda")
+        ck(L, L.rtd_op_conv(code, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None,
+                            yd.data_ptr(), B, H, W, Cin, Cout, k, k, stride, pad, {"none": 0, "relu": 1, "silu": 2, "gelu": 3}[act],
+                            res_mode, out_f32))
+        got = yd.float().cpu().permute(0, 3, 1, 2)
+        assert torch.isfinite(got).all()
+        if dt == "f32":
+            tol = dict(atol=2e-5, rtol=2e-5)
+        elif out_f32:
+            tol = dict(atol=2e-3, rtol=2e-3)       # bf16 products are exact in fp32; only accumulation order differs
+        else:
+            tol = dict(atol=2e-2, rtol=1e-2)       # + one bf16 rounding of the output
+        torch.testing.assert_close(got, y, **tol)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dim", [64, 256, 384])
+def test_layernorm(L, dt, dim):
+    code, tdt = DT[dt]
+    rows = 77
+    g = torch.Generator().manual_seed(dim)
+    x = torch.randn(rows, dim, generator=g) * 2 + 0.5
+    r = torch.randn(rows, dim, generator=g)
+    gam = torch.randn(dim, generator=g)
+    bet = torch.randn(dim, generator=g)
+    xq, rq = x.to(tdt).float(), r.to(tdt).float()
+    for use_res in (False, True):
+        ref = F.layer_norm(xq + (rq if use_res else 0), (dim,), gam, bet, 1e-5)
+        xd, rd, gd, bd = x.to(tdt).cuda(), r.to(tdt).cuda(), gam.cuda(), bet.cuda()   # keep device buffers alive
+        yd = torch.empty(rows, dim, dtype=torch.float32, device="cuda")
+        ck(L, L.rtd_op_layernorm(code, xd.data_ptr(), rd.data_ptr() if use_res else None, gd.data_ptr(),
+                                 bd.data_ptr(), yd.data_ptr(), rows, dim, 1))
+        torch.testing.assert_close(yd.cpu(), ref, atol=2e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 400, 8, 32), (1, 300, 8, 32), (1, 130, 4, 48), (2, 70, 2, 64)])
+def test_attention(L, dt, shape):
+    code, tdt = DT[dt]
+    B, Lq, heads, hd = shape
+    D = heads * hd
+    g = torch.Generator().manual_seed(Lq)
+    qk = torch.randn(B, Lq, 2 * D, generator=g)
+    v = torch.randn(B, Lq, D, generator=g)
+    qkq, vq = qk.to(tdt).float(), v.to(tdt).float()
+    q = qkq[..., :D].view(B, Lq, heads, hd).transpose(1, 2)
+    k = qkq[..., D:].view(B, Lq, heads, hd).transpose(1, 2)
+    vv = vq.view(B, Lq, heads, hd).transpose(1, 2)
+    a = torch.softmax(q @ k.transpose(2, 3) * hd ** -0.5, -1)
+    ref = (a @ vv).transpose(1, 2).reshape(B, Lq, D)
+    od = torch.empty(B, Lq, D, dtype=tdt, device="cuda")
+    qkd, vd = qk.to(tdt).cuda(), v.to(tdt).cuda()
+    ck(L, L.rtd_op_attention(code, qkd.data_ptr(), vd.data_ptr(), od.data_ptr(), B, Lq, heads, hd))
+    tol = dict(atol=2e-5, rtol=2e-5) if dt == "f32" else dict(atol=1.5e-2, rtol=1.5e-2)
+    torch.testing.assert_close(od.float().cpu(), ref, **tol)
+
+
+def _msdeform_ref(value, offaw, ref, heads, hd, shapes, n_points, offset_scale):
+    """HF:rt_detr_v2/modeling_rt_detr_v2.py:44-115,186-221 restated with torch ops (fp32)."""
+    B, S, D = value.shape
+    Q = ref.shape[1]
+    Lv = len(shapes)
+    LP = Lv * n_points
+    off = offaw[..., : heads * LP * 2].view(B, Q, heads, LP, 2)
+    aw = torch.softmax(offaw[..., heads * LP * 2:].view(B, Q, heads, LP), -1)
+    r = ref[:, :, None, :]
+    scale = torch.full((LP, 1), 1.0 / n_points)
+    loc = r[:, :, None, :, :2] + off * scale * r[:, :, None, :, 2:] * offset_scale
+    grids = (2 * loc - 1).permute(0, 2, 1, 3, 4).flatten(0, 1)
+    vlist = value.view(B, S, heads, hd).permute(0, 2, 3, 1).flatten(0, 1).split([h * w for h, w in shapes], dim=-1)
+    samp = []
+    for l, (h, w) in enumerate(shapes):
+        samp.append(F.grid_sample(vlist[l].reshape(B * heads, hd, h, w), grids[:, :, l * n_points:(l + 1) * n_points],
+                                  mode="bilinear", padding_mode="zeros", align_corners=False))
+    a = aw.permute(0, 2, 1, 3).reshape(B * heads, 1, Q, LP)
+    return (torch.cat(samp, -1) * a).sum(-1).view(B, heads * hd, Q).transpose(1, 2).contiguous()
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_msdeform(L, dt):
+    code, tdt = DT[dt]
+    B, Q, heads, hd, n_points = 2, 75, 8, 32, 4
+    shapes = [(20, 24), (10, 12), (5, 6)]
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(7)
+    value = torch.randn(B, S, heads * hd, generator=g)
+    offaw = torch.randn(B, Q, heads * 12 * 3, generator=g) * 2.0        # large offsets: many taps leave the map
+    ref = torch.rand(B, Q, 4, generator=g)
+    ref[..., 2:] = ref[..., 2:] * 0.5 + 0.05
+    ref[0, 0] = torch.tensor([1.0, 1.0, 1.0, 1.0])                        # the masked-anchor reference box
+    want = _msdeform_ref(value.to(tdt).float(), offaw, ref, heads, hd, shapes, n_points, 0.5)
+    out = torch.empty(B, Q, heads * hd, dtype=torch.float32, device="cuda")
+    lv = (C.c_int32 * 6)(*[v for hw in shapes for v in hw])
+    vd, od_, rd = value.to(tdt).cuda(), offaw.cuda(), ref.cuda()
+    ck(L, L.rtd_op_msdeform(code, vd.data_ptr(), od_.data_ptr(), rd.data_ptr(), out.data_ptr(),
+                            B, Q, heads, hd, 3, n_points, lv, heads * hd, 0.5))
+    torch.testing.assert_close(out.cpu(), want, atol=3e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", [(3, 8400, 300), (2, 24000, 300), (1, 1000, 1000), (2, 5000, 1), (1, 33600, 300)])
+def test_topk_exact(L, case):
+    B, N, K = case
+    g = torch.Generator().manual_seed(N + K)
+    keys = torch.randn(B, N, generator=g)
+    keys[:, ::7] = keys[:, 3:4]            # many exact ties, some of them at the selection boundary
+    keys[0, :50] = -0.0
+    keys[0, 50:100] = 0.0
+    idx = torch.empty(B, K, dtype=torch.int32, device="cuda")
+    val = torch.empty(B, K, dtype=torch.float32, device="cuda")
+    kd = keys.cuda()
+    ck(L, L.rtd_op_topk(kd.data_ptr(), B, N, K, idx.data_ptr(), val.data_ptr()))
+    idx, val = idx.cpu().long(), val.cpu()
+    for b in range(B):
+        # stable descending order = (value desc, index asc): the kernel's documented tie rule
+        order = np.lexsort((np.arange(N), -keys[b].double().numpy()))[:K]
+        # -0.0 sorts below +0.0 in the kernel's total order (sign bit); lexsort on doubles treats them equal
+        want_v = keys[b][torch.as_tensor(order)]
+        assert torch.equal(val[b], keys[b][idx[b]]), "values must be the keys at the returned indices"
+        assert len(set(idx[b].tolist())) == K
+        assert torch.equal(torch.sort(val[b], descending=True).values, val[b])
+        torch.testing.assert_close(val[b], want_v, atol=0, rtol=0)
+        same_val = val[b][1:] == val[b][:-1]
+        assert (idx[b][1:][same_val & (val[b][1:] != 0)] > idx[b][:-1][same_val & (val[b][1:] != 0)]).all(), "ties: lowest index first"
+
+
+@pytest.mark.parametrize("size", [((720, 1280), (640, 640)), ((1080, 1920), (640, 640)), ((100, 90), (192, 128)),
+                                  ((300, 260), (192, 128)), ((640, 640), (640, 640)), ((37, 53), (64, 96))])
+def test_resize_matches_pil_bit_exactly(L, size):
+    from PIL import Image
+    (sh, sw), (dh, dw) = size
+    src = np.random.default_rng(sh * 7 + sw).integers(0, 256, (sh, sw, 3), dtype=np.uint8)     # BGR
+    rgb = np.ascontiguousarray(src[:, :, ::-1])
+    want = np.asarray(Image.fromarray(rgb).resize((dw, dh), Image.BILINEAR), dtype=np.uint8)
+    out = torch.empty(dh, dw, 8, dtype=torch.float32, device="cuda")
+    sd = torch.from_numpy(src).cuda()
+    ck(L, L.rtd_op_resize(sd.data_ptr(), sh, sw, out.data_ptr(), dh, dw, 1))
+    got = out.cpu().numpy()
+    assert (got[:, :, 3:] == 0).all()
+    np.testing.assert_array_equal(got[:, :, :3], want.astype(np.float32) / np.float32(255.0))
