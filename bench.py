@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py - frames/s of the MI355X-native RT-DETR path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): RT-DETR-R50, 640x640, bs=8 per GPU, bf16, synthetic uniform-noise
+uint8 BGR frames (the reference benchmark's input, tests/test_inference.py:76) already resident in HBM,
+seeded synthetic weights (no checkpoint exists offline).  One "step" = one batch of 8 frames through
+preprocess -> network -> post-process on the device (the fixed [8,300,6] result block stays in HBM).
+N > 1: one process per GPU, cameras sharded over ranks (weak scaling), and one RCCL all-gather of
+every rank's result block per step - the collate step for rank 0's web server.
+
+Prints ONE JSON line on rank 0 with the contract fields plus:
+  roofline     - MFMA roofline of the dominant kernel family (conv_igemm), from HIP-event timings of
+                 every launch on the engine's stream (rtd_profile) and the algorithmic FLOPs per launch
+  cpu_baseline - the CPU oracle (oracle/rtdetr_oracle.py, fp32 eager PyTorch) timed on this box's host
+                 cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+HBM_PEAK_GBS = 8000.0
+CANON_GFLOP_PER_FRAME = {"r18": 60.53, "r50": 133.91}  # BASELINE.md §3 @640x640
+
+
+class _DevPtr:
+    """zero-copy torch view of a raw device pointer (the engine's result block)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--arch", default="r50")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--profile-out", default="")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the hot path"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from telescope_cam_detection_amd import _capi
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.synth import noise_frame
+    from telescope_cam_detection_amd.weights import fold_weights, pack_blob, synth_weights
+
+    arch = ARCHS[args.arch]
+    B, H = args.batch, args.size
+    w = synth_weights(arch, 0)
+    blob = pack_blob(fold_weights(arch, w))
+    prec = _capi.PREC_FP32 if args.precision == "fp32" else _capi.PREC_BF16
+    eng = _capi.Engine(arch, blob, device=local_rank, precision=prec, max_batch=B, input_size=(H, H),
+                       use_graph=not args.no_graph)
+    # frame i of config c = default_rng(1000*c+i).integers(0,255,(H,W,3),uint8); camera k -> rank k
+    frames = [torch.from_numpy(noise_frame(2000 + rank * B + i, H, H)).cuda() for i in range(B)]
+    prepared = eng.make_async_args(frames)
+    Q = arch.num_queries
+
+    stream = torch.cuda.ExternalStream(eng.stream(), device=torch.device("cuda", local_rank))
+    gathered = None
+    if world > 1:
+        gathered = torch.empty(world * B * Q * 6, dtype=torch.float32, device="cuda")
+
+    def step():
+        eng.infer_async_prepared(prepared)
+        if world > 1:
+            ptr, n = eng.result_block()
+            block = torch.as_tensor(_DevPtr(ptr, n), device=f"cuda:{local_rank}")
+            with torch.cuda.stream(stream):                   # ordered after the forward on the engine's stream
+                dist.all_gather_into_tensor(gathered, block)
+
+    def fence():
+        eng.sync()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    fps = world * B * args.steps / elapsed
+    out = {
+        "metric": "frames_per_sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"RT-DETR-{args.arch.upper()} {H}x{H} bs={B}/GPU, uint8 BGR frames resident in HBM -> "
+                               f"[{B},{Q},6] detections in HBM; synthetic seeded weights",
+                   "global_batch": world * B, "parallelism": f"camera-shard x{world}" + (" + RCCL all_gather of detections" if world > 1 else ""),
+                   "hip_graph": not args.no_graph},
+    }
+    if args.arch in CANON_GFLOP_PER_FRAME and H == 640:
+        out["mfma_frac_whole_model"] = round(CANON_GFLOP_PER_FRAME[args.arch] * fps / world / (MFMA_PEAK_TFLOPS[args.precision] * 1e3), 4)
+
+    if rank == 0:
+        # ---- per-kernel HIP-event profile on the engine's stream -> roofline of the dominant kernel ----
+        print(f"[bench] {fps:.1f} frames/s; profiling kernels ...", file=sys.stderr, flush=True)
+        prof = eng.profile(B, reps=5)
+        fam = {}
+        for p in prof:
+            f = fam.setdefault(p["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            f["ms"] += p["ms"]; f["flops"] += p["flops"]; f["bytes"] += p["bytes"]; f["launches"] += 1
+        total_ms = sum(f["ms"] for f in fam.values())
+        dom = max(fam, key=lambda k: fam[k]["ms"])
+        d = fam[dom]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[args.precision]
+        out["roofline"] = {
+            "kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+            "alg_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
+            "alg_gbytes_per_s_unfused": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
+            "share_of_step": round(d["ms"] / total_ms, 3),
+            "method": "rtd_profile: hipEvent pairs around every launch of one eager forward on the engine stream, mean of 5",
+        }
+        out["kernel_families_ms"] = {k: round(v["ms"], 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+        if args.profile_out:
+            with open(args.profile_out, "w") as fh:
+                json.dump(prof, fh, indent=0)
+        # ---- p50 single-frame latency (BASELINE metric's second half), synchronous detect() semantics ----
+        if not args.no_latency and world == 1:
+            print("[bench] bs=1 latency ...", file=sys.stderr, flush=True)
+            lat = []
+            one = [frames[0]]
+            for i in range(60):
+                t1 = time.perf_counter()
+                eng.infer(one, 0.25, True, on_device=True)
+                if i >= 10:
+                    lat.append((time.perf_counter() - t1) * 1e3)
+            out["p50_ms_per_frame_bs1"] = round(float(np.percentile(lat, 50)), 4)
+            out["p99_ms_per_frame_bs1"] = round(float(np.percentile(lat, 99)), 4)
+        # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import rtdetr_oracle as orc
+            # the box's CPU share, not the host's core count (oversubscribed OpenMP spin-waits look like a hang)
+            cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("RTD_CPU_THREADS", "16")))
+            torch.set_num_threads(cores)
+            print(f"[bench] cpu baseline on {cores} threads ...", file=sys.stderr, flush=True)
+            nb = 2
+            host = [f.cpu().numpy() for f in frames[:nb]]
+            orc.detect_batch(arch, w, host, (H, H))          # warm-up
+            reps = 3
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                orc.detect_batch(arch, w, host, (H, H))
+            dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": round(nb * reps / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+                                   "sample": f"CPU oracle (fp32 eager PyTorch restatement of the reference path), RT-DETR-{args.arch.upper()} "
+                                             f"{H}x{H} bs={nb}, {reps} timed batches after 1 warm-up, torch threads={cores}"}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

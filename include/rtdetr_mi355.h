@@ -127,6 +127,8 @@ int rtd_debug_force_topk(rtd_handle h, const int32_t* idx, int32_t n);
 /* time every kernel of one forward of batch n with HIP events on the handle's stream */
 int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int32_t capacity, int32_t* count);
 int64_t rtd_arena_bytes(rtd_handle h);
+/* process-wide A/B switches for tests and profiling: "conv_v1" = 1 keeps every conv on the small-tile kernels */
+int rtd_debug_option(const char* name, int value);
 
 /* ---- kernel-level test entry points (device pointers; dtype 0 = bf16, 1 = fp32) --------------- */
 int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* bias, const void* res,

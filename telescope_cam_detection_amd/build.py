@@ -15,7 +15,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmi355rtdetr.so")
-SOURCES = ["conv_igemm.hip", "ops.hip", "engine.hip"]
+SOURCES = ["conv_igemm.hip", "ops.hip", "decoder.hip", "engine.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(PKG), "include", "rtdetr_mi355.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
@@ -53,7 +53,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(r.stderr[-2000:], file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=3) as ex:
+    with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     tmp = LIB_PATH + ".tmp"
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs], capture_output=True, text=True)

@@ -72,6 +72,10 @@ struct ConvArgs {
 void launch_conv(const ConvArgs& a, hipStream_t s);
 int conv_kpad(int K);                 // padded filter row length the kernels expect
 int conv_npad(int N);
+void conv_set_force_v1(int v);      // A/B hook: 1 = never take the large-tile (v2) path
+void conv_set_glds_min_blocks(int v);
+void conv_set_glds_drop(int v);     // timing-only traffic probe (MI355X guide §7): drop one operand's DMA via a 0-record descriptor
+void conv_set_mode(int v);          // A/B hook: 0 auto, 1 = v1 only, 2 = v1 + v2 (no LDS-DMA kernel)
 
 void launch_layernorm(const Tensor& x, const Tensor* res, const float* g, const float* b, const Tensor& y,
                       float eps, hipStream_t s);
@@ -79,6 +83,7 @@ void launch_layernorm(const Tensor& x, const Tensor* res, const float* g, const 
 void launch_add(const Tensor& a, const Tensor& b, const Tensor& y, hipStream_t s);
 void launch_maxpool3x3s2(const Tensor& x, const Tensor& y, hipStream_t s);
 void launch_upsample2x(const Tensor& x, const Tensor& y, hipStream_t s);
+void launch_avgpool2(const Tensor& x, const Tensor& y, hipStream_t s);
 // qk: [B,L,2*D] (q | k), v: [B,L,D] -> o [B,L,D]; softmax(q k^T / sqrt(hd)) v per head
 void launch_attention(const Tensor& qk, const Tensor& v, const Tensor& o, int heads, hipStream_t s);
 void launch_set_rows(const Tensor& y, const int32_t* rows, int nrows, int rows_per_image, const float* vec,
@@ -107,6 +112,47 @@ struct ResizeCoef {
 };
 void launch_resize_pil(const uint8_t* src, int sh, int sw, uint8_t* tmp, const Tensor& y, int image, const ResizeCoef& coef,
                        hipStream_t s);
+// ---- fused decoder layer (decoder.hip) ----
+struct DecLin {
+  const float* w;   // fragment-major fp32: [tile = n/16][chunk = k/16][lane 0..63][4] = W[16 tile + (lane & 15)][16 chunk + 4 (lane >> 4) + j]
+  const float* b;   // [Npad]
+  int ldw, N, K;
+};
+struct DecLN {
+  const float* g;
+  const float* b;
+};
+
+struct DecArgs {
+  int mode;                 // 0 = prologue (enc_bbox head + ref init + next projections), 1 = layer, 2 = last layer (+ class head)
+  int B, Q, D, heads, S, n_levels, n_points, ffn, C;
+  float offset_scale;
+  // per-row state (global, fp32)
+  const float* att;         // [B*Q, D]   self-attention output (mode 1,2)
+  const float* hs_in;       // [B*Q, D]
+  float* hs_out;            // [B*Q, D]
+  const float* qpos_in;     // [B*Q, D]
+  float* ref8;              // [B*Q, 8]   sigmoid boxes, refined in place
+  float* ref_unact8;        // mode 0: raw enc boxes (debug / parity)
+  const float* anchors;     // mode 0: [S,4]
+  const int32_t* tk_idx;    // mode 0: [B*Q]
+  // cross attention
+  const void* value;        // [B, S, value_ld] (+ value_coff), bf16 or fp32
+  int value_ld, value_coff, value_f32;
+  const int32_t* lvl;       // [n_levels][3] h, w, start
+  // outputs for the next layer
+  float* qpos_out;          // [B*Q, D]
+  float* qk_out;            // [B*Q, 2D]
+  float* v_out;             // [B*Q, D]
+  float* logits;            // mode 2: [B*Q, C]
+  float* stamps;            // diagnostic: [blocks][16] phase end times (10 ns units) or nullptr
+  // weights
+  DecLin o, offaw, op, fc1, fc2, bb0, bb1, bb2, qp0, qp1, qk, v, cls;
+  DecLN ln1, ln2, ln3;
+};
+
+void launch_dec_layer(const DecArgs& a, hipStream_t s);
+
 void launch_f32_to(const float* src, void* dst, int dt, int64_t n, hipStream_t s);
 void launch_to_f32(const void* src, int dt, float* dst, int64_t n, hipStream_t s);
 

@@ -17,6 +17,8 @@
 // Block = 256 threads = 4 waves (2 along pixels x 2 along channels), tile BM x BN x 32, operands
 // staged global -> registers -> LDS (rows padded by one 16-byte access so ds_read_b128 is
 // conflict-free), next tile's global loads issued before the current tile's MFMAs.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace rtd {
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
         const int ch = (tid + i * 256) % CPR;
         const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+        if (k0 < a.Kreal && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {   // k0 >= Kreal: zero-padded filter tail
           const long long off = a_base[i] + ((long long)iy * a.W + ix) * a.ldx + c0 + ch * EPC;
           v = *(const uint4*)(xg + off);
         }
@@ -255,8 +257,468 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
   }
 }
 
-int conv_kpad(int K) { return (K + 31) / 32 * 32; }
+
+// ------------------------------------------------------------------------------------------------
+// v2: the large-tile path.  128 pixels x BN channels x 128 bytes of K per step (64 bf16 / 32 fp32),
+// LDS double-buffered (ONE barrier per K-step, next tile's global loads in flight under the MFMAs),
+// XCD-aware block order, and an epilogue staged through LDS so that every global store / residual
+// load is a coalesced 16-byte access along NHWC's channel dimension (a pixel's BN channels are one
+// contiguous 128-256 byte run) instead of 64 lanes x 8 bytes at a pixel stride.
+// Requires Cin % (128/sizeof(T)) == 0, N % 8 == 0 and 8-element aligned output / residual strides.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvK a) {
+  constexpr int BM = 128;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int BK = 128 / (int)sizeof(T);
+  constexpr int ROWB = 144;                      // 128 data bytes + one 16-byte pad (conflict-free ds_read_b128)
+  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
+  constexpr int WM = 64, WN = BN / 2, TM = 2, TN = WN / 32;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int SLD = BN + 4;                    // fp32 staging row (floats)
+  constexpr int KSUB = Mma<T>::KSUB;
+  typedef typename Mma<T>::Frag Frag;
+  static_assert(BM * SLD * 4 <= 2 * STAGE, "epilogue staging must fit in the operand buffers");
+
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int wm = wv & 1, wn = wv >> 1;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD one
+  // contiguous run of tiles (neighbouring pixel tiles share halo rows and all N tiles of a pixel
+  // tile share the input tile in that XCD's L2).  Bijective for any grid size.
+  int wg;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = wg % a.ntn, mt = wg / a.ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int ch = tid & 7;                        // this thread's 16-byte chunk inside a tile row
+  const int row0 = tid >> 3;                     // its rows: row0 + 32*i
+  long long a_base[A_CH];
+  int a_iy0[A_CH], a_ix0[A_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int m = m0 + row0 + 32 * i;
+    if (m < a.M) {
+      const int b = m / a.OHW;
+      const int r = m - b * a.OHW;
+      const int oy = r / a.OW;
+      const int ox = r - oy * a.OW;
+      a_base[i] = (long long)b * a.x_bstride + ch * EPC;
+      a_iy0[i] = oy * a.stride - a.pad;
+      a_ix0[i] = ox * a.stride - a.pad;
+    } else {
+      a_base[i] = 0;
+      a_iy0[i] = -(1 << 28);
+      a_ix0[i] = -(1 << 28);
+    }
+  }
+  const T* __restrict__ xg = (const T*)a.x;
+  const T* __restrict__ wg_ = (const T*)a.w + (long long)(n0 + row0) * a.Kpad + ch * EPC;
+
+  uint4 areg[A_CH], breg[B_CH];
+  int kh = 0, kw = 0, c0 = 0;                    // tap / channel offset of the tile being LOADED (uniform)
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+        v = *(const uint4*)(xg + a_base[i] + ((long long)iy * a.W + ix) * a.ldx + c0);
+      areg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) breg[i] = *(const uint4*)(wg_ + (long long)(32 * i) * a.Kpad + k0);
+    c0 += BK;
+    if (c0 >= a.Cin) {
+      c0 = 0;
+      if (++kw == a.KW) { kw = 0; ++kh; }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    char* sa = smem + buf * STAGE + row0 * ROWB + ch * 16;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) *(uint4*)(sa + 32 * i * ROWB) = areg[i];
+    char* sb = sa + BM * ROWB;
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) *(uint4*)(sb + 32 * i * ROWB) = breg[i];
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = a.Kpad / BK;
+  const int foff = (lane & 31) * ROWB + (lane >> 5) * 16;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const bool more = ks + 1 < nk;
+    if (more) load_tiles((ks + 1) * BK);
+    const char* sa = smem + (ks & 1) * STAGE + wm * WM * ROWB + foff;
+    const char* sb = smem + (ks & 1) * STAGE + (BM + wn * WN) * ROWB + foff;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {             // 4 x 32 bytes of K
+      Frag xf[TM], wf[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) xf[j] = *(const Frag*)(sa + j * 32 * ROWB + kk * 32);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *(const Frag*)(sb + i * 32 * ROWB + kk * 32);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+    }
+    if (more) store_tiles((ks + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue phase 1: accumulators -> LDS as fp32 [pixel][channel] ---------------------------
+  float* st = (float*)smem;
+  {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int pl = wm * WM + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          *(f32x4*)(&st[pl * SLD + wn * WN + i * 32 + 8 * g + 4 * h]) = v;
+        }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: 8 channels of one pixel per thread-iteration, coalesced along channels ----------
+  constexpr int CPP = BN / 8;                    // 8-channel chunks per pixel
+  constexpr int NIT = BM * CPP / 256;
+  const int c8 = tid % CPP;
+  const int c = n0 + c8 * 8;
+  if (c < a.N) {
+    const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pl = (tid + it * 256) / CPP;
+      const int m = m0 + pl;
+      if (m >= a.M) continue;
+      const f32x4 s0 = *(const f32x4*)(&st[pl * SLD + c8 * 8]), s1 = *(const f32x4*)(&st[pl * SLD + c8 * 8 + 4]);
+      float v[8] = {s0[0] + b0[0], s0[1] + b0[1], s0[2] + b0[2], s0[3] + b0[3],
+                    s1[0] + b1[0], s1[1] + b1[1], s1[2] + b1[2], s1[3] + b1[3]};
+      const int b = m / a.OHW;
+      const int p = m - b * a.OHW;
+      float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (a.res_mode != RES_NONE) {
+        const long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
+        if (a.res_f32) {
+          const f32x4 t0 = *(const f32x4*)((const float*)a.res + roff), t1 = *(const f32x4*)((const float*)a.res + roff + 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { rv[q] = t0[q]; rv[4 + q] = t1[q]; }
+        } else {
+          const bf16x8 t = *(const bf16x8*)((const bf16*)a.res + roff);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) rv[q] = (float)t[q];
+        }
+      }
+      if (a.res_mode == RES_PRE) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = act_fn(v[q], a.act);
+      if (a.res_mode == RES_POST) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+      }
+      const long long yoff = (long long)b * a.y_bstride + (long long)p * a.ldy + c;
+      if (a.y_f32) {
+        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        *(f32x4*)((float*)a.y + yoff) = o0;
+        *(f32x4*)((float*)a.y + yoff + 4) = o1;
+      } else {
+        bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+        *(bf16x8*)((bf16*)a.y + yoff) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// v3: the LDS-DMA path.  Same 128 x 128 x 128-byte tile and LDS-staged epilogue as v2, but both
+// operands go global -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR staging, no ds_write: in v2
+// the ds_write_b128 traffic of the register-staged tiles costs more LDS-pipe cycles than the MFMAs).
+//  * one wave-instruction writes 1 KiB = 8 tile rows x 128 B linearly, so rows are unpadded and the
+//    bank-conflict swizzle lives on the SOURCE side: LDS slot s of row r holds the row's 16-byte
+//    chunk s ^ ((r >> 1) & 7); readers apply the same involution (conflict-free for ds_read_b128's
+//    16-lane groups, checked against the bank rule of MI355X_MICROARCH.md §LDS).
+//  * the im2col gather is the per-lane source offset; zero padding = an out-of-range buffer offset
+//    (the range check makes the DMA write zeros - probed with tools/glds_probe.hip).
+//  * 2 LDS buffers, one `vmcnt(0)` + barrier per K-step: tile k+1 streams in under tile k's MFMAs.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct ConvG {
+  ConvK k;
+  unsigned x_bytes, w_bytes;   // extents of the two buffers from their base pointers (buffer descriptors)
+  int probe;                   // timing-only probes (results wrong): bit 2 = issue no DMA at all
+};
+
+template <typename T, int STAGES>
+__global__ __launch_bounds__(256, (STAGES == 2 ? 2 : 1)) void conv_igemm_glds_kernel(const ConvG g) {
+  const ConvK& a = g.k;
+  constexpr int BM = 128, BN = 128;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int BK = 128 / ES;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int SLD = BN + 4;
+  constexpr int SMEM = (STAGES * STAGE > BM * SLD * 4) ? STAGES * STAGE : BM * SLD * 4;
+  typedef typename Mma<T>::Frag Frag;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int wm = wv & 1, wn = wv >> 1;
+  int wg;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = wg % a.ntn, mt = wg / a.ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- loader geometry: DMA instruction i covers tile rows [32 i, 32 i + 32); this lane's row / slot
+  const int lrow = wv * 8 + (lane >> 3);
+  const int chunk = (lane & 7) ^ ((wv * 4 + (lane >> 4)) & 7);     // source chunk for LDS slot (lane & 7)
+  int a_off[4], a_iy0[4], a_ix0[4], b_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + i * 32 + lrow;
+    if (m < a.M) {
+      const int b = m / a.OHW;
+      const int r = m - b * a.OHW;
+      const int oy = r / a.OW;
+      const int ox = r - oy * a.OW;
+      a_iy0[i] = oy * a.stride - a.pad;
+      a_ix0[i] = ox * a.stride - a.pad;
+      a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)a_iy0[i] * a.W + a_ix0[i]) * a.ldx) * ES) + chunk * 16;
+    } else {
+      a_iy0[i] = -(1 << 28);
+      a_ix0[i] = -(1 << 28);
+      a_off[i] = 0;
+    }
+    b_off[i] = (n0 + i * 32 + lrow) * a.Kpad * ES + chunk * 16;
+  }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
+
+  int kh = 0, kw = 0, c0 = 0, k0 = 0;            // position of the tile being ISSUED (wave-uniform)
+  auto issue = [&](int buf) {
+    if (g.probe & 4) return;
+    char* sa = smem + buf * STAGE + wv * 1024;
+    const int delta = ((kh * a.W + kw) * (int)a.ldx + c0) * ES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+      const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const unsigned vo = ok ? (unsigned)(a_off[i] + delta) : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 4096), 16, vo, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sa + BM * 128 + i * 4096), 16, (unsigned)(b_off[i] + k0 * ES), 0, 0, 0);
+    k0 += BK;
+    c0 += BK;
+    if (c0 >= a.Cin) {
+      c0 = 0;
+      if (++kw == a.KW) { kw = 0; ++kh; }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets: row (lane & 31), chunk 2 kk + (lane >> 5), swizzled with ((row >> 1) & 7)
+  int foff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 128 + (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
+
+  const int nk = a.Kpad / BK;
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * STAGE + wm * 64 * 128;
+    const char* sb = smem + buf * STAGE + (BM + wn * 64) * 128;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      Frag xf[2], wf[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) xf[j] = *(const Frag*)(sa + j * 4096 + foff[kk]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wf[i] = *(const Frag*)(sb + i * 4096 + foff[kk]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+    }
+  };
+  if constexpr (STAGES == 2) {
+    // 2 blocks per CU: the co-resident block covers this block's DMA latency
+    issue(0);
+    for (int ks = 0; ks < nk; ++ks) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile ks has landed (issued one iteration ago)
+      __syncthreads();                                    // ... for every wave; tile ks-1's buffer is free
+      if (ks + 1 < nk) issue((ks + 1) & 1);
+      compute(ks & 1);
+    }
+  } else {
+    // small grids (<= 1 block per CU): nothing else hides the DMA latency, so keep STAGES-1 tiles in
+    // flight.  Each wave issues 8 DMA instructions per tile -> counted vmcnt(8 * tiles still allowed in
+    // flight); raw s_barrier (a __syncthreads() would drain vmcnt to 0).
+    constexpr int AHEAD = STAGES - 1;
+    for (int t = 0; t < AHEAD && t < nk; ++t) issue(t);
+    for (int ks = 0; ks < nk; ++ks) {
+      const int younger = nk - 1 - ks;                   // tiles issued after tile ks (at most AHEAD-1 = 2 here)
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                      // tile ks visible to all waves; buffer of tile ks-1 is free
+      if (ks + AHEAD < nk) issue((ks + AHEAD) % STAGES);
+      compute(ks % STAGES);
+    }
+  }
+  __syncthreads();                                      // all MFMA operand reads done: smem becomes the fp32 staging tile
+
+  float* st = (float*)smem;
+  {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pl = wm * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          *(f32x4*)(&st[pl * SLD + wn * 64 + i * 32 + 8 * q + 4 * h]) = v;
+        }
+    }
+  }
+  __syncthreads();
+  const int c8 = tid & 15;
+  const int c = n0 + c8 * 8;
+  if (c < a.N) {
+    const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int pl = (tid >> 4) + it * 16;
+      const int m = m0 + pl;
+      if (m >= a.M) continue;
+      const f32x4 s0 = *(const f32x4*)(&st[pl * SLD + c8 * 8]), s1 = *(const f32x4*)(&st[pl * SLD + c8 * 8 + 4]);
+      float v[8] = {s0[0] + b0[0], s0[1] + b0[1], s0[2] + b0[2], s0[3] + b0[3],
+                    s1[0] + b1[0], s1[1] + b1[1], s1[2] + b1[2], s1[3] + b1[3]};
+      const int b = m / a.OHW;
+      const int p = m - b * a.OHW;
+      float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (a.res_mode != RES_NONE) {
+        const long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
+        if (a.res_f32) {
+          const f32x4 t0 = *(const f32x4*)((const float*)a.res + roff), t1 = *(const f32x4*)((const float*)a.res + roff + 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { rv[q] = t0[q]; rv[4 + q] = t1[q]; }
+        } else {
+          const bf16x8 t = *(const bf16x8*)((const bf16*)a.res + roff);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) rv[q] = (float)t[q];
+        }
+      }
+      if (a.res_mode == RES_PRE) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = act_fn(v[q], a.act);
+      if (a.res_mode == RES_POST) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+      }
+      const long long yoff = (long long)b * a.y_bstride + (long long)p * a.ldy + c;
+      if (a.y_f32) {
+        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        *(f32x4*)((float*)a.y + yoff) = o0;
+        *(f32x4*)((float*)a.y + yoff + 4) = o1;
+      } else {
+        bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+        *(bf16x8*)((bf16*)a.y + yoff) = o;
+      }
+    }
+  }
+}
+
+int conv_kpad(int K) { return (K + 63) / 64 * 64; }
 int conv_npad(int N) { return (N + 127) / 128 * 128; }
+
+static int g_glds_min_blocks = 40;    // bf16: the LDS-DMA tile wins down to ~40 blocks (measured); fp32 GEMMs: 512
+static int g_glds_drop = 0;           // timing-only probe: 1 = x descriptor has 0 records, 2 = w, 3 = both (results wrong)
+static int g_conv_mode = 0;   // 0 auto, 1 = v1 only, 2 = v1 + v2 (no LDS-DMA path)
+static int g_force_v1 = 0;   // test / A-B hook (rtd_debug_option "conv_v1"): keep every layer on the v1 kernels
+void conv_set_force_v1(int v) { g_force_v1 = v; }
+void conv_set_glds_min_blocks(int v) { g_glds_min_blocks = v; }
+void conv_set_glds_drop(int v) { g_glds_drop = v; }
+void conv_set_mode(int v) { g_conv_mode = v; g_force_v1 = (v == 1); }
+template <typename T>
+static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long w_bytes, hipStream_t s) {
+  if (!ok || g_conv_mode != 0) return false;
+  const long long mt = (k.M + 127) / 128, ntn = (k.N + 127) / 128;
+  if (k.N < 128 || mt * ntn < (sizeof(T) == 2 ? g_glds_min_blocks : 512) || x_bytes >= (1ll << 31) || w_bytes >= (1ll << 31)) return false;
+  ConvG g;
+  g.k = k;
+  g.k.ntn = (int)ntn;
+  g.probe = g_glds_drop;
+  g.x_bytes = (g_glds_drop & 1) ? 0u : (unsigned)x_bytes;
+  g.w_bytes = (g_glds_drop & 2) ? 0u : (unsigned)w_bytes;
+  // grids that fill every CU twice run 2 blocks/CU with a 2-deep pipeline; smaller grids get the
+  // whole LDS for one block and a 4-deep pipeline
+  if (mt * ntn >= 512) hipLaunchKernelGGL((conv_igemm_glds_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((conv_igemm_glds_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(256), 0, s, g);
+  return true;
+}
+
+template <typename T>
+static bool dispatch_v2(const ConvK& k, bool v2_ok, hipStream_t s) {
+  if (!v2_ok || g_force_v1) return false;
+  const long long mt = (k.M + 127) / 128;
+  ConvK kk = k;
+  if (g_conv_mode == 0) {
+    // measured on R50 bs8 (tools/profile_layers.py): the 128-pixel register-staged tile only pays with
+    // >= 2 blocks per CU slot; smaller grids run faster on v1's 64x64 tiles (more, shorter blocks)
+    if (!(k.N >= 128 && mt * ((k.N + 127) / 128) >= 512)) return false;
+  }
+  if (k.N >= 128 && mt * ((k.N + 127) / 128) >= 200) {
+    kk.ntn = (k.N + 127) / 128;
+    hipLaunchKernelGGL((conv_igemm_v2_kernel<T, 128>), dim3((unsigned)(mt * kk.ntn)), dim3(256), 0, s, kk);
+    return true;
+  }
+  if (mt * ((k.N + 63) / 64) >= 200) {
+    kk.ntn = (k.N + 63) / 64;
+    hipLaunchKernelGGL((conv_igemm_v2_kernel<T, 64>), dim3((unsigned)(mt * kk.ntn)), dim3(256), 0, s, kk);
+    return true;
+  }
+  return false;
+}
 
 template <typename T>
 static void dispatch(const ConvK& k, bool smallc, hipStream_t s) {
@@ -314,8 +776,25 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
   k.act = a.act; k.res_mode = a.res_mode; k.y_f32 = y.dt == F32;
   k.ntn = 1;
   const bool smallc = (x.c % 32) != 0;
-  if (x.dt == BF16) dispatch<bf16>(k, smallc, s);
-  else dispatch<float>(k, smallc, s);
+  const int bk2 = x.dt == BF16 ? 64 : 32;
+  bool v2_ok = (x.c % bk2 == 0) && (y.c % 8 == 0) && (y.ld % 8 == 0) && (((uintptr_t)y.p & 15) == 0);
+  if (a.res_mode != RES_NONE) v2_ok = v2_ok && (a.res.ld % 8 == 0) && (((uintptr_t)a.res.p & 15) == 0);
+  bool done = false;
+  {
+    const long long es = (long long)dtype_size(x.dt);
+    const long long x_bytes = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * es;
+    const long long w_bytes = (long long)a.Npad * a.Kpad * es;
+    if (x.dt == BF16) done = dispatch_glds<bf16>(k, v2_ok, x_bytes, w_bytes, s);
+    else done = dispatch_glds<float>(k, v2_ok, x_bytes, w_bytes, s);
+  }
+  if (!done) {
+    if (x.dt == BF16) done = dispatch_v2<bf16>(k, v2_ok, s);
+    else done = dispatch_v2<float>(k, v2_ok, s);
+  }
+  if (!done) {
+    if (x.dt == BF16) dispatch<bf16>(k, smallc, s);
+    else dispatch<float>(k, smallc, s);
+  }
   HIP_CHECK(hipGetLastError());
 }
 

@@ -1,0 +1,378 @@
+// decoder.hip - one fused kernel per RT-DETR decoder layer (everything except the 300x300 self-attention).
+//
+// HF:rt_detr_v2/modeling_rt_detr_v2.py:339-431 (layer), :603-661 (loop), :119-225 (MS-deformable attention).
+// Every op of a decoder layer other than self-attention is independent per query row, so a block
+// owns 16 query rows of one image and carries them through the whole layer with the activations in
+// LDS (fp32) and the weights streamed from L2 straight into MFMA B-fragments:
+//
+//   att -> o_proj -> +hs -> LN1 -> (+qpos) offsets|weights -> MS-deformable sampling -> out_proj -> +res -> LN2
+//       -> FFN(relu) -> +res -> LN3 -> bbox MLP -> ref = sigmoid(delta + logit(ref))
+//       -> [next layer]  qpos = MLP(ref), q|k = (hs+qpos) Wqk, v = hs Wv        (or the class head on the last layer)
+//
+// This replaces ~19 launches per layer (2400 x 256 GEMMs that were latency-bound at ~20 us each) by one.
+// The arithmetic is exact fp32: v_mfma_f32_16x16x4_f32 (an fp32 fma chain) - the decoder carries the box
+// refinement chain and the class logits, which is where the 1e-3 / 1e-2 px parity bar is decided.
+#include "common.h"
+
+namespace rtd {
+
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+
+constexpr int DR = 16;            // rows per block
+constexpr int NW = 8;             // waves per block (2 per SIMD: one wave's weight-load latency hides under the other's MFMAs)
+constexpr int NT = NW * 64;
+
+__device__ __forceinline__ float dsig(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float dinv_sig(float x) {
+  x = fminf(fmaxf(x, 0.f), 1.f);
+  return __logf(fmaxf(x, 1e-5f) / fmaxf(1.f - x, 1e-5f));
+}
+
+// Ys[16][N] = act(Xs[16][K] @ W^T + b (+ Rs)).   Xs / Ys / Rs live in LDS; K % 64 == 0 (zero padded).
+// The 4 waves take the N/16 column tiles round-robin; a lane's A fragment is Xs[row = lane & 15][k0 + 4 (lane >> 4) .. +3],
+// its B fragment W[n0 + (lane & 15)][same k] - each 16-byte load feeds 4 MFMAs (the k order inside a
+// step only has to agree between A and B).  The weights are stored FRAGMENT-MAJOR (engine.hip pack_fragments):
+// block (tile t, 16-wide k chunk c) is 64 lanes x 16 bytes in lane order, so one wave load is one contiguous
+// 1 KiB read.  (Row-major weights put adjacent lanes on different rows: 4x the cache-line requests, and the
+// layer ran 7x slower than its MFMA time.)
+template <int ACT>
+__device__ void row_gemm(const float* Xs, int ldx, const DecLin& L, float* Ys, int ldy, const float* Rs, int ldr, int wave, int lane) {
+  const int ntiles = (L.N + 15) >> 4;
+  const int r16 = lane & 15, q = lane >> 4;
+  const float* xrow = Xs + r16 * ldx + 4 * q;
+  // two column tiles (t, t+NW) per pass share the A fragment and give the MFMA pipe two independent accumulators
+  for (int t = wave; t < ntiles; t += 2 * NW) {
+    const bool has2 = t + NW < ntiles;                          // wave-uniform
+    const int n0 = t << 4, n1 = has2 ? (t + NW) << 4 : n0;
+    const int kc = L.K >> 4;                                   // 16-wide chunks per tile
+    const float* w0 = L.w + (size_t)t * kc * 256 + lane * 4;
+    const float* w1 = L.w + (size_t)(has2 ? t + NW : t) * kc * 256 + lane * 4;
+    f32x4_ acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4_ c0[4], c1[4], p0[4], p1[4];
+    // every load is unconditional (K % 64 == 0; the prefetch past the end is clamped onto the last chunk):
+    // a per-element "load or zero" select makes hipcc branch and drain vmcnt(0) around each load.
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      c0[j] = *(const f32x4_*)(w0 + 256 * j);
+      c1[j] = *(const f32x4_*)(w1 + 256 * j);
+    }
+    for (int k0 = 0; k0 < L.K; k0 += 64) {
+      const int kn = min(k0 + 64, L.K - 64);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        p0[j] = *(const f32x4_*)(w0 + (kn >> 4) * 256 + 256 * j);
+        p1[j] = *(const f32x4_*)(w1 + (kn >> 4) * 256 + 256 * j);
+      }
+      // pin the order: the next chunk's 8 loads are in flight under this chunk's 32 MFMAs (left alone, hipcc
+      // sinks each load to just before its use and the L2 latency is exposed every 4 MFMAs)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4_ x4 = *(const f32x4_*)(xrow + k0 + 16 * j);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x4[u], c0[j][u], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x4[u], c1[j][u], acc1, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { c0[j] = p0[j]; c1[j] = p1[j]; }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1 && !has2) break;
+      const int col = (h == 0 ? n0 : n1) + r16;
+      if (col < L.N) {
+        const float bv = L.b[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = q * 4 + r;
+          float v = (h == 0 ? acc0[r] : acc1[r]) + bv;
+          if (Rs) v += Rs[row * ldr + col];
+          if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
+          Ys[row * ldy + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// in-place LayerNorm of Xs[16][D] (D <= 256, D % 4 == 0); each wave owns DR / NW rows
+__device__ void row_ln(float* Xs, int ldx, int D, const DecLN& P, int wave, int lane) {
+  for (int r = wave * (DR / NW); r < (wave + 1) * (DR / NW); ++r) {
+    float v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = c < D ? Xs[r * ldx + c] : 0.f;
+      s += v[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      const float d = c < D ? v[i] - mean : 0.f;
+      sq += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float rstd = rsqrtf(sq / (float)D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D) Xs[r * ldx + c] = (v[i] - mean) * rstd * P.g[c] + P.b[c];
+    }
+  }
+}
+
+
+// MS-deformable sampling of the block's 16 rows x 8 heads = 128 (row, head) items; 3 levels x 4 points.
+// FOUR lanes own one item, each 8 of its 32 channels (one 16-byte load per tap), so the 256 threads cover 64
+// items per pass (2 passes).  All 16 bilinear taps of a level are loaded UNCONDITIONALLY (clamped address, zero
+// weight when the tap is outside the map = grid_sample's zero padding) so they are in flight together: this phase
+// is pure HBM/MALL latency (random 64-byte rows of a ~200 MB tensor) and was 50 % of the kernel with one
+// 2-byte load per lane and 8 items per pass.
+template <typename TV>
+__device__ void sample_rows(const DecArgs& a, const float* sO, int LDO, const float* sR, int LDR, float* sA, int LDH, int b,
+                            int nvalid, int tid) {
+  constexpr int NL = 3, NP = 4, LP = NL * NP;
+  constexpr int V = 16 / (int)sizeof(TV);                      // channels per 16-byte load: 8 (bf16) / 4 (fp32)
+  typedef TV VT __attribute__((ext_vector_type(V)));
+  const int c8 = tid & 3;
+  const float pscale = 1.f / (float)NP;
+  for (int item = tid >> 2; item < DR * a.heads; item += NT / 4) {
+    const int r = item / a.heads, head = item - r * a.heads;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    if (r < nvalid) {
+      const float* offs = sO + r * LDO + head * LP * 2;
+      const float* awl = sO + r * LDO + a.heads * LP * 2 + head * LP;
+      float lg[LP];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < LP; ++i) { lg[i] = awl[i]; mx = fmaxf(mx, lg[i]); }
+      float den = 0.f;
+#pragma unroll
+      for (int i = 0; i < LP; ++i) { lg[i] = __expf(lg[i] - mx); den += lg[i]; }
+      const float inv_den = 1.f / den;
+      const float rx = sR[r * LDR + 0], ry = sR[r * LDR + 1], rw = sR[r * LDR + 2], rh = sR[r * LDR + 3];
+      const TV* vb = (const TV*)a.value + (long long)b * a.S * a.value_ld + a.value_coff + head * 32 + c8 * 8;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        const int H = a.lvl[l * 3 + 0], W = a.lvl[l * 3 + 1], start = a.lvl[l * 3 + 2];
+        float wt[NP * 4];
+        int of[NP * 4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int i = l * NP + p;
+          const float aw = lg[i] * inv_den;
+          const float lx = rx + offs[i * 2 + 0] * pscale * rw * a.offset_scale;
+          const float ly = ry + offs[i * 2 + 1] * pscale * rh * a.offset_scale;
+          const float gx = 2.f * lx - 1.f, gy = 2.f * ly - 1.f;
+          const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+          const float iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+          const float fx = floorf(ix), fy = floorf(iy);
+          // clamp before the int conversion: masked-anchor boxes (ref = 1) with large offsets can be far outside
+          const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)W + 1.f), y0 = (int)fminf(fmaxf(fy, -2.f), (float)H + 1.f);
+          const int x1 = x0 + 1, y1 = y0 + 1;
+          const float wx1 = ix - fx, wy1 = iy - fy, wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy;
+          const bool okx0 = (unsigned)x0 < (unsigned)W, okx1 = (unsigned)x1 < (unsigned)W;
+          const bool oky0 = (unsigned)y0 < (unsigned)H, oky1 = (unsigned)y1 < (unsigned)H;
+          const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+          const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+          wt[p * 4 + 0] = (oky0 && okx0) ? wx0 * wy0 * aw : 0.f;
+          wt[p * 4 + 1] = (oky0 && okx1) ? wx1 * wy0 * aw : 0.f;
+          wt[p * 4 + 2] = (oky1 && okx0) ? wx0 * wy1 * aw : 0.f;
+          wt[p * 4 + 3] = (oky1 && okx1) ? wx1 * wy1 * aw : 0.f;
+          of[p * 4 + 0] = (start + cy0 * W + cx0) * a.value_ld;
+          of[p * 4 + 1] = (start + cy0 * W + cx1) * a.value_ld;
+          of[p * 4 + 2] = (start + cy1 * W + cx0) * a.value_ld;
+          of[p * 4 + 3] = (start + cy1 * W + cx1) * a.value_ld;
+        }
+        VT vv[NP * 4][8 / V];
+#pragma unroll
+        for (int t = 0; t < NP * 4; ++t)
+#pragma unroll
+          for (int u = 0; u < 8 / V; ++u) vv[t][u] = *(const VT*)(vb + of[t] + u * V);
+#pragma unroll
+        for (int t = 0; t < NP * 4; ++t)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)vv[t][k / V][k % V], wt[t], acc[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sA[r * LDH + head * 32 + c8 * 8 + k] = acc[k];
+  }
+}
+
+// diagnostic phase stamps (100 MHz wall clock), enabled only when a.stamps != nullptr (rtd_debug_option "dec_stamps")
+#define DEC_STAMP(i)                                                                         \
+  do {                                                                                       \
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = (float)(long long)(__builtin_amdgcn_s_memrealtime() - t_start); \
+  } while (0)
+
+__global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
+  // LDS (floats).  Row strides are (cols + 4): ds_read_b128 of 16 rows x 4 k-groups is conflict-free.
+  constexpr int LDH = 260, LDF = 1028, LDQ = 516, LDO = 292, LDR = 68;
+  __shared__ __attribute__((aligned(16))) float sH[DR * LDH];   // hs / running activation x
+  __shared__ __attribute__((aligned(16))) float sP[DR * LDH];   // query_pos of this layer, later of the next
+  __shared__ __attribute__((aligned(16))) float sA[DR * LDH];   // attention out / sampled values / scratch
+  __shared__ __attribute__((aligned(16))) float sF[DR * LDF];   // FFN hidden (1024)
+  float* const sT = sF;                                         // 512-wide scratch (bbox hidden, qpos hidden, q|k): live only while sF is dead
+  __shared__ __attribute__((aligned(16))) float sO[DR * LDO];   // sampling offsets | attention logits
+  __shared__ __attribute__((aligned(16))) float sR[DR * LDR];   // ref boxes (cols 0..3), zero padded to 64 (K of qpos.0)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long t_start = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  const int tiles = (a.Q + DR - 1) / DR;
+  const int b = blockIdx.x / tiles;
+  const int q0 = (blockIdx.x - b * tiles) * DR;
+  const int D = a.D;
+  const long long row0 = (long long)b * a.Q + q0;
+  const int nvalid = min(DR, a.Q - q0);
+
+  // ---- load the block's rows --------------------------------------------------------------------
+  for (int e = tid; e < DR * D; e += NT) {
+    const int r = e / D, c = e - r * D;
+    const bool ok = r < nvalid;
+    sH[r * LDH + c] = ok ? a.hs_in[(row0 + r) * D + c] : 0.f;
+    if (a.mode != 0) {
+      sA[r * LDH + c] = ok ? a.att[(row0 + r) * D + c] : 0.f;
+      sP[r * LDH + c] = ok ? a.qpos_in[(row0 + r) * D + c] : 0.f;
+    }
+  }
+  for (int e = tid; e < DR * LDR; e += NT) {
+    const int r = e / LDR, c = e - r * LDR;
+    sR[e] = (a.mode != 0 && r < nvalid && c < 4) ? a.ref8[(row0 + r) * 8 + c] : 0.f;
+  }
+  __syncthreads();
+  DEC_STAMP(0);   // rows loaded
+
+  if (a.mode != 0) {
+    // ---- self-attention output projection + residual + LN1 (HF:v2.py:395-405) ---------------------
+    row_gemm<ACT_NONE>(sA, LDH, a.o, sH, LDH, sH, LDH, wave, lane);      // x = hs + att @ Wo   (in place: each element read then written by one lane)
+    __syncthreads();
+    DEC_STAMP(1);   // o_proj
+    row_ln(sH, LDH, D, a.ln1, wave, lane);
+    __syncthreads();
+    DEC_STAMP(2);   // ln1
+    // ---- cross attention: (x + qpos) -> offsets | weights (HF:v2.py:170-186) -------------------------
+    for (int e = tid; e < DR * D; e += NT) {
+      const int r = e / D, c = e - r * D;
+      sA[r * LDH + c] = sH[r * LDH + c] + sP[r * LDH + c];
+    }
+    __syncthreads();
+    row_gemm<ACT_NONE>(sA, LDH, a.offaw, sO, LDO, nullptr, 0, wave, lane);
+    __syncthreads();
+    DEC_STAMP(3);   // add + offaw
+    // ---- MS-deformable sampling (HF:v2.py:44-115,203-221): 32 lanes = one (row, head) ---------------
+    if (a.value_f32) sample_rows<float>(a, sO, LDO, sR, LDR, sA, LDH, b, nvalid, tid);
+    else sample_rows<bf16>(a, sO, LDO, sR, LDR, sA, LDH, b, nvalid, tid);
+    __syncthreads();
+    DEC_STAMP(4);   // sampling
+    // ---- output projection + residual + LN2 (HF:v2.py:221,418-421) ----------------------------------
+    row_gemm<ACT_NONE>(sA, LDH, a.op, sH, LDH, sH, LDH, wave, lane);
+    __syncthreads();
+    row_ln(sH, LDH, D, a.ln2, wave, lane);
+    __syncthreads();
+    DEC_STAMP(5);   // op + ln2
+    // ---- FFN + residual + LN3 (HF:v2.py:423-428) ------------------------------------------------------
+    row_gemm<ACT_RELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane);
+    __syncthreads();
+    DEC_STAMP(6);   // fc1
+    row_gemm<ACT_NONE>(sF, LDF, a.fc2, sH, LDH, sH, LDH, wave, lane);
+    __syncthreads();
+    row_ln(sH, LDH, D, a.ln3, wave, lane);
+    __syncthreads();
+    DEC_STAMP(7);   // fc2 + ln3
+  }
+
+  // ---- box head: mode 0 = enc_bbox_head(target) + anchors (HF:v2.py:1588-1599), else bbox_embed[i] + logit(ref) (:636-639)
+  row_gemm<ACT_RELU>(sH, LDH, a.bb0, sA, LDH, nullptr, 0, wave, lane);
+  __syncthreads();
+  row_gemm<ACT_RELU>(sA, LDH, a.bb1, sT, LDQ, nullptr, 0, wave, lane);
+  __syncthreads();
+  row_gemm<ACT_NONE>(sT, LDQ, a.bb2, sO, LDO, nullptr, 0, wave, lane);    // [16][4] deltas in sO cols 0..3
+  __syncthreads();
+  if (tid < DR * 4) {
+    const int r = tid >> 2, c = tid & 3;
+    if (r < nvalid) {
+      float v;
+      if (a.mode == 0) {
+        int t = a.tk_idx[row0 + r];
+        t = min(max(t, 0), a.S - 1);
+        const float u = sO[r * LDO + c] + a.anchors[(long long)t * 4 + c];
+        a.ref_unact8[(row0 + r) * 8 + c] = u;
+        a.ref_unact8[(row0 + r) * 8 + 4 + c] = 0.f;
+        v = dsig(u);
+      } else {
+        v = dsig(sO[r * LDO + c] + dinv_sig(sR[r * LDR + c]));
+      }
+      sR[r * LDR + c] = v;
+      a.ref8[(row0 + r) * 8 + c] = v;
+      a.ref8[(row0 + r) * 8 + 4 + c] = 0.f;
+    }
+  }
+  DEC_STAMP(8);   // bbox head + refine
+  // hidden state of this layer
+  if (a.mode != 0) {
+    for (int e = tid; e < DR * D; e += NT) {
+      const int r = e / D, c = e - r * D;
+      if (r < nvalid) a.hs_out[(row0 + r) * D + c] = sH[r * LDH + c];
+    }
+  }
+  __syncthreads();
+
+  if (a.mode == 2) {
+    // ---- class head of the last layer (HF:v2.py:644-646,1880) ----------------------------------------
+    row_gemm<ACT_NONE>(sH, LDH, a.cls, sT, LDQ, nullptr, 0, wave, lane);
+    __syncthreads();
+    for (int e = tid; e < DR * a.C; e += NT) {
+      const int r = e / a.C, c = e - r * a.C;
+      if (r < nvalid) a.logits[(row0 + r) * a.C + c] = sT[r * LDQ + c];
+    }
+    return;
+  }
+
+  // ---- projections for the NEXT layer: qpos = MLP(ref) (HF:v2.py:613), q|k = (hs+qpos) Wqk, v = hs Wv ----
+  row_gemm<ACT_RELU>(sR, LDR, a.qp0, sT, LDQ, nullptr, 0, wave, lane);
+  __syncthreads();
+  row_gemm<ACT_NONE>(sT, LDQ, a.qp1, sP, LDH, nullptr, 0, wave, lane);
+  __syncthreads();
+  DEC_STAMP(9);   // hs store + qpos MLP
+  for (int e = tid; e < DR * D; e += NT) {
+    const int r = e / D, c = e - r * D;
+    sA[r * LDH + c] = sH[r * LDH + c] + sP[r * LDH + c];
+    if (r < nvalid) a.qpos_out[(row0 + r) * D + c] = sP[r * LDH + c];
+  }
+  __syncthreads();
+  row_gemm<ACT_NONE>(sA, LDH, a.qk, sT, LDQ, nullptr, 0, wave, lane);
+  row_gemm<ACT_NONE>(sH, LDH, a.v, sO, LDO, nullptr, 0, wave, lane);
+  __syncthreads();
+  DEC_STAMP(10);  // qk + v
+  for (int e = tid; e < DR * 2 * D; e += NT) {
+    const int r = e / (2 * D), c = e - r * 2 * D;
+    if (r < nvalid) a.qk_out[(row0 + r) * 2 * D + c] = sT[r * LDQ + c];
+  }
+  for (int e = tid; e < DR * D; e += NT) {
+    const int r = e / D, c = e - r * D;
+    if (r < nvalid) a.v_out[(row0 + r) * D + c] = sO[r * LDO + c];
+  }
+  DEC_STAMP(11);  // stores
+}
+
+void launch_dec_layer(const DecArgs& a, hipStream_t s) {
+  RTD_CHECK(a.D == 256 && a.D / a.heads == 32 && a.ffn <= 1024 && a.C <= 512, 1, "fused decoder: d_model 256, head dim 32, ffn <= 1024");
+  RTD_CHECK(a.n_levels == 3 && a.n_points == 4 && a.heads * 36 <= 288, 1, "fused decoder: 3 levels x 4 points");
+  const int tiles = (a.Q + DR - 1) / DR;
+  hipLaunchKernelGGL(dec_layer_kernel, dim3(a.B * tiles), dim3(NT), 0, s, a);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace rtd

@@ -24,6 +24,8 @@ void launch_force_idx(int32_t* dst, const int32_t* src, const int32_t* flag, int
 namespace {
 
 thread_local std::string g_create_error;
+int g_dec_stamps = 0;  // plan-build switch: record per-phase stamps of decoder layer 2 into debug tensor "dec_stamps"
+int g_dec_fused = 1;   // plan-build switch (rtd_debug_option "dec_fused"): 0 = one launch per decoder op
 
 struct HostTensor {
   const float* data = nullptr;
@@ -176,6 +178,37 @@ DevWeight get_weight(rtd_engine* e, const std::string& name, int dt, int N, int 
   }
   if (tmp) (void)hipFree(tmp);
   HIP_CHECK(er);
+  std::vector<float> bp(d.Npad, 0.f);
+  memcpy(bp.data(), b.data, (size_t)N * 4);
+  d.bias = (float*)e->dmalloc(bp.size() * 4);
+  HIP_CHECK(hipMemcpy(d.bias, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+  e->wcache[key] = d;
+  return d;
+}
+
+// fp32 filter [N][K] -> fragment-major layout of decoder.hip's row_gemm (K padded to Kuse, N to 8 tiles)
+DevWeight get_weight_packed(rtd_engine* e, const std::string& name, int N, int K, int Kuse) {
+  const std::string key = name + "#packed";
+  auto it = e->wcache.find(key);
+  if (it != e->wcache.end()) return it->second;
+  const HostTensor& w = host_tensor(e, name + ".w");
+  const HostTensor& b = host_tensor(e, name + ".b");
+  RTD_CHECK(!w.shape.empty() && w.shape[0] == N && w.numel() == (int64_t)N * K, RTD_E_WEIGHTS, "weight shape mismatch: " + name);
+  RTD_CHECK(b.numel() == N && Kuse % 64 == 0 && Kuse >= K, RTD_E_WEIGHTS, "bias / K padding: " + name);
+  DevWeight d;
+  d.N = N; d.K = Kuse; d.Kpad = Kuse; d.dt = F32;
+  const int ntiles = ((N + 15) / 16 + 7) / 8 * 8, kc = Kuse / 16;
+  d.Npad = ntiles * 16;
+  std::vector<float> pk((size_t)ntiles * kc * 256, 0.f);
+  for (int t = 0; t < ntiles; ++t)
+    for (int c = 0; c < kc; ++c)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 4; ++j) {
+          const int n = t * 16 + (lane & 15), k = c * 16 + 4 * (lane >> 4) + j;
+          if (n < N && k < K) pk[(((size_t)t * kc + c) * 64 + lane) * 4 + j] = w.data[(size_t)n * K + k];
+        }
+  d.w = e->dmalloc(pk.size() * 4);
+  HIP_CHECK(hipMemcpy(d.w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
   std::vector<float> bp(d.Npad, 0.f);
   memcpy(bp.data(), b.data, (size_t)N * 4);
   d.bias = (float*)e->dmalloc(bp.size() * 4);
@@ -397,9 +430,15 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       else has_sc = (bi == 0);
       if (has_sc) {
         res = B.act(P, n, oh, ow, cout);
-        // stride 2: AvgPool2d(2,2) + 1x1 folded into one 2x2 stride-2 filter (weights.py fold_weights)
-        if (stride == 2) B.conv(pfx + ".sc", cur, res, 2, 2, 0, ACT_NONE);
-        else B.conv(pfx + ".sc", cur, res, 1, 1, 0, ACT_NONE);
+        // stride 2: AvgPool2d(2,2,ceil) then 1x1 (HF:rt_detr_resnet.py:199-213); extents are even here
+        if (stride == 2) {
+          Tensor pooled = B.act(P, n, oh, ow, cin);
+          B.push(pfx + ".avgpool", "avgpool", 4.0 * pooled.pixels() * cin, Builder::tbytes(cur) + Builder::tbytes(pooled),
+                 [cur, pooled](hipStream_t s) { launch_avgpool2(cur, pooled, s); });
+          B.conv(pfx + ".sc", pooled, res, 1, 1, 0, ACT_NONE);
+        } else {
+          B.conv(pfx + ".sc", cur, res, 1, 1, 0, ACT_NONE);
+        }
       }
       Tensor out = B.act(P, n, oh, ow, cout, oname);
       if (c.layer_type == RTD_LAYER_BOTTLENECK) {
@@ -530,9 +569,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   }
   Tensor target = B.act(F32, n, Q, 1, dm, "target");
   B.push("dec.gather_target", "gather", 0.0, 2.0 * n * Q * dm * 4, [om, tk, S, target](hipStream_t s) { launch_gather_rows(om, tk, S, target, s); });
-  Tensor b0 = B.linear("dec.enc_bbox.0", target, dm, F32, ACT_RELU);
-  Tensor b1 = B.linear("dec.enc_bbox.1", b0, dm, F32, ACT_RELU);
-  Tensor b2 = B.linear("dec.enc_bbox.2", b1, 4, F32, ACT_NONE);
+  const int npts = c.dec_heads * c.n_levels * c.n_points;
   float* ref_unact8 = (float*)B.alloc((size_t)n * Q * 8 * 4);
   float* ref8 = (float*)B.alloc((size_t)n * Q * 8 * 4);
   Tensor ref8t; ref8t.p = ref8; ref8t.dt = F32; ref8t.n = n; ref8t.h = Q; ref8t.w = 1; ref8t.c = 8; ref8t.ld = 8; ref8t.bstride = (int64_t)Q * 8;
@@ -540,13 +577,86 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   {
     Tensor ru = ref8t; ru.p = ref_unact8;
     plan->named["ref_unact"] = ru;
+  }
+  Tensor hs = target;
+  Tensor logits;
+  const bool fused = g_dec_fused && dm == 256 && dm / c.dec_heads == 32 && c.dec_ffn <= 1024 && C <= 512 && c.n_levels == 3 && c.n_points == 4;
+  if (fused) {
+    // ---- fused decoder: 1 prologue + per layer (self-attention kernel + one fused kernel), decoder.hip -----
+    Tensor qpos = B.act(F32, n, Q, 1, dm);
+    Tensor sqk = B.act(F32, n, Q, 1, 2 * dm);
+    Tensor sv = B.act(F32, n, Q, 1, dm);
+    Tensor att = B.act(F32, n, Q, 1, dm);
+    logits = B.act(F32, n, Q, 1, C, "logits");
+    auto lin = [&](const std::string& name, int N, int K, int Kuse = 0) {
+      DecLin L{};
+      if (!B.dry) {
+        DevWeight w = get_weight_packed(e, name, N, K, Kuse ? Kuse : K);
+        L.w = (const float*)w.w; L.b = w.bias; L.ldw = w.Kpad; L.N = N; L.K = w.K;
+      }
+      return L;
+    };
+    auto lnp = [&](const std::string& name) {
+      DecLN P{};
+      if (!B.dry) { P.g = get_vec(e, name + ".g", dm); P.b = get_vec(e, name + ".b", dm); }
+      return P;
+    };
+    DecArgs base{};
+    base.B = n; base.Q = Q; base.D = dm; base.heads = c.dec_heads; base.S = S; base.n_levels = c.n_levels;
+    base.n_points = c.n_points; base.ffn = c.dec_ffn; base.C = C; base.offset_scale = c.offset_scale;
+    base.ref8 = ref8; base.ref_unact8 = ref_unact8; base.anchors = e->anchors_dev; base.tk_idx = tk;
+    base.value = vall.p; base.value_ld = (int)vall.ld; base.value_f32 = vall.dt == F32; base.lvl = e->lvl_dev;
+    base.qpos_in = (const float*)qpos.p; base.qpos_out = (float*)qpos.p; base.qk_out = (float*)sqk.p; base.v_out = (float*)sv.p;
+    base.att = (const float*)att.p; base.logits = (float*)logits.p;
+    base.qp0 = lin("dec.qpos.0", 2 * dm, 8, 64);   // K padded to one 64-wide step (zero weights / zero LDS columns)
+    base.qp1 = lin("dec.qpos.1", dm, 2 * dm);
+    const double row_flops_next = 2.0 * n * Q * ((double)8 * 2 * dm + 2.0 * dm * dm + 2.0 * dm * dm + (double)dm * dm);
+    {
+      DecArgs a = base;
+      a.mode = 0;
+      a.hs_in = (const float*)target.p; a.hs_out = nullptr;
+      a.bb0 = lin("dec.enc_bbox.0", dm, dm); a.bb1 = lin("dec.enc_bbox.1", dm, dm); a.bb2 = lin("dec.enc_bbox.2", 4, dm);
+      a.qk = lin("dec.l0.sa.qk", 2 * dm, dm); a.v = lin("dec.l0.sa.v", dm, dm);
+      B.push("dec.prologue", "dec_layer", 2.0 * n * Q * (2.0 * dm * dm + 4.0 * dm) + row_flops_next, (double)n * Q * dm * 4 * 6,
+             [a](hipStream_t s) { launch_dec_layer(a, s); });
+    }
+    for (int i = 0; i < NL; ++i) {
+      const std::string p = nm("dec.l%d", i);
+      const int heads = c.dec_heads;
+      B.push(p + ".sa.attn", "attention", 4.0 * n * (double)Q * Q * dm, Builder::tbytes(sqk) + 2 * Builder::tbytes(sv),
+             [sqk, sv, att, heads](hipStream_t s) { launch_attention(sqk, sv, att, heads, s); });
+      Tensor hs_out = B.act(F32, n, Q, 1, dm, nm("dec%d.hs", i));
+      DecArgs a = base;
+      const bool last = i == NL - 1;
+      a.mode = last ? 2 : 1;
+      a.hs_in = (const float*)hs.p; a.hs_out = (float*)hs_out.p;
+      a.value_coff = i * dm;
+      a.o = lin(p + ".sa.o", dm, dm); a.ln1 = lnp(p + ".ln1");
+      a.offaw = lin(p + ".ca.offaw", 3 * npts, dm); a.op = lin(p + ".ca.op", dm, dm); a.ln2 = lnp(p + ".ln2");
+      a.fc1 = lin(p + ".fc1", c.dec_ffn, dm); a.fc2 = lin(p + ".fc2", dm, c.dec_ffn); a.ln3 = lnp(p + ".ln3");
+      a.bb0 = lin(nm("dec.bbox.%d.0", i), dm, dm); a.bb1 = lin(nm("dec.bbox.%d.1", i), dm, dm); a.bb2 = lin(nm("dec.bbox.%d.2", i), 4, dm);
+      if (last) a.cls = lin("dec.cls", C, dm);
+      else { a.qk = lin(nm("dec.l%d.sa.qk", i + 1), 2 * dm, dm); a.v = lin(nm("dec.l%d.sa.v", i + 1), dm, dm); }
+      if (g_dec_stamps && i == std::min(2, NL - 1)) {
+        const int blocks = n * ((Q + 15) / 16);
+        Tensor st = B.act(F32, 1, blocks, 1, 16, "dec_stamps");
+        a.stamps = (float*)st.p;
+      }
+      const double fl = 2.0 * n * Q * ((double)dm * dm * 2 + 3.0 * npts * dm + 2.0 * dm * c.dec_ffn + 2.0 * dm * dm + 4.0 * dm) +
+                        2.0 * n * Q * dm * c.n_levels * c.n_points * 4 + (last ? 2.0 * n * Q * dm * C : row_flops_next);
+      B.push(p + ".fused", "dec_layer", fl, (double)n * Q * dm * 4 * 8, [a](hipStream_t s) { launch_dec_layer(a, s); });
+      hs = hs_out;
+    }
+  } else {
+  Tensor b0 = B.linear("dec.enc_bbox.0", target, dm, F32, ACT_RELU);
+  Tensor b1 = B.linear("dec.enc_bbox.1", b0, dm, F32, ACT_RELU);
+  Tensor b2 = B.linear("dec.enc_bbox.2", b1, 4, F32, ACT_NONE);
+  {
     const float* anchors = e->anchors_dev;
     B.push("dec.ref_init", "ref_init", 0.0, (double)n * Q * 64, [b2, anchors, tk, S, ref_unact8, ref8](hipStream_t s) { launch_ref_init(b2, anchors, tk, S, ref_unact8, ref8, s); });
   }
 
   // ---- decoder layers (HF:v2.py:603-661, layer :339-431) ---------------------------------------
-  Tensor hs = target;
-  const int npts = c.dec_heads * c.n_levels * c.n_points;
   for (int i = 0; i < NL; ++i) {
     const std::string p = nm("dec.l%d", i);
     Tensor qp0 = B.linear("dec.qpos.0", ref8t, 2 * dm, F32, ACT_RELU);
@@ -587,8 +697,9 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     B.push(p + ".refine", "box_refine", 0.0, (double)n * Q * 48, [d2, ref8](hipStream_t s) { launch_box_refine(d2, ref8, s); });
     hs = hs3;
   }
+    logits = B.linear("dec.cls", hs, C, F32, ACT_NONE, nullptr, "logits");
+  }
   // ---- heads + post-processor (HF:v2.py:1880-1881; image_processing_rt_detr.py:510-533) ---------
-  Tensor logits = B.linear("dec.cls", hs, C, F32, ACT_NONE, nullptr, "logits");
   float* scores = (float*)B.alloc((size_t)n * Q * C * 4);
   float* topv = (float*)B.alloc((size_t)n * Q * 4);
   int32_t* topi = (int32_t*)B.alloc((size_t)n * Q * 4);
@@ -1044,6 +1155,17 @@ int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int3
 }
 
 // ---- kernel-level test entry points ---------------------------------------------------------------
+int rtd_debug_option(const char* name, int value) {
+  if (!name) return RTD_E_INVALID;
+  if (strcmp(name, "conv_v1") == 0) { conv_set_force_v1(value); return RTD_OK; }
+  if (strcmp(name, "dec_stamps") == 0) { g_dec_stamps = value; return RTD_OK; }
+  if (strcmp(name, "dec_fused") == 0) { g_dec_fused = value; return RTD_OK; }
+  if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
+  if (strcmp(name, "glds_drop") == 0) { conv_set_glds_drop(value); return RTD_OK; }
+  if (strcmp(name, "glds_min_blocks") == 0) { conv_set_glds_min_blocks(value); return RTD_OK; }
+  return RTD_E_INVALID;
+}
+
 int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* bias, const void* res, void* y, int B, int H,
                 int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int act, int res_mode, int out_f32) {
   return op_guard([&] {

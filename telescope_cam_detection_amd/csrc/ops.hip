@@ -187,6 +187,43 @@ void launch_maxpool3x3s2(const Tensor& x, const Tensor& y, hipStream_t s) {
   HIP_CHECK(hipGetLastError());
 }
 
+
+// ------------------------------------------------------------------------------------------ avg-pool 2x2 s2
+// nn.AvgPool2d(2, 2, 0, ceil_mode=True) of the ResNet-vd shortcut (HF:rt_detr_resnet.py:199-205); extents are
+// even here (input sizes are multiples of 32), so every window is a full 2x2.  8 channels per thread.
+template <typename T>
+__global__ void k_avgpool2(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int64_t ldx, int64_t ldy) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int V = 16 / (int)sizeof(T);
+  const int cv = C / V;
+  const int OH = H / 2, OW = W / 2;
+  const int64_t total = (int64_t)B * OH * OW * cv;
+  if (i >= total) return;
+  const int cc = (int)(i % cv) * V;
+  int64_t p = i / cv;
+  const int ox = (int)(p % OW); p /= OW;
+  const int oy = (int)(p % OH);
+  const int b = (int)(p / OH);
+  const T* q = x + (((int64_t)b * H + 2 * oy) * W + 2 * ox) * ldx + cc;
+  typedef T VT __attribute__((ext_vector_type(V)));
+  const VT a0 = *(const VT*)q, a1 = *(const VT*)(q + ldx), a2 = *(const VT*)(q + (int64_t)W * ldx), a3 = *(const VT*)(q + (int64_t)(W + 1) * ldx);
+  VT o;
+#pragma unroll
+  for (int k = 0; k < V; ++k) o[k] = (T)((((float)a0[k] + (float)a1[k]) + ((float)a2[k] + (float)a3[k])) * 0.25f);
+  *(VT*)(y + (((int64_t)b * OH + oy) * OW + ox) * ldy + cc) = o;
+}
+void launch_avgpool2(const Tensor& x, const Tensor& y, hipStream_t s) {
+  const int V = x.dt == BF16 ? 8 : 4;
+  RTD_CHECK(x.dt == y.dt && x.c == y.c && x.c % V == 0 && x.ld % V == 0 && y.ld % V == 0 && x.n == y.n, 1, "avgpool: dtype/channels");
+  RTD_CHECK(x.h % 2 == 0 && x.w % 2 == 0 && y.h == x.h / 2 && y.w == x.w / 2, 1, "avgpool: even extents only");
+  RTD_CHECK(x.bstride == (int64_t)x.h * x.w * x.ld && y.bstride == (int64_t)y.h * y.w * y.ld, 1, "avgpool: dense images");
+  RTD_CHECK((((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0, 1, "avgpool: alignment");
+  const int64_t total = (int64_t)y.n * y.h * y.w * (y.c / V);
+  DISPATCH_T(x.dt, hipLaunchKernelGGL(k_avgpool2<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const T*)x.p, (T*)y.p, x.n,
+                                      x.h, x.w, x.c, x.ld, y.ld));
+  HIP_CHECK(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------ nearest 2x upsample
 // F.interpolate(scale_factor=2, mode="nearest") (HF:v2.py:1191), written straight into the first
 // channel half of the FPN concat buffer (y is a channel-slice view).
@@ -223,13 +260,17 @@ void launch_upsample2x(const Tensor& x, const Tensor& y, hipStream_t s) {
 // tiles of 64 and read as wave-wide broadcasts; online softmax.  L is 300..1600 here, so the whole
 // problem is a few GFLOP - fp32 VALU keeps the decoder in exact-fp32 territory.
 template <typename T, int HD>
-__global__ __launch_bounds__(128) void k_attention(const T* __restrict__ qk, int64_t ldqk, const T* __restrict__ v,
+__global__ __launch_bounds__(256) void k_attention(const T* __restrict__ qk, int64_t ldqk, const T* __restrict__ v,
                                                     int64_t ldv, T* __restrict__ o, int64_t ldo, int L, int D) {
-  constexpr int KT = 64;
-  __shared__ float Ks[KT * HD];
-  __shared__ float Vs[KT * HD];
+  // 4 lanes share one query row: lane part p takes keys p, p+4, ... of every staged tile and the
+  // four partial (max, sum, acc) states are merged with two xor-shuffles at the end.
+  constexpr int KT = 64, KS = 4, QPB = 256 / KS;
+  constexpr int LDK = HD + 4;                     // padded rows: the 4 parts read 4 different rows per instruction
+  __shared__ __attribute__((aligned(16))) float Ks[KT * LDK];
+  __shared__ __attribute__((aligned(16))) float Vs[KT * LDK];
   const int b = blockIdx.z, head = blockIdx.y;
-  const int qi = blockIdx.x * 128 + threadIdx.x;
+  const int part = threadIdx.x & (KS - 1);
+  const int qi = blockIdx.x * QPB + (threadIdx.x >> 2);
   const bool active = qi < L;
   const float scale = rsqrtf((float)HD);
   float q[HD], acc[HD];
@@ -242,7 +283,7 @@ __global__ __launch_bounds__(128) void k_attention(const T* __restrict__ qk, int
   float m = -INFINITY, l = 0.f;
   for (int k0 = 0; k0 < L; k0 += KT) {
     __syncthreads();
-    for (int e = threadIdx.x; e < KT * HD; e += 128) {
+    for (int e = threadIdx.x; e < KT * HD; e += 256) {
       const int j = e / HD, d = e - j * HD;
       const int kj = k0 + j;
       float kv = 0.f, vv = 0.f;
@@ -250,15 +291,17 @@ __global__ __launch_bounds__(128) void k_attention(const T* __restrict__ qk, int
         kv = (float)qk[((int64_t)b * L + kj) * ldqk + D + head * HD + d];
         vv = (float)v[((int64_t)b * L + kj) * ldv + head * HD + d];
       }
-      Ks[e] = kv;
-      Vs[e] = vv;
+      Ks[j * LDK + d] = kv;
+      Vs[j * LDK + d] = vv;
     }
     __syncthreads();
     const int jn = min(KT, L - k0);
-    for (int j = 0; j < jn; ++j) {
+    for (int j = part; j < jn; j += KS) {
+      const float* kr = &Ks[j * LDK];
+      const float* vr = &Vs[j * LDK];
       float sc = 0.f;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) sc = fmaf(q[d], Ks[j * HD + d], sc);
+      for (int d = 0; d < HD; ++d) sc = fmaf(q[d], kr[d], sc);
       if (sc > m) {
         const float f = __expf(m - sc);
         l *= f;
@@ -269,14 +312,28 @@ __global__ __launch_bounds__(128) void k_attention(const T* __restrict__ qk, int
       const float p = __expf(sc - m);
       l += p;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) acc[d] = fmaf(p, Vs[j * HD + d], acc[d]);
+      for (int d = 0; d < HD; ++d) acc[d] = fmaf(p, vr[d], acc[d]);
     }
+  }
+  // merge the 4 partial softmax states (a part that saw no key has m = -inf, l = 0)
+#pragma unroll
+  for (int off = 1; off < KS; off <<= 1) {
+    const float mo = __shfl_xor(m, off, 64), lo = __shfl_xor(l, off, 64);
+    const float mn = fmaxf(m, mo);
+    const float fa = (m == -INFINITY) ? 0.f : __expf(m - mn);
+    const float fb = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+    l = l * fa + lo * fb;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] = acc[d] * fa + __shfl_xor(acc[d], off, 64) * fb;
+    m = mn;
   }
   if (active) {
     const float inv = 1.f / l;
     T* orow = o + ((int64_t)b * L + qi) * ldo + head * HD;
+    // each of the 4 lanes writes a quarter of the row
 #pragma unroll
-    for (int d = 0; d < HD; ++d) orow[d] = (T)(acc[d] * inv);
+    for (int d = 0; d < HD; ++d)
+      if (d / (HD / KS) == part) orow[d] = (T)(acc[d] * inv);    // static register index, predicated store
   }
 }
 
@@ -286,7 +343,7 @@ void launch_attention(const Tensor& qk, const Tensor& v, const Tensor& o, int he
   RTD_CHECK(qk.dt == v.dt && qk.dt == o.dt, 1, "attention: dtype");
   RTD_CHECK(D % heads == 0, 1, "attention: heads");
   const int hd = D / heads;
-  const dim3 grid((L + 127) / 128, heads, B), blk(128);
+  const dim3 grid((L + 63) / 64, heads, B), blk(256);
 #define ATT_GO(HD) DISPATCH_T(qk.dt, hipLaunchKernelGGL((k_attention<T, HD>), grid, blk, 0, s, (const T*)qk.p, qk.ld, (const T*)v.p, v.ld, (T*)o.p, o.ld, L, D))
   if (hd == 32) ATT_GO(32);
   else if (hd == 48) ATT_GO(48);

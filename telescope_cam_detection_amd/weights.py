@@ -8,8 +8,7 @@ Three things live here, all host-side "load_model" work (reference: src/rtdetr_d
   prescribes (no checkpoint exists offline; HF's default init gives an all-ties top-k).
 * `fold_weights()` / `pack_blob()` - what upstream's `.deploy()` does at load time
   (src/rtdetr_detector.py:164-165): BN folded into the conv, RepVGG 3x3+1x1 re-parameterised
-  into one 3x3, plus this build's own layout choices (OHWI filters, fused sibling GEMMs,
-  AvgPool2d(2,2)+1x1 shortcut expressed as one 2x2 stride-2 filter).  The blob is a flat
+  into one 3x3, plus this build's own layout choices (OHWI filters, fused sibling GEMMs).  The blob is a flat
   container of named fp32 tensors that `rtd_load_weights` (include/rtdetr_mi355.h) parses.
 """
 from __future__ import annotations
@@ -226,11 +225,7 @@ def fold_weights(arch: Arch, w: Dict[str, torch.Tensor]) -> Dict[str, torch.Tens
             put(pfx + s, _ohwi(f), b)
         if (pfx + ".sc") in spec:
             f, b = _fold_bn(w, pfx + ".sc")
-            f = _ohwi(f)                                   # [Co,1,1,Ci]
-            if stride == 2:
-                # AvgPool2d(2,2,ceil) + 1x1  ==  2x2 stride-2 filter with every tap = W/4
-                # (resnet.py:199-213).  Odd extents are fixed up in the conv epilogue.
-                f = (f / 4.0).expand(-1, 2, 2, -1).contiguous()
+            f = _ohwi(f)                                   # [Co,1,1,Ci]; stride 2: the engine runs AvgPool2d(2,2) first
             put(pfx + ".sc", f, b)
     d, h = arch.enc_dim, arch.csp_hidden
     for l in range(3):

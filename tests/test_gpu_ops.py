@@ -41,6 +41,13 @@ CONV_CASES = [
     (1, 300, 1, 8, 512, 1, 1, 0, "relu", 0),       # K=8 (query_pos layer 0)
     (1, 64, 64, 256, 256, 3, 1, 1, "gelu", 0),     # big enough for the 128x128 tile path
     (4, 80, 80, 128, 128, 3, 1, 1, "silu", 1),     # 128x128 tile, many blocks
+    # shapes large enough for the v2 (128-pixel, LDS-staged epilogue) path
+    (2, 120, 120, 64, 64, 1, 1, 0, "relu", 1),     # v2 BN=64, pre-activation residual
+    (4, 100, 97, 128, 192, 3, 1, 1, "silu", 2),    # v2/v3 BN=128, ragged M, partial last N tile, post residual
+    (2, 160, 160, 64, 256, 1, 1, 0, "relu", 1),    # stage-0 c3 shape
+    (4, 208, 128, 256, 384, 3, 2, 1, "silu", 0),   # v2/v3 stride 2
+    (1, 26000, 1, 256, 288, 1, 1, 0, "none", 0),   # v2 token GEMM, N = 288
+    (2, 96, 96, 512, 64, 1, 1, 0, "gelu", 0),      # v2 BN=64, K = 512
 ]
 
 
@@ -71,7 +78,10 @@ def test_conv(L, dt, case):
     wd = w.permute(0, 2, 3, 1).contiguous().cuda()      # OHWI fp32
     bd = b.cuda()
     rd = nhwc(res, tdt) if res is not None else None
-    for out_f32 in ((1,) if dt == "f32" else (0, 1)):
+    from telescope_cam_detection_amd import _capi
+    # conv_mode 0 = auto (LDS-DMA kernel where eligible), 2 = register-staged large tile, 1 = small tiles only
+    for out_f32, mode in (((1, 0), (1, 1), (1, 2)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 2))):
+        _capi.debug_option("conv_mode", mode)
         yd = torch.full((B, OH, OW, Cout), float("nan"), dtype=torch.float32 if out_f32 else tdt, device="cuda")
         ck(L, L.rtd_op_conv(code, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None,
                             yd.data_ptr(), B, H, W, Cin, Cout, k, k, stride, pad, {"none": 0, "relu": 1, "silu": 2, "gelu": 3}[act],
@@ -85,6 +95,7 @@ def test_conv(L, dt, case):
         else:
             tol = dict(atol=2e-2, rtol=1e-2)       # + one bf16 rounding of the output
         torch.testing.assert_close(got, y, **tol)
+    _capi.debug_option("conv_mode", 0)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])

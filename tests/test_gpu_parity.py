@@ -27,7 +27,7 @@ def make_engine(arch, w, frames, input_size, precision, use_graph=False):
 
 
 def oracle_run(arch, w, frames, input_size):
-    torch.set_num_threads(16)
+    torch.set_num_threads(min(16, len(__import__('os').sched_getaffinity(0))))
     xs, sizes = zip(*[orc.preprocess(f, input_size) for f in frames])
     col = {}
     out = orc.model_forward(arch, w, torch.cat(xs, 0), list(sizes), collect=col)
@@ -91,6 +91,26 @@ def test_graph_replay_equals_eager(name):
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)
     e1.close(); e2.close()
+
+
+def test_fused_decoder_equals_per_op_decoder():
+    """decoder.hip's one-kernel-per-layer path against the one-launch-per-op path (both exact fp32)."""
+    from telescope_cam_detection_amd import _capi
+    arch, wseed, input_size, frames, g = load_case("c1_r18_640_scene")
+    w = weights_for(arch, wseed)
+    outs = []
+    for fused in (0, 1):
+        _capi.debug_option("dec_fused", fused)
+        eng = make_engine(arch, w, frames, input_size, "fp32")
+        outs.append(eng.infer_raw(frames) + (eng.debug_tensor(f"dec{arch.dec_layers - 1}.hs"), eng.debug_tensor("ref")))
+        eng.close()
+    _capi.debug_option("dec_fused", 1)
+    (l0, b0, s0, h0, r0), (l1, b1, s1, h1, r1) = outs
+    np.testing.assert_allclose(h1, h0, atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(r1[..., :4], r0[..., :4], atol=2e-6)
+    for b in range(len(frames)):
+        m, n, ws, wb = match_detections(l0[b], b0[b], s0[b], l1[b], b1[b], s1[b], 1e-5, 2e-3)
+        assert m == n, (m, n, ws, wb)
 
 
 BF16_CASES = ["t_tiny_160", "t_tinyb_192x128", "c1_r18_640_scene", "c1_r18_640_resize", "c2_r50_640_scene_bs2"]
