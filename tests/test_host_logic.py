@@ -1,0 +1,154 @@
+"""CPU: host-side logic - load-time folding against the oracle, blob round trip, C-ABI export list,
+the drop-in class's failure behaviour without a GPU, and the N>1 collate path on gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import rtdetr_oracle as orc
+from telescope_cam_detection_amd.arch import ARCHS, arch_from_config_path
+from telescope_cam_detection_amd.weights import fold_weights, pack_blob, synth_weights, unpack_blob
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_fold_bn_and_repvgg_match_unfused_oracle():
+    """what `.deploy()` does at load time (src/rtdetr_detector.py:164-165): conv+BN and RepVGG 3x3+1x1 folded."""
+    arch = ARCHS["tiny"]
+    w = synth_weights(arch, 3)
+    f = fold_weights(arch, w)
+    x = torch.randn(2, arch.enc_dim * 2, 12, 10)
+    # CSP c12 = [c1 | c2] of the un-fused oracle
+    ref1 = orc.conv_bn(w, "enc.fpn.0.c1", x, act="silu")
+    ref2 = orc.conv_bn(w, "enc.fpn.0.c2", x, act="silu")
+    got = F.silu(F.conv2d(x, f["enc.fpn.0.c12.w"].permute(0, 3, 1, 2), f["enc.fpn.0.c12.b"]))
+    h = arch.csp_hidden
+    torch.testing.assert_close(got[:, :h], ref1, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(got[:, h:], ref2, atol=2e-5, rtol=1e-5)
+    # RepVGG: 3x3 + 1x1 branches -> one 3x3
+    y = torch.randn(2, h, 9, 7)
+    ref = F.silu(orc.conv_bn(w, "enc.fpn.0.rep0.k3", y, padding=1) + orc.conv_bn(w, "enc.fpn.0.rep0.k1", y, padding=0))
+    got = F.silu(F.conv2d(y, f["enc.fpn.0.rep0.w"].permute(0, 3, 1, 2), f["enc.fpn.0.rep0.b"], padding=1))
+    torch.testing.assert_close(got, ref, atol=2e-5, rtol=1e-5)
+    # stem conv: input channels padded 3 -> 8 with zeros
+    assert f["backbone.stem.0.w"].shape[-1] == 8 and float(f["backbone.stem.0.w"][..., 3:].abs().max()) == 0.0
+    # fused sibling GEMMs keep row order
+    assert torch.equal(f["dec.l0.ca.offaw.w"][: w["dec.l0.ca.off.w"].shape[0]], w["dec.l0.ca.off.w"])
+    assert torch.equal(f["dec.vp_all.w"][arch.d_model:2 * arch.d_model], w["dec.l1.ca.vp.w"])
+    assert f["dec.qpos.0.w"].shape[1] == 8
+
+
+def test_blob_roundtrip_and_alignment():
+    arch = ARCHS["tinyb"]
+    f = fold_weights(arch, synth_weights(arch, 5))
+    blob = pack_blob(f)
+    back = unpack_blob(blob)
+    assert set(back) == set(f)
+    for k, v in f.items():
+        np.testing.assert_array_equal(back[k], v.numpy())
+    with pytest.raises(AssertionError):
+        unpack_blob(b"XXXX" + blob[4:])
+
+
+def test_arch_from_config_path():
+    assert arch_from_config_path("RT-DETR/rtdetrv2_pytorch/configs/rtdetrv2/rtdetrv2_r18vd_120e_coco.yml").name == "r18"
+    assert arch_from_config_path("configs/rtdetrv2/rtdetrv2_r50vd_6x_coco.yml").name == "r50"
+    assert arch_from_config_path("configs/rtdetrv2/rtdetrv2_r101vd_6x_coco.yml").name == "r101"
+    with pytest.raises(ValueError):
+        arch_from_config_path("yolox_s.py")
+    assert ARCHS["r50"].level_shapes(640, 640) == [(80, 80), (40, 40), (20, 20)]
+    assert ARCHS["r101"].level_shapes(1280, 1280) == [(160, 160), (80, 80), (40, 40)]
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """no compute calls without a GPU: dlopen + symbol table only"""
+    from telescope_cam_detection_amd import _capi
+    lib = _capi.lib()
+    header = open(os.path.join(ROOT, "include", "rtdetr_mi355.h")).read()
+    declared = set(re.findall(r"\b(rtd_[a-z0-9_]+)\s*\(", header))
+    declared -= {"rtd_engine"}
+    assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.rtd_version().startswith(b"mi355-rtdetr")
+    # argument validation happens before any HIP call
+    cfg = _capi.make_config(ARCHS["r18"], 0, _capi.PREC_BF16, 8, (641, 640), True)
+    h = ctypes.c_void_p()
+    assert lib.rtd_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.RTD_E_INVALID
+    assert b"multiple of 32" in lib.rtd_last_error(None)
+    cfg = _capi.make_config(ARCHS["r18"], 0, _capi.PREC_BF16, 8, (640, 640), True)
+    cfg.struct_size = 12
+    assert lib.rtd_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.RTD_E_INVALID
+    assert lib.rtd_debug_option(b"no_such_option", 1) == _capi.RTD_E_INVALID
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_detector_fails_loudly_without_gpu():
+    """the product path has no CPU fallback: load_model() -> False (never raises), detect() -> [] (reference :248-250)"""
+    from telescope_cam_detection_amd.rtdetr_detector import RTDETRDetector
+    det = RTDETRDetector(config_path="tiny", model_path="synthetic:tiny:1", device="cuda:0", input_size=(160, 160))
+    assert det.load_model(max_retries=1) is False
+    assert det.model is None
+    assert det.detect(np.zeros((160, 160, 3), np.uint8)) == []
+    assert det.detect_batch([np.zeros((160, 160, 3), np.uint8)] * 2) == [[], []]
+    cpu = RTDETRDetector(config_path="tiny", model_path="synthetic:tiny:1", device="cpu", input_size=(160, 160))
+    assert cpu.load_model(max_retries=1) is False          # "cpu" is not a device this detector can use
+    assert det.is_wildlife_relevant(21) and det.get_class_category(14) == "bird"
+
+
+def test_block_to_detections_matches_reference_row_loop():
+    from telescope_cam_detection_amd.shard import block_to_detections
+    rng = np.random.default_rng(0)
+    Q = 40
+    labels = rng.integers(0, 80, Q)
+    scores = np.sort(rng.uniform(0, 1, Q).astype(np.float32))[::-1]
+    boxes = rng.uniform(0, 640, (Q, 4)).astype(np.float32)
+    block = np.concatenate([labels[:, None].astype(np.float32), scores[:, None], boxes], 1)[None]
+    for wl in (True, False):
+        assert block_to_detections(block, 0.3, wl)[0] == orc.format_detections(labels, boxes, scores, 0.3, wl)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _collate_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from telescope_cam_detection_amd.shard import cameras_of_rank, collate_blocks
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    cams = cameras_of_rank(4, rank, world)                   # 4 cameras over 2 ranks
+    block = torch.stack([torch.full((5, 6), float(10 * k)) + torch.arange(6) for k in cams])   # [2, Q=5, 6]
+    out = collate_blocks(block)
+    dist.barrier()
+    q.put((rank, cams, out.numpy()))
+    dist.destroy_process_group()
+
+
+def test_collate_detections_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_collate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2] and res[1][1] == [1, 3]
+    for rank, cams, out in res:
+        assert out.shape == (2, 2, 5, 6)
+        for r in range(2):
+            for j, k in enumerate([r, r + 2]):               # camera k lives on rank k % 2
+                np.testing.assert_array_equal(out[r, j], np.full((5, 6), 10.0 * k) + np.arange(6))
