@@ -668,6 +668,206 @@ __global__ __launch_bounds__(256, (STAGES == 2 ? 2 : 1)) void conv_igemm_glds_ke
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v4: wave-specialised LDS-DMA kernel.  Same tile / swizzle / epilogue as v3, but 8 waves per block with
+// fixed roles: waves 0-3 only read fragments and issue MFMAs (one per SIMD, 64x64 outputs each), waves 4-7
+// only compute im2col offsets and issue the `buffer_load ... lds` DMA, STAGES-1 tiles ahead.  In v3 every
+// wave paid ~8 DMA issues (60-185 cycles each next to MFMAs, MI355X_MICROARCH.md cycle constants) per
+// 16 MFMAs; the `glds_drop=4` probe showed 25 % of the kernel was DMA issue.  Here the issue cost runs on
+// the loader waves beside the MFMA waves.  One s_barrier per K-step orders both roles:
+//   loader : wait tile ks (counted vmcnt) | barrier | issue tile ks+STAGES-1
+//   compute:                                barrier | MFMA tile ks
+// ------------------------------------------------------------------------------------------------
+template <typename T, int STAGES>
+__global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kernel(const ConvG g) {
+  const ConvK& a = g.k;
+  constexpr int BM = 128, BN = 128;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int BK = 128 / ES;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int SLD = BN + 4;
+  constexpr int SMEM = (STAGES * STAGE > BM * SLD * 4) ? STAGES * STAGE : BM * SLD * 4;
+  constexpr int AHEAD = STAGES - 1;
+  static_assert(STAGES >= 2 && STAGES <= 4, "counted waits below assume 1..3 tiles ahead");
+  typedef typename Mma<T>::Frag Frag;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform -> scalar role branches
+  const bool loader = wv >= 4;
+  const int w4 = wv & 3;
+  const int wm = w4 & 1, wn = w4 >> 1;
+  int wg;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = wg % a.ntn, mt = wg / a.ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int nk = a.Kpad / BK;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (loader) {
+    // ---- loader role -------------------------------------------------------------------------------
+    const int lrow = w4 * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((w4 * 4 + (lane >> 4)) & 7);
+    int a_off[4], a_iy0[4], a_ix0[4], b_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + i * 32 + lrow;
+      if (m < a.M) {
+        const int b = m / a.OHW;
+        const int r = m - b * a.OHW;
+        const int oy = r / a.OW;
+        const int ox = r - oy * a.OW;
+        a_iy0[i] = oy * a.stride - a.pad;
+        a_ix0[i] = ox * a.stride - a.pad;
+        a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)a_iy0[i] * a.W + a_ix0[i]) * a.ldx) * ES) + chunk * 16;
+      } else {
+        a_iy0[i] = -(1 << 28);
+        a_ix0[i] = -(1 << 28);
+        a_off[i] = 0;
+      }
+      b_off[i] = (n0 + i * 32 + lrow) * a.Kpad * ES + chunk * 16;
+    }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
+    int kh = 0, kw = 0, c0 = 0, k0 = 0;
+    auto issue = [&](int buf) {
+      char* sa = smem + buf * STAGE + w4 * 1024;
+      const int delta = ((kh * a.W + kw) * (int)a.ldx + c0) * ES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+        const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const unsigned vo = ok ? (unsigned)(a_off[i] + delta) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 4096), 16, vo, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sa + BM * 128 + i * 4096), 16, (unsigned)(b_off[i] + k0 * ES), 0, 0, 0);
+      k0 += BK;
+      c0 += BK;
+      if (c0 >= a.Cin) {
+        c0 = 0;
+        if (++kw == a.KW) { kw = 0; ++kh; }
+      }
+    };
+    for (int t = 0; t < AHEAD && t < nk; ++t) issue(t);
+    for (int ks = 0; ks < nk; ++ks) {
+      const int younger = nk - 1 - ks;
+      if (STAGES == 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (STAGES >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (ks + AHEAD < nk) issue((ks + AHEAD) % STAGES);
+    }
+  } else {
+    // ---- MFMA role ---------------------------------------------------------------------------------
+    int foff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 128 + (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
+    for (int ks = 0; ks < nk; ++ks) {
+      __builtin_amdgcn_s_barrier();
+      const char* sa = smem + (ks % STAGES) * STAGE + wm * 64 * 128;
+      const char* sb = smem + (ks % STAGES) * STAGE + (BM + wn * 64) * 128;
+      Frag xf[2][2], wf[2][2];                     // [register buffer][tile]: fragments of step kk+1 load under the MFMAs of kk
+#pragma unroll
+      for (int j = 0; j < 2; ++j) xf[0][j] = *(const Frag*)(sa + j * 4096 + foff[0]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wf[0][i] = *(const Frag*)(sb + i * 4096 + foff[0]);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) xf[(kk + 1) & 1][j] = *(const Frag*)(sa + j * 4096 + foff[kk + 1]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) wf[(kk + 1) & 1][i] = *(const Frag*)(sb + i * 4096 + foff[kk + 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) Mma<T>::run(wf[kk & 1][i], xf[kk & 1][j], acc[i][j]);
+      }
+    }
+  }
+  __syncthreads();                                 // every MFMA operand read is done: smem becomes the fp32 staging tile
+
+  float* st = (float*)smem;
+  if (!loader) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pl = wm * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          *(f32x4*)(&st[pl * SLD + wn * 64 + i * 32 + 8 * q + 4 * h]) = v;
+        }
+    }
+  }
+  __syncthreads();
+  const int c8 = tid & 15;
+  const int c = n0 + c8 * 8;
+  if (c < a.N) {
+    const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int pl = (tid >> 4) + it * 32;
+      const int m = m0 + pl;
+      if (m >= a.M) continue;
+      const f32x4 s0 = *(const f32x4*)(&st[pl * SLD + c8 * 8]), s1 = *(const f32x4*)(&st[pl * SLD + c8 * 8 + 4]);
+      float v[8] = {s0[0] + b0[0], s0[1] + b0[1], s0[2] + b0[2], s0[3] + b0[3],
+                    s1[0] + b1[0], s1[1] + b1[1], s1[2] + b1[2], s1[3] + b1[3]};
+      const int b = m / a.OHW;
+      const int p = m - b * a.OHW;
+      float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (a.res_mode != RES_NONE) {
+        const long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
+        if (a.res_f32) {
+          const f32x4 t0 = *(const f32x4*)((const float*)a.res + roff), t1 = *(const f32x4*)((const float*)a.res + roff + 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { rv[q] = t0[q]; rv[4 + q] = t1[q]; }
+        } else {
+          const bf16x8 t = *(const bf16x8*)((const bf16*)a.res + roff);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) rv[q] = (float)t[q];
+        }
+      }
+      if (a.res_mode == RES_PRE) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = act_fn(v[q], a.act);
+      if (a.res_mode == RES_POST) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+      }
+      const long long yoff = (long long)b * a.y_bstride + (long long)p * a.ldy + c;
+      if (a.y_f32) {
+        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        *(f32x4*)((float*)a.y + yoff) = o0;
+        *(f32x4*)((float*)a.y + yoff + 4) = o1;
+      } else {
+        bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+        *(bf16x8*)((bf16*)a.y + yoff) = o;
+      }
+    }
+  }
+}
+
 int conv_kpad(int K) { return (K + 63) / 64 * 64; }
 int conv_npad(int N) { return (N + 127) / 128 * 128; }
 
@@ -681,7 +881,7 @@ void conv_set_glds_drop(int v) { g_glds_drop = v; }
 void conv_set_mode(int v) { g_conv_mode = v; g_force_v1 = (v == 1); }
 template <typename T>
 static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long w_bytes, hipStream_t s) {
-  if (!ok || g_conv_mode != 0) return false;
+  if (!ok || g_conv_mode == 1 || g_conv_mode == 2) return false;     // 5 = single-role LDS-DMA kernels (v3) for A/B
   const long long mt = (k.M + 127) / 128, ntn = (k.N + 127) / 128;
   if (k.N < 128 || mt * ntn < (sizeof(T) == 2 ? g_glds_min_blocks : 512) || x_bytes >= (1ll << 31) || w_bytes >= (1ll << 31)) return false;
   ConvG g;
@@ -692,6 +892,18 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
   g.w_bytes = (g_glds_drop & 2) ? 0u : (unsigned)w_bytes;
   // grids that fill every CU twice run 2 blocks/CU with a 2-deep pipeline; smaller grids get the
   // whole LDS for one block and a 4-deep pipeline
+  if (g_conv_mode == 3 || g_conv_mode == 4) {      // A/B: wave-specialised kernel everywhere (3 = 4 stages, 4 = 2 stages at 2 blocks/CU)
+    if (g_conv_mode == 3) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+    return true;
+  }
+  // measured (tools/profile_layers.py --ab conv_mode): loader/MFMA wave roles win at every grid size; >= 512 tiles run
+  // 2 blocks per CU with 2 stages, smaller grids 1 block per CU with 4 stages (3 tiles of DMA in flight)
+  if (g_conv_mode == 0) {
+    if (mt * ntn < 512) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+    return true;
+  }
   if (mt * ntn >= 512) hipLaunchKernelGGL((conv_igemm_glds_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(256), 0, s, g);
   else hipLaunchKernelGGL((conv_igemm_glds_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(256), 0, s, g);
   return true;
@@ -702,7 +914,7 @@ static bool dispatch_v2(const ConvK& k, bool v2_ok, hipStream_t s) {
   if (!v2_ok || g_force_v1) return false;
   const long long mt = (k.M + 127) / 128;
   ConvK kk = k;
-  if (g_conv_mode == 0) {
+  if (g_conv_mode == 0 || g_conv_mode >= 3) {
     // measured on R50 bs8 (tools/profile_layers.py): the 128-pixel register-staged tile only pays with
     // >= 2 blocks per CU slot; smaller grids run faster on v1's 64x64 tiles (more, shorter blocks)
     if (!(k.N >= 128 && mt * ((k.N + 127) / 128) >= 512)) return false;

@@ -79,8 +79,9 @@ def test_conv(L, dt, case):
     bd = b.cuda()
     rd = nhwc(res, tdt) if res is not None else None
     from telescope_cam_detection_amd import _capi
-    # conv_mode 0 = auto (LDS-DMA kernel where eligible), 2 = register-staged large tile, 1 = small tiles only
-    for out_f32, mode in (((1, 0), (1, 1), (1, 2)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 2))):
+    # conv_mode 0 = auto (LDS-DMA kernel where eligible), 2 = register-staged large tile, 1 = small tiles only,
+    # 3 / 4 = wave-specialised LDS-DMA kernel (4 / 3 stages)
+    for out_f32, mode in (((1, 0), (1, 1), (1, 2), (1, 3)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (0, 4))):
         _capi.debug_option("conv_mode", mode)
         yd = torch.full((B, OH, OW, Cout), float("nan"), dtype=torch.float32 if out_f32 else tdt, device="cuda")
         ck(L, L.rtd_op_conv(code, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None,
