@@ -124,11 +124,15 @@ struct DecLN {
 };
 
 struct DecArgs {
-  int mode;                 // 0 = prologue (enc_bbox head + ref init + next projections), 1 = layer, 2 = last layer (+ class head)
+  int mode;                 // 0 = prologue (enc_bbox head + ref init + next projections), 1 = layer, 2 = last layer (+ class head),
+                            // 3 = AIFI prologue (x + pos -> q, K/V fragments), 4 = AIFI encoder layer
   int B, Q, D, heads, S, n_levels, n_points, ffn, C;
   float offset_scale;
   // per-row state (global, fp32)
-  const float* att;         // [B*Q, D]   self-attention output (mode 1,2)
+  // self-attention inputs of this layer (written by the previous launch): q rows + K / V in MFMA-fragment order
+  const float* q_in;        // [B*Q, D]
+  const float* kfrag_in;    // [B][heads][tiles][2][64 lanes][4]: K[key 16t+(lane&15)][32h + 16c + 4(lane>>4) + u]
+  const float* vfrag_in;    // [B][heads][tiles][2][64 lanes][4]: V[key 16t+4(lane>>4)+u][32h + 16d + (lane&15)]
   const float* hs_in;       // [B*Q, D]
   float* hs_out;            // [B*Q, D]
   const float* qpos_in;     // [B*Q, D]
@@ -142,9 +146,11 @@ struct DecArgs {
   const int32_t* lvl;       // [n_levels][3] h, w, start
   // outputs for the next layer
   float* qpos_out;          // [B*Q, D]
-  float* qk_out;            // [B*Q, 2D]
-  float* v_out;             // [B*Q, D]
+  float* q_out;             // [B*Q, D]
+  float* kfrag_out;         // same layouts as *_in, for the next layer (ping-pong buffers)
+  float* vfrag_out;
   float* logits;            // mode 2: [B*Q, C]
+  void* out_bf16;           // mode 4: write the output tokens as bf16 here instead of fp32 hs_out (nullptr = fp32)
   float* stamps;            // diagnostic: [blocks][16] phase end times (10 ns units) or nullptr
   // weights
   DecLin o, offaw, op, fc1, fc2, bb0, bb1, bb2, qp0, qp1, qk, v, cls;

@@ -91,6 +91,7 @@ __device__ void row_gemm(const float* Xs, int ldx, const DecLin& L, float* Ys, i
           float v = (h == 0 ? acc0[r] : acc1[r]) + bv;
           if (Rs) v += Rs[row * ldr + col];
           if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
+          if (ACT == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
           Ys[row * ldy + col] = v;
         }
       }
@@ -211,6 +212,79 @@ __device__ void sample_rows(const DecArgs& a, const float* sO, int LDO, const fl
   }
 }
 
+
+// Self-attention of the block's 16 query rows (HF:v2.py:246-336, no mask), one head per wave, exact fp32 MFMA.
+// Computed TRANSPOSED so nothing crosses LDS: per 16-key tile  S^T = K Q^T  (keys on accumulator rows, the
+// lane's query on the column), so the softmax reductions over keys are 4 registers + two xor-shuffles (16, 32),
+// and the accumulator tile of P^T is already the B-fragment of the next product  O^T += V^T P^T
+// (MI355X guide: "an accumulator tile as the next MFMA's operand").  K and V were written by the previous launch
+// in fragment order, so each operand fetch is one contiguous 1 KiB wave load.
+__device__ void self_attention_rows(const DecArgs& a, const float* sQ, int ldq, float* sA, int LDH, int b, int tiles, int wave, int lane) {
+  const int head = wave;                                        // NW == heads
+  const int r16 = lane & 15, q = lane >> 4;
+  const float scale = rsqrtf(32.f);
+  f32x4_ qa[2];                                                 // Q[query r16][32 head + 16 c + 4 q + u] * scale
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    qa[c] = *(const f32x4_*)(sQ + r16 * ldq + head * 32 + 16 * c + 4 * q);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) qa[c][u] *= scale;
+  }
+  float m = -INFINITY, l = 0.f;                                 // running max / sum of this lane's query
+  f32x4_ O[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // O^T: dims 16 d + 4 q + r of query r16
+  const float* kb = a.kfrag_in + ((size_t)(b * a.heads + head) * tiles) * 512 + lane * 4;
+  const float* vb = a.vfrag_in + ((size_t)(b * a.heads + head) * tiles) * 512 + lane * 4;
+  f32x4_ kc[2], vc[2], kn[2], vn[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) { kc[c] = *(const f32x4_*)(kb + c * 256); vc[c] = *(const f32x4_*)(vb + c * 256); }
+  for (int t = 0; t < tiles; ++t) {
+    const int tn = min(t + 1, tiles - 1);                       // unconditional prefetch (clamped)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { kn[c] = *(const f32x4_*)(kb + (size_t)tn * 512 + c * 256); vn[c] = *(const f32x4_*)(vb + (size_t)tn * 512 + c * 256); }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4_ S = {0.f, 0.f, 0.f, 0.f};                            // S^T[key 4 q + r][query r16]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) S = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[c][u], qa[c][u], S, 0, 0, 0);
+    float sv[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sv[r] = (t * 16 + 4 * q + r < a.Q) ? S[r] : -INFINITY;
+      mx = fmaxf(mx, sv[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __expf(m - mn);
+    f32x4_ p;
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { p[r] = __expf(sv[r] - mn); rs += p[r]; }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    l = l * alpha + rs;
+    m = mn;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) O[d][r] *= alpha;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) O[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc[d][u], p[u], O[d], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { kc[c] = kn[c]; vc[c] = vn[c]; }
+  }
+  const float inv = 1.f / l;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    f32x4_ o = {O[d][0] * inv, O[d][1] * inv, O[d][2] * inv, O[d][3] * inv};
+    *(f32x4_*)(sA + r16 * LDH + head * 32 + 16 * d + 4 * q) = o;
+  }
+}
+
 // diagnostic phase stamps (100 MHz wall clock), enabled only when a.stamps != nullptr (rtd_debug_option "dec_stamps")
 #define DEC_STAMP(i)                                                                         \
   do {                                                                                       \
@@ -236,25 +310,32 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
   const int D = a.D;
   const long long row0 = (long long)b * a.Q + q0;
   const int nvalid = min(DR, a.Q - q0);
+  // modes: 0 decoder prologue | 1 decoder layer | 2 last decoder layer | 3 AIFI prologue (x + pos -> q,k,v) |
+  //        4 AIFI layer (self-attention, o-proj + LN, GELU FFN + LN; HF:v2.py:838-904)
+  const bool has_attn = a.mode == 1 || a.mode == 2 || a.mode == 4;
+  const bool has_cross = a.mode == 1 || a.mode == 2;
 
   // ---- load the block's rows --------------------------------------------------------------------
   for (int e = tid; e < DR * D; e += NT) {
     const int r = e / D, c = e - r * D;
     const bool ok = r < nvalid;
     sH[r * LDH + c] = ok ? a.hs_in[(row0 + r) * D + c] : 0.f;
-    if (a.mode != 0) {
-      sA[r * LDH + c] = ok ? a.att[(row0 + r) * D + c] : 0.f;
-      sP[r * LDH + c] = ok ? a.qpos_in[(row0 + r) * D + c] : 0.f;
-    }
+    if (has_attn) sT[r * LDQ + c] = ok ? a.q_in[(row0 + r) * D + c] : 0.f;
+    if (has_cross) sP[r * LDH + c] = ok ? a.qpos_in[(row0 + r) * D + c] : 0.f;
+    if (a.mode == 3) sP[r * LDH + c] = ok ? a.qpos_in[(long long)(q0 + r) * D + c] : 0.f;   // AIFI: one sin-cos table for every image
   }
   for (int e = tid; e < DR * LDR; e += NT) {
     const int r = e / LDR, c = e - r * LDR;
-    sR[e] = (a.mode != 0 && r < nvalid && c < 4) ? a.ref8[(row0 + r) * 8 + c] : 0.f;
+    sR[e] = (has_cross && r < nvalid && c < 4) ? a.ref8[(row0 + r) * 8 + c] : 0.f;
   }
   __syncthreads();
   DEC_STAMP(0);   // rows loaded
 
-  if (a.mode != 0) {
+  if (has_attn) {
+    // ---- self-attention (q in sT, K/V fragments from the previous launch) -> sA ----------------------------
+    self_attention_rows(a, sT, LDQ, sA, LDH, b, tiles, wave, lane);
+    __syncthreads();
+    DEC_STAMP(12);  // self-attention
     // ---- self-attention output projection + residual + LN1 (HF:v2.py:395-405) ---------------------
     row_gemm<ACT_NONE>(sA, LDH, a.o, sH, LDH, sH, LDH, wave, lane);      // x = hs + att @ Wo   (in place: each element read then written by one lane)
     __syncthreads();
@@ -262,6 +343,8 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     row_ln(sH, LDH, D, a.ln1, wave, lane);
     __syncthreads();
     DEC_STAMP(2);   // ln1
+  }
+  if (has_cross) {
     // ---- cross attention: (x + qpos) -> offsets | weights (HF:v2.py:170-186) -------------------------
     for (int e = tid; e < DR * D; e += NT) {
       const int r = e / D, c = e - r * D;
@@ -282,8 +365,11 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     row_ln(sH, LDH, D, a.ln2, wave, lane);
     __syncthreads();
     DEC_STAMP(5);   // op + ln2
-    // ---- FFN + residual + LN3 (HF:v2.py:423-428) ------------------------------------------------------
-    row_gemm<ACT_RELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane);
+  }
+  if (has_attn) {
+    // ---- FFN + residual + LN3 (HF:v2.py:423-428; AIFI: GELU, :888-896) ---------------------------------
+    if (a.mode == 4) row_gemm<ACT_GELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane);
+    else row_gemm<ACT_RELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane);
     __syncthreads();
     DEC_STAMP(6);   // fc1
     row_gemm<ACT_NONE>(sF, LDF, a.fc2, sH, LDH, sH, LDH, wave, lane);
@@ -292,7 +378,19 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     __syncthreads();
     DEC_STAMP(7);   // fc2 + ln3
   }
+  if (a.mode == 4) {
+    // AIFI output tokens in the trunk's storage type (they feed the CCFF convolutions)
+    for (int e = tid; e < DR * D; e += NT) {
+      const int r = e / D, c = e - r * D;
+      if (r < nvalid) {
+        if (a.out_bf16) ((bf16*)a.out_bf16)[(row0 + r) * D + c] = (bf16)sH[r * LDH + c];
+        else a.hs_out[(row0 + r) * D + c] = sH[r * LDH + c];
+      }
+    }
+    return;
+  }
 
+  if (a.mode != 3) {
   // ---- box head: mode 0 = enc_bbox_head(target) + anchors (HF:v2.py:1588-1599), else bbox_embed[i] + logit(ref) (:636-639)
   row_gemm<ACT_RELU>(sH, LDH, a.bb0, sA, LDH, nullptr, 0, wave, lane);
   __syncthreads();
@@ -328,6 +426,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     }
   }
   __syncthreads();
+  }   // mode != 3
 
   if (a.mode == 2) {
     // ---- class head of the last layer (HF:v2.py:644-646,1880) ----------------------------------------
@@ -341,35 +440,45 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
   }
 
   // ---- projections for the NEXT layer: qpos = MLP(ref) (HF:v2.py:613), q|k = (hs+qpos) Wqk, v = hs Wv ----
-  row_gemm<ACT_RELU>(sR, LDR, a.qp0, sT, LDQ, nullptr, 0, wave, lane);
-  __syncthreads();
-  row_gemm<ACT_NONE>(sT, LDQ, a.qp1, sP, LDH, nullptr, 0, wave, lane);
-  __syncthreads();
+  if (a.mode != 3) {
+    row_gemm<ACT_RELU>(sR, LDR, a.qp0, sT, LDQ, nullptr, 0, wave, lane);
+    __syncthreads();
+    row_gemm<ACT_NONE>(sT, LDQ, a.qp1, sP, LDH, nullptr, 0, wave, lane);
+    __syncthreads();
+  }
   DEC_STAMP(9);   // hs store + qpos MLP
   for (int e = tid; e < DR * D; e += NT) {
     const int r = e / D, c = e - r * D;
     sA[r * LDH + c] = sH[r * LDH + c] + sP[r * LDH + c];
-    if (r < nvalid) a.qpos_out[(row0 + r) * D + c] = sP[r * LDH + c];
+    if (a.mode != 3 && r < nvalid) a.qpos_out[(row0 + r) * D + c] = sP[r * LDH + c];
   }
   __syncthreads();
   row_gemm<ACT_NONE>(sA, LDH, a.qk, sT, LDQ, nullptr, 0, wave, lane);
   row_gemm<ACT_NONE>(sH, LDH, a.v, sO, LDO, nullptr, 0, wave, lane);
   __syncthreads();
   DEC_STAMP(10);  // qk + v
-  for (int e = tid; e < DR * 2 * D; e += NT) {
-    const int r = e / (2 * D), c = e - r * 2 * D;
-    if (r < nvalid) a.qk_out[(row0 + r) * 2 * D + c] = sT[r * LDQ + c];
-  }
+  // q rows, and K / V of these 16 rows (= key tile `tile`) in the fragment order self_attention_rows() reads
   for (int e = tid; e < DR * D; e += NT) {
     const int r = e / D, c = e - r * D;
-    if (r < nvalid) a.v_out[(row0 + r) * D + c] = sO[r * LDO + c];
+    if (r < nvalid) a.q_out[(row0 + r) * D + c] = sT[r * LDQ + c];
+  }
+  {
+    const int tile = q0 / DR;
+    for (int e = tid; e < a.heads * 512; e += NT) {
+      const int h = e >> 9, rem = e & 511, c = rem >> 8, ln = (rem & 255) >> 2, u = rem & 3;
+      const size_t dst = ((size_t)(b * a.heads + h) * tiles + tile) * 512 + rem;
+      const int kr = ln & 15;                                   // K: key = lane & 15, dim = 32h + 16c + 4 (lane>>4) + u
+      a.kfrag_out[dst] = kr < nvalid ? sT[kr * LDQ + D + h * 32 + 16 * c + 4 * (ln >> 4) + u] : 0.f;
+      const int vr = 4 * (ln >> 4) + u;                         // V: key = 4 (lane>>4) + u, dim = 32h + 16c + (lane & 15)
+      a.vfrag_out[dst] = vr < nvalid ? sO[vr * LDO + h * 32 + 16 * c + (ln & 15)] : 0.f;
+    }
   }
   DEC_STAMP(11);  // stores
 }
 
 void launch_dec_layer(const DecArgs& a, hipStream_t s) {
   RTD_CHECK(a.D == 256 && a.D / a.heads == 32 && a.ffn <= 1024 && a.C <= 512, 1, "fused decoder: d_model 256, head dim 32, ffn <= 1024");
-  RTD_CHECK(a.n_levels == 3 && a.n_points == 4 && a.heads * 36 <= 288, 1, "fused decoder: 3 levels x 4 points");
+  RTD_CHECK(a.n_levels == 3 && a.n_points == 4 && a.heads == NW, 1, "fused decoder: 3 levels x 4 points, 8 heads");
   const int tiles = (a.Q + DR - 1) / DR;
   hipLaunchKernelGGL(dec_layer_kernel, dim3(a.B * tiles), dim3(NT), 0, s, a);
   HIP_CHECK(hipGetLastError());

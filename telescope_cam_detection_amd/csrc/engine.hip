@@ -476,6 +476,43 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   // AIFI in fp32 (0.5 % of the FLOPs; keeps the only global-mixing layer of the encoder exact)
   Tensor pos;
   pos.p = e->pos_dev; pos.dt = F32; pos.n = 1; pos.h = L; pos.w = 1; pos.c = d; pos.ld = d; pos.bstride = (int64_t)L * d;
+  Tensor t2;
+  const bool aifi_fused = g_dec_fused && d == 256 && c.enc_heads == 8 && c.enc_ffn <= 1024;
+  if (aifi_fused) {
+    // ---- fused AIFI: 2 launches of decoder.hip's row kernel (modes 3, 4) instead of 9 ----------------------------
+    t2 = B.act(P, n, L, 1, d, "aifi_out");
+    Tensor qrows = B.act(F32, n, L, 1, d);
+    const int tl = (L + 15) / 16;
+    float* kf = (float*)B.alloc((size_t)n * 8 * tl * 512 * 4);
+    float* vf = (float*)B.alloc((size_t)n * 8 * tl * 512 * 4);
+    auto elin = [&](const std::string& name, int N, int K) {
+      DecLin Lw{};
+      if (!B.dry) {
+        DevWeight w = get_weight_packed(e, name, N, K, K);
+        Lw.w = (const float*)w.w; Lw.b = w.bias; Lw.ldw = w.Kpad; Lw.N = N; Lw.K = w.K;
+      }
+      return Lw;
+    };
+    DecArgs a0{};
+    a0.B = n; a0.Q = L; a0.D = d; a0.heads = 8; a0.S = 0; a0.n_levels = 3; a0.n_points = 4; a0.ffn = c.enc_ffn; a0.C = 4;
+    a0.hs_in = (const float*)t0.p; a0.qpos_in = e->pos_dev;
+    a0.q_in = (const float*)qrows.p; a0.q_out = (float*)qrows.p;
+    a0.kfrag_in = kf; a0.vfrag_in = vf; a0.kfrag_out = kf; a0.vfrag_out = vf;
+    DecArgs a3 = a0;
+    a3.mode = 3;
+    a3.qk = elin("enc.aifi.qk", 2 * d, d); a3.v = elin("enc.aifi.v", d, d);
+    B.push("enc.aifi.qkv", "dec_layer", 2.0 * n * L * 3.0 * d * d, (double)n * L * d * 4 * 5, [a3](hipStream_t s) { launch_dec_layer(a3, s); });
+    DecArgs a4 = a0;
+    a4.mode = 4;
+    a4.o = elin("enc.aifi.o", d, d); a4.fc1 = elin("enc.aifi.fc1", c.enc_ffn, d); a4.fc2 = elin("enc.aifi.fc2", d, c.enc_ffn);
+    if (!B.dry) {
+      a4.ln1.g = get_vec(e, "enc.aifi.ln1.g", d); a4.ln1.b = get_vec(e, "enc.aifi.ln1.b", d);
+      a4.ln3.g = get_vec(e, "enc.aifi.ln2.g", d); a4.ln3.b = get_vec(e, "enc.aifi.ln2.b", d);
+    }
+    if (P == BF16) a4.out_bf16 = t2.p; else a4.hs_out = (float*)t2.p;
+    B.push("enc.aifi.layer", "dec_layer", 4.0 * n * (double)L * L * d + 2.0 * n * L * ((double)d * d + 2.0 * d * c.enc_ffn),
+           (double)n * L * d * 4 * 4, [a4](hipStream_t s) { launch_dec_layer(a4, s); });
+  } else {
   Tensor xp = B.act(F32, n, L, 1, d);
   B.push("enc.aifi.addpos", "add", (double)xp.pixels() * d, 3 * Builder::tbytes(xp), [t0, pos, xp](hipStream_t s) { launch_add(t0, pos, xp, s); });
   Tensor qk = B.linear("enc.aifi.qk", xp, 2 * d, F32, ACT_NONE);
@@ -490,7 +527,8 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   Tensor t1 = B.layernorm("enc.aifi.ln1", ao, F32);
   Tensor f1 = B.linear("enc.aifi.fc1", t1, c.enc_ffn, F32, ACT_GELU);
   Tensor f2 = B.linear("enc.aifi.fc2", f1, d, F32, ACT_NONE, &t1);
-  Tensor t2 = B.layernorm("enc.aifi.ln2", f2, P, "aifi_out");
+  t2 = B.layernorm("enc.aifi.ln2", f2, P, "aifi_out");
+  }
   t2.h = lh[2]; t2.w = lw[2];
 
   auto csp = [&](const std::string& pfx, const Tensor& cat, const std::string& oname) {
@@ -580,13 +618,17 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   }
   Tensor hs = target;
   Tensor logits;
-  const bool fused = g_dec_fused && dm == 256 && dm / c.dec_heads == 32 && c.dec_ffn <= 1024 && C <= 512 && c.n_levels == 3 && c.n_points == 4;
+  const bool fused = g_dec_fused && dm == 256 && c.dec_heads == 8 && c.dec_ffn <= 1024 && C <= 512 && c.n_levels == 3 && c.n_points == 4;
   if (fused) {
     // ---- fused decoder: 1 prologue + per layer (self-attention kernel + one fused kernel), decoder.hip -----
     Tensor qpos = B.act(F32, n, Q, 1, dm);
-    Tensor sqk = B.act(F32, n, Q, 1, 2 * dm);
-    Tensor sv = B.act(F32, n, Q, 1, dm);
-    Tensor att = B.act(F32, n, Q, 1, dm);
+    Tensor qrows = B.act(F32, n, Q, 1, dm);
+    const int dtiles = (Q + 15) / 16;
+    float* kfrag[2]; float* vfrag[2];
+    for (int i = 0; i < 2; ++i) {
+      kfrag[i] = (float*)B.alloc((size_t)n * c.dec_heads * dtiles * 512 * 4);
+      vfrag[i] = (float*)B.alloc((size_t)n * c.dec_heads * dtiles * 512 * 4);
+    }
     logits = B.act(F32, n, Q, 1, C, "logits");
     auto lin = [&](const std::string& name, int N, int K, int Kuse = 0) {
       DecLin L{};
@@ -606,8 +648,9 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     base.n_points = c.n_points; base.ffn = c.dec_ffn; base.C = C; base.offset_scale = c.offset_scale;
     base.ref8 = ref8; base.ref_unact8 = ref_unact8; base.anchors = e->anchors_dev; base.tk_idx = tk;
     base.value = vall.p; base.value_ld = (int)vall.ld; base.value_f32 = vall.dt == F32; base.lvl = e->lvl_dev;
-    base.qpos_in = (const float*)qpos.p; base.qpos_out = (float*)qpos.p; base.qk_out = (float*)sqk.p; base.v_out = (float*)sv.p;
-    base.att = (const float*)att.p; base.logits = (float*)logits.p;
+    base.qpos_in = (const float*)qpos.p; base.qpos_out = (float*)qpos.p;
+    base.q_in = (const float*)qrows.p; base.q_out = (float*)qrows.p;
+    base.logits = (float*)logits.p;
     base.qp0 = lin("dec.qpos.0", 2 * dm, 8, 64);   // K padded to one 64-wide step (zero weights / zero LDS columns)
     base.qp1 = lin("dec.qpos.1", dm, 2 * dm);
     const double row_flops_next = 2.0 * n * Q * ((double)8 * 2 * dm + 2.0 * dm * dm + 2.0 * dm * dm + (double)dm * dm);
@@ -617,20 +660,20 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       a.hs_in = (const float*)target.p; a.hs_out = nullptr;
       a.bb0 = lin("dec.enc_bbox.0", dm, dm); a.bb1 = lin("dec.enc_bbox.1", dm, dm); a.bb2 = lin("dec.enc_bbox.2", 4, dm);
       a.qk = lin("dec.l0.sa.qk", 2 * dm, dm); a.v = lin("dec.l0.sa.v", dm, dm);
+      a.kfrag_out = kfrag[0]; a.vfrag_out = vfrag[0];
       B.push("dec.prologue", "dec_layer", 2.0 * n * Q * (2.0 * dm * dm + 4.0 * dm) + row_flops_next, (double)n * Q * dm * 4 * 6,
              [a](hipStream_t s) { launch_dec_layer(a, s); });
     }
     for (int i = 0; i < NL; ++i) {
       const std::string p = nm("dec.l%d", i);
-      const int heads = c.dec_heads;
-      B.push(p + ".sa.attn", "attention", 4.0 * n * (double)Q * Q * dm, Builder::tbytes(sqk) + 2 * Builder::tbytes(sv),
-             [sqk, sv, att, heads](hipStream_t s) { launch_attention(sqk, sv, att, heads, s); });
       Tensor hs_out = B.act(F32, n, Q, 1, dm, nm("dec%d.hs", i));
       DecArgs a = base;
       const bool last = i == NL - 1;
       a.mode = last ? 2 : 1;
       a.hs_in = (const float*)hs.p; a.hs_out = (float*)hs_out.p;
       a.value_coff = i * dm;
+      a.kfrag_in = kfrag[i & 1]; a.vfrag_in = vfrag[i & 1];
+      a.kfrag_out = kfrag[(i + 1) & 1]; a.vfrag_out = vfrag[(i + 1) & 1];
       a.o = lin(p + ".sa.o", dm, dm); a.ln1 = lnp(p + ".ln1");
       a.offaw = lin(p + ".ca.offaw", 3 * npts, dm); a.op = lin(p + ".ca.op", dm, dm); a.ln2 = lnp(p + ".ln2");
       a.fc1 = lin(p + ".fc1", c.dec_ffn, dm); a.fc2 = lin(p + ".fc2", dm, c.dec_ffn); a.ln3 = lnp(p + ".ln3");
@@ -642,7 +685,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
         Tensor st = B.act(F32, 1, blocks, 1, 16, "dec_stamps");
         a.stamps = (float*)st.p;
       }
-      const double fl = 2.0 * n * Q * ((double)dm * dm * 2 + 3.0 * npts * dm + 2.0 * dm * c.dec_ffn + 2.0 * dm * dm + 4.0 * dm) +
+      const double fl = 4.0 * n * (double)Q * Q * dm + 2.0 * n * Q * ((double)dm * dm * 2 + 3.0 * npts * dm + 2.0 * dm * c.dec_ffn + 2.0 * dm * dm + 4.0 * dm) +
                         2.0 * n * Q * dm * c.n_levels * c.n_points * 4 + (last ? 2.0 * n * Q * dm * C : row_flops_next);
       B.push(p + ".fused", "dec_layer", fl, (double)n * Q * dm * 4 * 8, [a](hipStream_t s) { launch_dec_layer(a, s); });
       hs = hs_out;

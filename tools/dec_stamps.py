@@ -13,10 +13,11 @@ eng = _capi.Engine(arch, pack_blob(fold_weights(arch, synth_weights(arch, 0))), 
 frames = [noise_frame(i, 640, 640) for i in range(B)]
 for _ in range(3):
     eng.infer_raw(frames)
-st = eng.debug_tensor("dec_stamps")[0, :, 0, :12] * 0.01   # us
-names = ["load", "o_proj", "ln1", "add+offaw", "sampling", "op+ln2", "fc1", "fc2+ln3", "bbox+refine", "hs st+qpos", "qk+v", "stores"]
+raw = eng.debug_tensor("dec_stamps")[0, :, 0, :] * 0.01   # us
+st = np.concatenate([raw[:, 0:1], raw[:, 12:13], raw[:, 1:12]], 1)
+names = ["load", "self-attn", "o_proj", "ln1", "add+offaw", "sampling", "op+ln2", "fc1", "fc2+ln3", "bbox+refine", "hs st+qpos", "qk+v", "stores"]
 d = np.diff(np.concatenate([np.zeros((st.shape[0], 1)), st], 1), axis=1)
-print("blocks", st.shape[0], " total us: median %.1f  max %.1f" % (np.median(st[:, 11]), st[:, 11].max()))
+print("blocks", st.shape[0], " total us: median %.1f  max %.1f" % (np.median(st[:, 12]), st[:, 12].max()))
 for i, nme in enumerate(names):
     print(f"  {nme:12s} median {np.median(d[:, i]):7.2f} us   p90 {np.percentile(d[:, i], 90):7.2f}")
 eng.close()
