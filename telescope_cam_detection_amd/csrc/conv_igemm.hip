@@ -883,7 +883,8 @@ template <typename T>
 static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long w_bytes, hipStream_t s) {
   if (!ok || g_conv_mode == 1 || g_conv_mode == 2) return false;     // 5 = single-role LDS-DMA kernels (v3) for A/B
   const long long mt = (k.M + 127) / 128, ntn = (k.N + 127) / 128;
-  if (k.N < 128 || mt * ntn < (sizeof(T) == 2 ? g_glds_min_blocks : 512) || x_bytes >= (1ll << 31) || w_bytes >= (1ll << 31)) return false;
+  // fp32 GEMMs (query-selection heads) may use a partly empty N tile: N >= 64 still beats the small-tile kernel
+  if (k.N < (sizeof(T) == 2 ? 128 : 64) || mt * ntn < (sizeof(T) == 2 ? g_glds_min_blocks : 512) || x_bytes >= (1ll << 31) || w_bytes >= (1ll << 31)) return false;
   ConvG g;
   g.k = k;
   g.k.ntn = (int)ntn;

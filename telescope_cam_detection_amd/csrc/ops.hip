@@ -408,15 +408,30 @@ __device__ __forceinline__ float key2f(unsigned k) {
   return __uint_as_float(u);
 }
 
+// REG = true: every thread keeps its <= 32 keys in registers (N <= 32768), so the four radix passes and the
+// compaction touch global memory once; REG = false re-reads the keys from global (any N).
+template <bool REG>
 __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ keys, int N, int K, int32_t* __restrict__ idx_out,
                                                 float* __restrict__ val_out) {
+  constexpr int MAXPT = 32;
   __shared__ unsigned hist[256];
   __shared__ unsigned long long sel[1024];
   __shared__ unsigned s_prefix, s_krem, s_cnt_gt, s_cnt_eq;
   __shared__ unsigned wave_cnt[16];
   const int tid = threadIdx.x;
   const float* kb = keys + (int64_t)blockIdx.x * N;
+  unsigned kreg[MAXPT];
+  const int npt = REG ? (N + 1023) / 1024 : 0;
+  if (REG) {
+#pragma unroll
+    for (int j = 0; j < MAXPT; ++j) {
+      const int i = tid + j * 1024;
+      kreg[j] = (j < npt && i < N) ? f2key(kb[i]) : 0u;         // slots beyond N are never counted (guarded by i < N)
+    }
+  }
+  auto key_at = [&](int j, int i) -> unsigned { return REG ? kreg[j] : f2key(kb[i]); };
   if (tid == 0) { s_prefix = 0; s_krem = (unsigned)K; s_cnt_gt = 0; s_cnt_eq = 0; }
+  sel[tid] = 0ull;
   __syncthreads();
   // ---- radix select: after the loop s_prefix is the key of the K-th largest element ------------
   for (int pass = 0; pass < 4; ++pass) {
@@ -425,41 +440,81 @@ __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ keys, i
     __syncthreads();
     const unsigned prefix = s_prefix;
     const unsigned mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-    for (int i = tid; i < N; i += 1024) {
-      const unsigned k = f2key(kb[i]);
-      if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+    if (REG) {
+#pragma unroll
+      for (int j = 0; j < MAXPT; ++j) {
+        const int i = tid + j * 1024;
+        if (j < npt && i < N && (kreg[j] & mask) == prefix) atomicAdd(&hist[(kreg[j] >> shift) & 255u], 1u);
+      }
+    } else {
+      for (int i = tid; i < N; i += 1024) {
+        const unsigned k = f2key(kb[i]);
+        if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+      }
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned rem = s_krem, d = 255;
-      for (;; --d) {
-        const unsigned c = hist[d];
-        if (c >= rem || d == 0) break;
-        rem -= c;
+    if (tid < 64) {
+      // wave 0 scans the 256 buckets from the top: lane l owns buckets 255-4l .. 252-4l
+      const int l = tid;
+      const unsigned c0 = hist[255 - 4 * l], c1 = hist[254 - 4 * l], c2 = hist[253 - 4 * l], c3 = hist[252 - 4 * l];
+      const unsigned tot = c0 + c1 + c2 + c3;
+      unsigned incl = tot;                                       // inclusive prefix over lanes (descending buckets)
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o, 64);
+        if (l >= o) incl += t;
       }
-      s_krem = rem;                     // rank of the target inside bucket d (1-based)
-      s_prefix = prefix | (d << shift);
+      const unsigned excl = incl - tot;
+      const unsigned rem = s_krem;
+      if (excl < rem && rem <= incl) {                           // exactly one lane holds the target bucket
+        unsigned r = rem - excl, d;
+        if (r <= c0) d = 255 - 4 * l;
+        else if ((r -= c0) <= c1) d = 254 - 4 * l;
+        else if ((r -= c1) <= c2) d = 253 - 4 * l;
+        else { r -= c2; d = 252 - 4 * l; }
+        s_krem = r;
+        s_prefix = prefix | (d << shift);
+      }
     }
     __syncthreads();
   }
   const unsigned T = s_prefix;
   const unsigned need_eq = s_krem;      // how many elements equal to T are taken (lowest indices)
-  for (int i = tid; i < 1024; i += 1024) sel[i] = 0ull;
-  __syncthreads();
   // ---- compaction: strictly greater (any order), then equal in index order ---------------------
-  for (int i = tid; i < N; i += 1024) {
-    const unsigned k = f2key(kb[i]);
-    if (k > T) {
-      const unsigned pos = atomicAdd(&s_cnt_gt, 1u);
-      if (pos < 1024) sel[pos] = ((unsigned long long)k << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+  if (REG) {
+#pragma unroll
+    for (int j = 0; j < MAXPT; ++j) {
+      const int i = tid + j * 1024;
+      if (j < npt && i < N && kreg[j] > T) {
+        const unsigned pos = atomicAdd(&s_cnt_gt, 1u);
+        if (pos < 1024) sel[pos] = ((unsigned long long)kreg[j] << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+      }
+    }
+  } else {
+    for (int i = tid; i < N; i += 1024) {
+      const unsigned k = f2key(kb[i]);
+      if (k > T) {
+        const unsigned pos = atomicAdd(&s_cnt_gt, 1u);
+        if (pos < 1024) sel[pos] = ((unsigned long long)k << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+      }
     }
   }
   __syncthreads();
   const unsigned n_gt = s_cnt_gt;       // == K - need_eq
   const int lane = tid & 63, wv = tid >> 6;
-  for (int base = 0; base < N; base += 1024) {
+  for (int base = 0, j = 0; base < N; base += 1024, ++j) {
     const int i = base + tid;
-    const bool eq = (i < N) && (f2key(kb[i]) == T);
+    bool eq = false;
+    if (i < N) {
+      if (REG) {
+        unsigned kv = 0;
+#pragma unroll
+        for (int jj = 0; jj < MAXPT; ++jj) kv = (jj == j) ? kreg[jj] : kv;   // static register indices
+        eq = kv == T;
+      } else {
+        eq = f2key(kb[i]) == T;
+      }
+    }
     const unsigned long long bal = __ballot(eq);
     if (lane == 0) wave_cnt[wv] = (unsigned)__popcll(bal);
     __syncthreads();
@@ -498,7 +553,8 @@ __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ keys, i
 }
 void launch_topk(const float* keys, int B, int N, int K, int32_t* idx, float* vals, hipStream_t s) {
   RTD_CHECK(K >= 1 && K <= 1024 && K <= N, 1, "topk: K must be in [1, min(1024, N)]");
-  hipLaunchKernelGGL(k_topk, dim3(B), dim3(1024), 0, s, keys, N, K, idx, vals);
+  if (N <= 32768) hipLaunchKernelGGL(k_topk<true>, dim3(B), dim3(1024), 0, s, keys, N, K, idx, vals);
+  else hipLaunchKernelGGL(k_topk<false>, dim3(B), dim3(1024), 0, s, keys, N, K, idx, vals);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -48,6 +48,7 @@ CONV_CASES = [
     (4, 208, 128, 256, 384, 3, 2, 1, "silu", 0),   # v2/v3 stride 2
     (1, 26000, 1, 256, 288, 1, 1, 0, "none", 0),   # v2 token GEMM, N = 288
     (2, 96, 96, 512, 64, 1, 1, 0, "gelu", 0),      # v2 BN=64, K = 512
+    (1, 67200, 1, 256, 80, 1, 1, 0, "none", 0),    # enc_score_head shape: fp32 takes the LDS-DMA kernel with a partial N tile
 ]
 
 
