@@ -130,6 +130,15 @@ int64_t rtd_arena_bytes(rtd_handle h);
 /* process-wide A/B switches for tests and profiling: "conv_v1" = 1 keeps every conv on the small-tile kernels */
 int rtd_debug_option(const char* name, int value);
 
+/* ---- Stage 2: crop + classifier pre-processing for a whole batch of detections ------------------
+ * For crop i: frame slice [y1:y2, x1:x2] (src/two_stage_pipeline_yolox.py:289) of a device-resident HWC uint8 BGR frame,
+ * then SpeciesClassifier.preprocess (src/species_classifier.py:298-352): BGR->RGB, F.interpolate(bilinear,
+ * align_corners=False) to out_size x out_size, /255, (x-mean)/std.  out_dev: [n][3][out_size][out_size] fp32 (what the
+ * classifier network consumes).  rects = [n][4] (x1, y1, x2, y2), frame_hw = [n][2].  Enqueued on `stream` (may be NULL);
+ * returns after the work completed (the reference's classify() is synchronous too). */
+int rtd_crop_resize_batch(int32_t n, const uint8_t* const* frames_dev, const int32_t* frame_hw, const int32_t* rects,
+                          int32_t out_size, const float* mean3, const float* std3, float* out_dev, void* stream);
+
 /* ---- kernel-level test entry points (device pointers; dtype 0 = bf16, 1 = fp32) --------------- */
 int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* bias, const void* res,
                 void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,

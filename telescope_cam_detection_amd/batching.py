@@ -1,0 +1,235 @@
+"""Cross-camera batching for RT-DETR.
+
+The reference batches only YOLOX: `_initialize_shared_coordinator` returns None for every other detector
+type (/root/reference/main.py:793-797), although its `SharedInferenceCoordinator` only needs an object with
+`detect_batch(frames)` (src/shared_inference_coordinator.py:250).  The MI355X detector provides that contract
+(one HIP graph replay per batch), so this module
+
+* builds the coordinator's detector from the reference's own config keys (`detection.rtdetr.*`,
+  `detection.batching.*`, config/config.yaml:74,90-99,130-135,511-517), and
+* supplies `BatchCoordinator`, a host-side mirror of the reference coordinator's interface and behaviour
+  (`start/stop`, `infer_async(frame, callback, camera_id)`, drop-oldest at `max_queue_depth` with
+  `callback([])`, every callback gets `[]` when the batch raises, `get_stats()` keys), used when the
+  reference package is not importable, and
+* `install(system_cls)`: the three-line hook a maintainer adds so `main.py` stays untouched.
+
+The engines (src/inference_engine_yolox.py:341-350) call `coordinator.infer_async(frame, callback, camera_id)`
+and never look at the detector, so nothing else changes.
+"""
+from __future__ import annotations
+
+import logging
+import threading
+import time
+from collections import deque
+from typing import Any, Callable, Dict, List, Optional
+
+logger = logging.getLogger(__name__)
+
+
+class _Request:
+    __slots__ = ("frame", "callback", "enqueue_time", "camera_id")
+
+    def __init__(self, frame, callback, camera_id):
+        self.frame = frame
+        self.callback = callback
+        self.enqueue_time = time.time()
+        self.camera_id = camera_id
+
+
+class BatchCoordinator:
+    """Same constructor arguments, methods and stats keys as the reference's SharedInferenceCoordinator
+    (src/shared_inference_coordinator.py:27-338)."""
+
+    def __init__(self, detector: Any, max_batch_size: int = 4, max_batch_wait_ms: float = 10.0,
+                 enable_metrics: bool = True, max_queue_depth: int = 60):
+        self.detector = detector
+        self.max_batch_size = int(max_batch_size)
+        self.max_batch_wait_ms = max_batch_wait_ms / 1000.0          # seconds, like the reference attribute
+        self.enable_metrics = enable_metrics
+        self.max_queue_depth = int(max_queue_depth)
+        self.pending_queue: deque = deque()
+        self.queue_lock = threading.Lock()
+        self.queue_condition = threading.Condition(self.queue_lock)
+        self.coordinator_thread: Optional[threading.Thread] = None
+        self.stop_event = threading.Event()
+        self.running = False
+        self.total_batches = 0
+        self.total_frames = 0
+        self.total_batch_time_ms = 0.0
+        self.dropped_frames = 0
+        self.batch_sizes: deque = deque(maxlen=1000)
+        self.wait_times_ms: deque = deque(maxlen=1000)
+
+    # ---- lifecycle
+    def start(self):
+        if self.running:
+            logger.warning("Coordinator already running")
+            return
+        self.running = True
+        self.stop_event.clear()
+        self.coordinator_thread = threading.Thread(target=self._coordinator_loop, name="InferenceCoordinator", daemon=True)
+        self.coordinator_thread.start()
+
+    def stop(self):
+        if not self.running:
+            return
+        self.running = False
+        self.stop_event.set()
+        with self.queue_condition:
+            self.queue_condition.notify_all()
+        if self.coordinator_thread:
+            self.coordinator_thread.join(timeout=2.0)
+            if self.coordinator_thread.is_alive():
+                logger.warning("Coordinator thread did not stop cleanly")
+
+    def __enter__(self):
+        self.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop()
+
+    # ---- producer side (camera engine threads)
+    def infer_async(self, frame: Any, callback: Callable[[List[Dict[str, Any]]], None], camera_id: Optional[str] = None):
+        if not self.running:
+            raise RuntimeError("Coordinator not running - call start() first")
+        req = _Request(frame, callback, camera_id)
+        dropped = None
+        with self.queue_condition:
+            if len(self.pending_queue) >= self.max_queue_depth:      # overloaded: drop the OLDEST request
+                dropped = self.pending_queue.popleft()
+                self.dropped_frames += 1
+            self.pending_queue.append(req)
+            self.queue_condition.notify()
+        if dropped is not None:
+            if self.dropped_frames % 10 == 0:
+                logger.warning(f"Inference queue full - dropped {self.dropped_frames} frames total")
+            try:
+                dropped.callback([])                                   # its owner still gets an answer
+            except Exception:
+                pass
+
+    # ---- consumer side
+    def _collect_batch(self) -> List[_Request]:
+        batch: List[_Request] = []
+        with self.queue_condition:
+            while not self.pending_queue and not self.stop_event.is_set():
+                self.queue_condition.wait(timeout=0.1)
+            if self.stop_event.is_set():
+                return []
+            deadline = time.time() + self.max_batch_wait_ms
+            while len(batch) < self.max_batch_size:
+                if self.pending_queue:
+                    batch.append(self.pending_queue.popleft())
+                    continue
+                remaining = deadline - time.time()
+                if remaining <= 0 or self.stop_event.is_set():
+                    break
+                self.queue_condition.wait(timeout=remaining)           # a little patience for a fuller batch
+        return batch
+
+    def _process_batch(self, batch: List[_Request]):
+        if not batch:
+            return
+        t_start = time.time()
+        if self.enable_metrics:
+            for r in batch:
+                self.wait_times_ms.append((t_start - r.enqueue_time) * 1000)
+        try:
+            results = self.detector.detect_batch([r.frame for r in batch])
+            elapsed_ms = (time.time() - t_start) * 1000
+            for r, dets in zip(batch, results):
+                try:
+                    r.callback(dets)
+                except Exception as e:
+                    logger.error(f"Error in callback for camera {r.camera_id}: {e}")
+            if self.enable_metrics:
+                self.total_batches += 1
+                self.total_frames += len(batch)
+                self.total_batch_time_ms += elapsed_ms
+                self.batch_sizes.append(len(batch))
+        except Exception as e:
+            logger.error(f"Error processing batch: {e}", exc_info=True)
+            for r in batch:
+                try:
+                    r.callback([])
+                except Exception as cb_error:
+                    logger.error(f"Error calling callback on error: {cb_error}")
+
+    def _coordinator_loop(self):
+        while not self.stop_event.is_set():
+            try:
+                self._process_batch(self._collect_batch())
+            except Exception as e:                                     # never let the thread die
+                logger.error(f"Error in coordinator loop: {e}", exc_info=True)
+
+    def get_stats(self) -> Dict[str, Any]:
+        if not self.enable_metrics or self.total_batches == 0:
+            return {"enabled": False, "total_batches": 0, "total_frames": 0}
+        return {
+            "enabled": True,
+            "total_batches": self.total_batches,
+            "total_frames": self.total_frames,
+            "avg_batch_size": round(sum(self.batch_sizes) / len(self.batch_sizes), 2),
+            "avg_batch_time_ms": round(self.total_batch_time_ms / self.total_batches, 2),
+            "avg_wait_time_ms": round(sum(self.wait_times_ms) / len(self.wait_times_ms), 2) if self.wait_times_ms else 0,
+            "throughput_fps": round(self.total_frames / (self.total_batch_time_ms / 1000), 1) if self.total_batch_time_ms > 0 else 0,
+            "queue_depth": len(self.pending_queue),
+        }
+
+
+def make_rtdetr_coordinator(config: Dict[str, Any], coordinator_cls=None, detector_cls=None):
+    """What `_initialize_shared_coordinator` (main.py:770-838) would do for `detector_type: rtdetr`.
+
+    Returns a started-able coordinator, or None when batching is disabled / the detector is not RT-DETR /
+    the model fails to load (same "return None" behaviour as the reference)."""
+    detection = config.get("detection", {})
+    batching = detection.get("batching", {})
+    if not batching.get("enabled", False):
+        return None
+    if detection.get("detector_type", "yolox").lower() != "rtdetr":
+        return None
+    if detector_cls is None:
+        from .rtdetr_detector import RTDETRDetector as detector_cls
+    if coordinator_cls is None:
+        try:
+            from src.shared_inference_coordinator import SharedInferenceCoordinator as coordinator_cls  # the reference's own class
+        except Exception:
+            coordinator_cls = BatchCoordinator
+    rt = detection.get("rtdetr", {})
+    max_batch = int(batching.get("max_batch_size", 4))
+    try:
+        detector = detector_cls(
+            config_path=rt.get("config_path", "RT-DETR/rtdetrv2_pytorch/configs/rtdetrv2/rtdetrv2_r18vd_120e_coco.yml"),
+            model_path=rt.get("weights", "models/rtdetr/rtdetrv2_r18vd.pth"),
+            device=detection.get("device", "cuda:0"),
+            conf_threshold=detection.get("conf_threshold", 0.25),
+            input_size=tuple(detection.get("input_size", [640, 640])),
+            wildlife_only=detection.get("wildlife_only", True),
+            max_batch=max_batch,
+        )
+        if not detector.load_model():
+            logger.error("Failed to load RT-DETR detector for coordinator")
+            return None
+        return coordinator_cls(detector=detector, max_batch_size=max_batch,
+                               max_batch_wait_ms=batching.get("max_batch_wait_ms", 10.0),
+                               enable_metrics=batching.get("enable_metrics", True))
+    except Exception as e:
+        logger.error(f"Failed to initialize shared coordinator: {e}")
+        return None
+
+
+def install(system_cls) -> None:
+    """Let `TelescopeDetectionSystem` batch RT-DETR too, without editing main.py:
+
+        import main, telescope_cam_detection_amd.batching as b
+        b.install(main.TelescopeDetectionSystem)
+    """
+    original = system_cls._initialize_shared_coordinator
+
+    def patched(self):
+        coord = make_rtdetr_coordinator(self.config)
+        return coord if coord is not None else original(self)
+
+    system_cls._initialize_shared_coordinator = patched

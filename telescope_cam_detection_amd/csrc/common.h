@@ -159,6 +159,14 @@ struct DecArgs {
 
 void launch_dec_layer(const DecArgs& a, hipStream_t s);
 
+// ---- Stage-2 crop batcher (ops.hip): up to 64 crops per launch, parameters by value ----
+struct CropBatch {
+  const uint8_t* frame[64];   // HWC uint8 BGR frames on the device
+  int fh[64], fw[64];
+  int x1[64], y1[64], x2[64], y2[64];   // crop rectangle [y1:y2, x1:x2] inside the frame
+};
+void launch_crop_resize(const CropBatch& cb, int n, int out_size, const float mean[3], const float stdv[3], float* out, hipStream_t s);
+
 void launch_f32_to(const float* src, void* dst, int dt, int64_t n, hipStream_t s);
 void launch_to_f32(const void* src, int dt, float* dst, int64_t n, hipStream_t s);
 

@@ -1274,6 +1274,25 @@ int rtd_op_msdeform(int dtype, const void* value, const float* offaw, const floa
   });
 }
 
+int rtd_crop_resize_batch(int32_t n, const uint8_t* const* frames_dev, const int32_t* frame_hw, const int32_t* rects, int32_t out_size,
+                          const float* mean3, const float* std3, float* out_dev, void* stream) {
+  return op_guard([&] {
+    RTD_CHECK(n >= 0 && frames_dev && frame_hw && rects && mean3 && std3 && out_dev, RTD_E_INVALID, "null argument");
+    for (int base = 0; base < n; base += 64) {
+      const int m = std::min(64, n - base);
+      CropBatch cb;
+      memset(&cb, 0, sizeof cb);
+      for (int i = 0; i < m; ++i) {
+        cb.frame[i] = frames_dev[base + i];
+        cb.fh[i] = frame_hw[2 * (base + i)]; cb.fw[i] = frame_hw[2 * (base + i) + 1];
+        cb.x1[i] = rects[4 * (base + i)]; cb.y1[i] = rects[4 * (base + i) + 1];
+        cb.x2[i] = rects[4 * (base + i) + 2]; cb.y2[i] = rects[4 * (base + i) + 3];
+      }
+      launch_crop_resize(cb, m, out_size, mean3, std3, out_dev + (size_t)base * 3 * out_size * out_size, (hipStream_t)stream);
+    }
+  });
+}
+
 int rtd_op_topk(const float* keys, int B, int N, int K, int32_t* idx_out, float* val_out) {
   return op_guard([&] { launch_topk(keys, B, N, K, idx_out, val_out, nullptr); });
 }

@@ -831,4 +831,50 @@ void launch_resize_pil(const uint8_t* src, int sh, int sw, uint8_t* tmp, const T
   HIP_CHECK(hipGetLastError());
 }
 
+
+// ------------------------------------------------------------------------------------------ Stage-2 crop batcher
+// SpeciesClassifier.preprocess (/root/reference/src/species_classifier.py:298-352) for a whole batch of crops in one
+// launch: slice frame[y1:y2, x1:x2] (src/two_stage_pipeline_yolox.py:289), BGR->RGB, bilinear resize to S x S with
+// F.interpolate(align_corners=False) semantics (no antialias), /255, (x - mean) / std, NCHW fp32.
+struct CropNorm { float mean[3], inv_std[3]; };
+__global__ void k_crop_resize(const CropBatch cb, int n, int S, CropNorm nm, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)S * S;
+  if (i >= per * n) return;
+  const int c = (int)(i / per);
+  const int p = (int)(i - (int64_t)c * per);
+  const int oy = p / S, ox = p - oy * S;
+  const int cw = cb.x2[c] - cb.x1[c], chh = cb.y2[c] - cb.y1[c];
+  // area_pixel_compute_source_index(scale, dst, align_corners=False, cubic=False): max(scale * (dst + 0.5) - 0.5, 0)
+  const float sx = (float)cw / (float)S, sy = (float)chh / (float)S;
+  const float fx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.f), fy = fmaxf(sy * ((float)oy + 0.5f) - 0.5f, 0.f);
+  const int x0 = min((int)fx, cw - 1), y0 = min((int)fy, chh - 1);
+  const int x1 = min(x0 + 1, cw - 1), y1 = min(y0 + 1, chh - 1);
+  const float lx1 = fx - (float)x0, ly1 = fy - (float)y0, lx0 = 1.f - lx1, ly0 = 1.f - ly1;
+  const uint8_t* f = cb.frame[c];
+  const int64_t fw = cb.fw[c];
+  const uint8_t* p00 = f + ((int64_t)(cb.y1[c] + y0) * fw + cb.x1[c] + x0) * 3;
+  const uint8_t* p01 = f + ((int64_t)(cb.y1[c] + y0) * fw + cb.x1[c] + x1) * 3;
+  const uint8_t* p10 = f + ((int64_t)(cb.y1[c] + y1) * fw + cb.x1[c] + x0) * 3;
+  const uint8_t* p11 = f + ((int64_t)(cb.y1[c] + y1) * fw + cb.x1[c] + x1) * 3;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const int sc = 2 - ch;                                       // RGB channel ch = BGR channel 2 - ch
+    const float v = ly0 * (lx0 * (float)p00[sc] + lx1 * (float)p01[sc]) + ly1 * (lx0 * (float)p10[sc] + lx1 * (float)p11[sc]);
+    out[((int64_t)c * 3 + ch) * per + p] = (v / 255.0f - nm.mean[ch]) * nm.inv_std[ch];
+  }
+}
+void launch_crop_resize(const CropBatch& cb, int n, int out_size, const float mean[3], const float stdv[3], float* out, hipStream_t s) {
+  RTD_CHECK(n >= 1 && n <= 64 && out_size >= 1 && out_size <= 4096, 1, "crop batch: 1..64 crops per launch");
+  for (int i = 0; i < n; ++i) {
+    RTD_CHECK(cb.frame[i] && cb.x1[i] >= 0 && cb.y1[i] >= 0 && cb.x2[i] > cb.x1[i] && cb.y2[i] > cb.y1[i] && cb.x2[i] <= cb.fw[i] &&
+                  cb.y2[i] <= cb.fh[i], 1, "crop batch: rectangle outside its frame");
+  }
+  CropNorm nm;
+  for (int k = 0; k < 3; ++k) { nm.mean[k] = mean[k]; nm.inv_std[k] = 1.0f / stdv[k]; }
+  const int64_t total = (int64_t)n * out_size * out_size;
+  hipLaunchKernelGGL(k_crop_resize, dim3(blocks_for(total, 256)), dim3(256), 0, s, cb, n, out_size, nm, out);
+  HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace rtd

@@ -1,0 +1,167 @@
+"""Batching coordinator for RT-DETR: CPU tests with a fake detector mirror the behaviours
+of the reference's src/shared_inference_coordinator.py; the GPU test drives the real detector from 4 camera threads."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from telescope_cam_detection_amd.batching import BatchCoordinator, install, make_rtdetr_coordinator
+
+
+class FakeDetector:
+    def __init__(self, delay=0.0, fail_on=None):
+        self.batches = []
+        self.delay = delay
+        self.fail_on = fail_on
+
+    def detect_batch(self, frames):
+        self.batches.append(len(frames))
+        if self.delay:
+            time.sleep(self.delay)
+        if self.fail_on is not None and any(int(f[0, 0, 0]) == self.fail_on for f in frames):
+            raise RuntimeError("boom")
+        return [[{"class_id": int(f[0, 0, 0]), "class_name": "x", "confidence": 1.0, "bbox": {}}] for f in frames]
+
+
+def frame(tag):
+    return np.full((4, 4, 3), tag, np.uint8)
+
+
+def test_requests_are_batched_and_routed_to_their_callbacks():
+    det = FakeDetector(delay=0.02)
+    got = {}
+    done = threading.Event()
+    with BatchCoordinator(det, max_batch_size=4, max_batch_wait_ms=30.0) as c:
+        def cb(tag):
+            def f(d):
+                got[tag] = d
+                if len(got) == 10:
+                    done.set()
+            return f
+        for i in range(10):
+            c.infer_async(frame(i), cb(i), camera_id=f"cam{i % 4}")
+        assert done.wait(5.0)
+        stats = c.get_stats()
+    assert all(got[i][0]["class_id"] == i for i in range(10))           # every frame answered by ITS result
+    assert max(det.batches) <= 4 and sum(det.batches) == 10 and len(det.batches) < 10   # real batching happened
+    assert stats["enabled"] and stats["total_frames"] == 10 and stats["total_batches"] == len(det.batches)
+    assert set(stats) == {"enabled", "total_batches", "total_frames", "avg_batch_size", "avg_batch_time_ms",
+                          "avg_wait_time_ms", "throughput_fps", "queue_depth"}
+
+
+def test_partial_batch_flushes_after_max_wait():
+    det = FakeDetector()
+    ev = threading.Event()
+    with BatchCoordinator(det, max_batch_size=8, max_batch_wait_ms=20.0) as c:
+        t0 = time.time()
+        c.infer_async(frame(7), lambda d: ev.set())
+        assert ev.wait(2.0)
+        assert time.time() - t0 < 1.0
+    assert det.batches == [1]
+
+
+def test_queue_overflow_drops_oldest_with_empty_result():
+    det = FakeDetector(delay=0.2)
+    res = {}
+    c = BatchCoordinator(det, max_batch_size=1, max_batch_wait_ms=1.0, max_queue_depth=2)
+    c.start()
+    c.infer_async(frame(0), lambda d: res.__setitem__(0, d))            # taken by the worker immediately
+    time.sleep(0.05)
+    for i in (1, 2, 3):                                                  # queue depth 2: request 1 must be dropped
+        c.infer_async(frame(i), lambda d, i=i: res.__setitem__(i, d))
+    deadline = time.time() + 5
+    while len(res) < 4 and time.time() < deadline:
+        time.sleep(0.01)
+    c.stop()
+    assert res[1] == [] and c.dropped_frames == 1
+    assert res[2][0]["class_id"] == 2 and res[3][0]["class_id"] == 3
+
+
+def test_detector_exception_gives_every_callback_an_empty_list_and_keeps_running():
+    det = FakeDetector(fail_on=5)
+    res = {}
+    with BatchCoordinator(det, max_batch_size=2, max_batch_wait_ms=50.0) as c:
+        c.infer_async(frame(5), lambda d: res.__setitem__("a", d))
+        c.infer_async(frame(6), lambda d: res.__setitem__("b", d))
+        time.sleep(0.3)
+        c.infer_async(frame(9), lambda d: res.__setitem__("c", d))
+        time.sleep(0.3)
+    assert res["a"] == [] and res["b"] == [] and res["c"][0]["class_id"] == 9
+    with pytest.raises(RuntimeError):
+        c.infer_async(frame(1), lambda d: None)                          # stopped
+
+
+def test_make_coordinator_follows_reference_config_keys():
+    built = {}
+
+    class Det:
+        def __init__(self, **kw):
+            built.update(kw)
+
+        def load_model(self):
+            return True
+
+        def detect_batch(self, frames):
+            return [[] for _ in frames]
+
+    cfg = {"detection": {"detector_type": "rtdetr", "device": "cuda:0", "input_size": [640, 640], "conf_threshold": 0.3,
+                         "wildlife_only": False, "rtdetr": {"config_path": "x_r50vd.yml", "weights": "w.pth"},
+                         "batching": {"enabled": True, "max_batch_size": 6, "max_batch_wait_ms": 5.0}}}
+    c = make_rtdetr_coordinator(cfg, coordinator_cls=BatchCoordinator, detector_cls=Det)
+    assert isinstance(c, BatchCoordinator) and c.max_batch_size == 6 and abs(c.max_batch_wait_ms - 0.005) < 1e-9
+    assert built["config_path"] == "x_r50vd.yml" and built["model_path"] == "w.pth" and built["max_batch"] == 6
+    assert built["input_size"] == (640, 640) and built["conf_threshold"] == 0.3 and built["wildlife_only"] is False
+    cfg["detection"]["batching"]["enabled"] = False
+    assert make_rtdetr_coordinator(cfg, detector_cls=Det) is None
+    cfg["detection"]["batching"]["enabled"] = True
+    cfg["detection"]["detector_type"] = "yolox"
+    assert make_rtdetr_coordinator(cfg, detector_cls=Det) is None
+
+    class System:                                                       # stands in for main.TelescopeDetectionSystem
+        def __init__(self, config):
+            self.config = config
+
+        def _initialize_shared_coordinator(self):
+            return "reference-path"
+
+    install(System)
+    assert System(cfg)._initialize_shared_coordinator() == "reference-path"     # yolox: reference behaviour untouched
+
+
+@pytest.mark.gpu
+def test_four_camera_threads_through_the_real_detector():
+    from oracle import rtdetr_oracle as orc
+    from telescope_cam_detection_amd.rtdetr_detector import RTDETRDetector
+    from tests.util import load_case
+    arch, wseed, input_size, frames, g = load_case("t_tinyb_192x128")
+    det = RTDETRDetector(config_path="tinyb", model_path=f"synthetic:tinyb:{wseed}", device="cuda:0", conf_threshold=0.2,
+                         input_size=input_size, wildlife_only=False, precision="fp32", max_batch=4)
+    assert det.load_model()
+    want = [det.detect(f) for f in frames]
+    results = {}
+    lock = threading.Lock()
+
+    def camera(cam):
+        for it in range(6):
+            f = frames[(cam + it) % len(frames)]
+            ev = threading.Event()
+            def cb(d, key=(cam, it)):
+                with lock:
+                    results[key] = d
+                ev.set()
+            coord.infer_async(f, cb, camera_id=f"cam{cam}")
+            assert ev.wait(10.0)
+
+    with BatchCoordinator(det, max_batch_size=4, max_batch_wait_ms=5.0) as coord:
+        threads = [threading.Thread(target=camera, args=(c,)) for c in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        stats = coord.get_stats()
+    assert len(results) == 24 and stats["total_frames"] == 24
+    for (cam, it), d in results.items():
+        ref = want[(cam + it) % len(frames)]
+        assert [x["class_id"] for x in d] == [x["class_id"] for x in ref]
+        assert np.allclose([x["confidence"] for x in d], [x["confidence"] for x in ref], atol=1e-5)
