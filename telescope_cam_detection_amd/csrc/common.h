@@ -59,6 +59,15 @@ struct Error : std::runtime_error {
 // ------------------------------------------------------------------------------------------
 // kernel launch wrappers (implemented in conv_igemm.hip / ops.hip)
 // ------------------------------------------------------------------------------------------
+// per-engine scratch for the in-launch split-K reduction of conv_igemm_ws_kernel (shared by all layers: launches on one
+// stream are sequential, every launch leaves the tickets at zero)
+struct ConvWorkspace {
+  float* slab = nullptr;
+  size_t slab_bytes = 0;
+  unsigned* cnt = nullptr;
+  size_t cnt_entries = 0;
+};
+
 struct ConvArgs {
   Tensor x;            // input  [B,H,W,Cin] (view)
   const void* w;       // filter [Npad][Kpad] in x.dt, K = KH*KW*Cin (tap-major, channel-minor)
@@ -68,12 +77,14 @@ struct ConvArgs {
   int KH = 1, KW = 1, stride = 1, pad = 0;
   int Kpad = 0, Npad = 0;
   int act = ACT_NONE, res_mode = RES_NONE;
+  ConvWorkspace ws;    // optional: enables split-K on small grids
 };
 void launch_conv(const ConvArgs& a, hipStream_t s);
 int conv_kpad(int K);                 // padded filter row length the kernels expect
 int conv_npad(int N);
 void conv_set_force_v1(int v);      // A/B hook: 1 = never take the large-tile (v2) path
 void conv_set_glds_min_blocks(int v);
+void conv_set_splitk(int v);        // A/B hook: 0 = never split K
 void conv_set_glds_drop(int v);     // timing-only traffic probe (MI355X guide §7): drop one operand's DMA via a 0-record descriptor
 void conv_set_mode(int v);          // A/B hook: 0 auto, 1 = v1 only, 2 = v1 + v2 (no LDS-DMA kernel)
 

@@ -19,6 +19,8 @@
 // conflict-free), next tile's global loads issued before the current tile's MFMAs.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace rtd {
@@ -471,6 +473,11 @@ struct ConvG {
   ConvK k;
   unsigned x_bytes, w_bytes;   // extents of the two buffers from their base pointers (buffer descriptors)
   int probe;                   // timing-only probes (results wrong): bit 2 = issue no DMA at all
+  // split-K (ws kernel): grid = tiles x splitk; every slice publishes its fp32 accumulators to `slab`, the block that
+  // draws the last ticket of a tile sums them and runs the epilogue
+  int splitk;
+  float* slab;                 // [tiles][splitk][128 x 128] fp32, fragment order
+  unsigned* cnt;               // [tiles] arrival tickets, zero between launches
 };
 
 template <typename T, int STAGES>
@@ -704,9 +711,14 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int nt = wg % a.ntn, mt = wg / a.ntn;
+  // split-K: the slices of one tile are consecutive ids -> same XCD under the remap above (speed only)
+  const int slice = wg % g.splitk;
+  const int tile = wg / g.splitk;
+  const int nt = tile % a.ntn, mt = tile / a.ntn;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int nk = a.Kpad / BK;
+  const int nk_all = a.Kpad / BK;
+  const int ks0 = (int)((long long)slice * nk_all / g.splitk), ks1 = (int)((long long)(slice + 1) * nk_all / g.splitk);
+  const int nk = ks1 - ks0;                                      // K-steps of this slice
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -741,8 +753,16 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
     }
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
-    int kh = 0, kw = 0, c0 = 0, k0 = 0;
+    int k0 = ks0 * BK;                                            // first K element of this slice
+    int kh, kw, c0;
+    {
+      const int tap = k0 / a.Cin;
+      c0 = k0 - tap * a.Cin;
+      kh = tap / a.KW;
+      kw = tap - kh * a.KW;
+    }
     auto issue = [&](int buf) {
+      if (g.probe & 4) return;
       char* sa = smem + buf * STAGE + w4 * 1024;
       const int delta = ((kh * a.W + kw) * (int)a.ldx + c0) * ES;
 #pragma unroll
@@ -801,6 +821,59 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
     }
   }
   __syncthreads();                                 // every MFMA operand read is done: smem becomes the fp32 staging tile
+
+  if (g.splitk > 1) {
+    // ---- in-launch split-K reduction (MI355X guide §5 "Projection GEMM" item 2 / Guideline 16, counter form; no spinning):
+    // plain slab stores -> every storing wave drains vmcnt -> barrier -> ONE lane: agent release, ticket fetch_add ->
+    // the last arriver: agent acquire -> barrier -> plain slab loads.  Fragment-order slabs: each store / load
+    // instruction of a wave is one contiguous 1 KiB.
+    float* my = g.slab + ((size_t)tile * g.splitk + slice) * (BM * BN);
+    if (!loader) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            *(f32x4*)(my + ((((i * 2 + j) * 4 + q) * 256) + w4 * 64 + lane) * 4) = v;
+          }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* flag = (unsigned*)smem;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *flag = __hip_atomic_fetch_add(g.cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned ticket = *flag;
+    if (ticket != (unsigned)(g.splitk - 1)) return;            // not the last slice of this tile: done (whole block)
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(g.cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    if (!loader) {
+      for (int sl = 0; sl < g.splitk; ++sl) {
+        if (sl == slice) continue;
+        const float* other = g.slab + ((size_t)tile * g.splitk + sl) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 v = *(const f32x4*)(other + ((((i * 2 + j) * 4 + q) * 256) + w4 * 64 + lane) * 4);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc[i][j][4 * q + u] += v[u];
+            }
+      }
+    }
+    __syncthreads();                               // the ticket word in smem is dead before staging overwrites it
+  }
 
   float* st = (float*)smem;
   if (!loader) {
@@ -872,15 +945,20 @@ int conv_kpad(int K) { return (K + 63) / 64 * 64; }
 int conv_npad(int N) { return (N + 127) / 128 * 128; }
 
 static int g_glds_min_blocks = 40;    // bf16: the LDS-DMA tile wins down to ~40 blocks (measured); fp32 GEMMs: 512
+// In-launch split-K is implemented and correct (op tests run it) but OFF: on R50 bs8 it made every 100-200 tile layer
+// 1.3-2x SLOWER (tools/profile_layers.py --ab splitk: 28 -> 56 us on the 3x3 256ch convs): publishing a 64 KiB fp32 slab per
+// block behind an agent-scope release costs more than the shorter K loop saves (MI355X guide: splitk-seam 5-13 us).
+static int g_splitk_enable = 0;       // A/B hook (rtd_debug_option "splitk")
 static int g_glds_drop = 0;           // timing-only probe: 1 = x descriptor has 0 records, 2 = w, 3 = both (results wrong)
 static int g_conv_mode = 0;   // 0 auto, 1 = v1 only, 2 = v1 + v2 (no LDS-DMA path)
 static int g_force_v1 = 0;   // test / A-B hook (rtd_debug_option "conv_v1"): keep every layer on the v1 kernels
 void conv_set_force_v1(int v) { g_force_v1 = v; }
 void conv_set_glds_min_blocks(int v) { g_glds_min_blocks = v; }
 void conv_set_glds_drop(int v) { g_glds_drop = v; }
+void conv_set_splitk(int v) { g_splitk_enable = v; }
 void conv_set_mode(int v) { g_conv_mode = v; g_force_v1 = (v == 1); }
 template <typename T>
-static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long w_bytes, hipStream_t s) {
+static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long w_bytes, const ConvWorkspace& ws, hipStream_t s) {
   if (!ok || g_conv_mode == 1 || g_conv_mode == 2) return false;     // 5 = single-role LDS-DMA kernels (v3) for A/B
   const long long mt = (k.M + 127) / 128, ntn = (k.N + 127) / 128;
   // fp32 GEMMs (query-selection heads) may use a partly empty N tile: N >= 64 still beats the small-tile kernel
@@ -889,6 +967,7 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
   g.k = k;
   g.k.ntn = (int)ntn;
   g.probe = g_glds_drop;
+  g.splitk = 1; g.slab = nullptr; g.cnt = nullptr;
   g.x_bytes = (g_glds_drop & 1) ? 0u : (unsigned)x_bytes;
   g.w_bytes = (g_glds_drop & 2) ? 0u : (unsigned)w_bytes;
   // grids that fill every CU twice run 2 blocks/CU with a 2-deep pipeline; smaller grids get the
@@ -901,8 +980,20 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
   // measured (tools/profile_layers.py --ab conv_mode): loader/MFMA wave roles win at every grid size; >= 512 tiles run
   // 2 blocks per CU with 2 stages, smaller grids 1 block per CU with 4 stages (3 tiles of DMA in flight)
   if (g_conv_mode == 0) {
-    if (mt * ntn < 512) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
-    else hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+    const long long tiles = mt * ntn;
+    const int nk = k.Kpad / (128 / (int)sizeof(T));
+    // small grids leave CUs idle and run long serial K loops: split K so that ~600 blocks exist (>= 4 K-steps per slice)
+    int sk = 1;
+    if (g_splitk_enable && ws.slab && tiles < 512) {
+      sk = (int)((600 + tiles - 1) / tiles);
+      sk = std::min(sk, std::min(8, nk / 4));
+      sk = std::max(sk, 1);
+      if ((size_t)tiles * sk * (128 * 128 * 4) > ws.slab_bytes || (size_t)tiles > ws.cnt_entries) sk = 1;
+    }
+    g.splitk = sk; g.slab = ws.slab; g.cnt = ws.cnt;
+    const long long blocks = tiles * sk;
+    if (blocks < 512) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)blocks), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)blocks), dim3(512), 0, s, g);
     return true;
   }
   if (mt * ntn >= 512) hipLaunchKernelGGL((conv_igemm_glds_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(256), 0, s, g);
@@ -997,8 +1088,8 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     const long long es = (long long)dtype_size(x.dt);
     const long long x_bytes = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * es;
     const long long w_bytes = (long long)a.Npad * a.Kpad * es;
-    if (x.dt == BF16) done = dispatch_glds<bf16>(k, v2_ok, x_bytes, w_bytes, s);
-    else done = dispatch_glds<float>(k, v2_ok, x_bytes, w_bytes, s);
+    if (x.dt == BF16) done = dispatch_glds<bf16>(k, v2_ok, x_bytes, w_bytes, a.ws, s);
+    else done = dispatch_glds<float>(k, v2_ok, x_bytes, w_bytes, a.ws, s);
   }
   if (!done) {
     if (x.dt == BF16) done = dispatch_v2<bf16>(k, v2_ok, s);

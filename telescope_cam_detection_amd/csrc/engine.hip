@@ -97,6 +97,7 @@ struct rtd_engine {
   float* anchors_dev = nullptr; int32_t* invalid_rows_dev = nullptr; int n_invalid = 0;
   int32_t* lvl_dev = nullptr;
   float* pos_dev = nullptr;
+  ConvWorkspace conv_ws;
   int last_n = 0;
 
   void* dmalloc(size_t bytes) {
@@ -362,6 +363,7 @@ struct Builder {
     a.KH = k; a.KW = k; a.stride = stride; a.pad = pad; a.Kpad = w.Kpad; a.Npad = w.Npad;
     a.act = act; a.res_mode = res ? res_mode : RES_NONE;
     if (res) a.res = *res;
+    a.ws = e->conv_ws;
     const double M = (double)y.pixels();
     const double kreal = (double)k * k * (real_cin ? real_cin : x.c);
     const double flops = 2.0 * M * y.c * kreal;
@@ -995,6 +997,12 @@ int rtd_load_weights(rtd_handle h, const void* blob, size_t nbytes) {
     std::vector<float> pos = sincos_pos(e->lvl_h[2], e->lvl_w[2], c.enc_dim);
     e->pos_dev = (float*)e->dmalloc(pos.size() * 4);
     HIP_CHECK(hipMemcpy(e->pos_dev, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+    // split-K scratch: 600 blocks x 64 KiB slabs cover every small-grid layer; tickets start (and always return to) zero
+    e->conv_ws.slab_bytes = (size_t)640 * 128 * 128 * 4;
+    e->conv_ws.slab = (float*)e->dmalloc(e->conv_ws.slab_bytes);
+    e->conv_ws.cnt_entries = 1024;
+    e->conv_ws.cnt = (unsigned*)e->dmalloc(e->conv_ws.cnt_entries * 4);
+    HIP_CHECK(hipMemset(e->conv_ws.cnt, 0, e->conv_ws.cnt_entries * 4));
     e->forced_idx = (int32_t*)e->dmalloc((size_t)c.max_batch * c.num_queries * 4);
     e->force_flag = (int32_t*)e->dmalloc(16);
     HIP_CHECK(hipMemset(e->force_flag, 0, 16));
@@ -1204,6 +1212,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "dec_stamps") == 0) { g_dec_stamps = value; return RTD_OK; }
   if (strcmp(name, "dec_fused") == 0) { g_dec_fused = value; return RTD_OK; }
   if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
+  if (strcmp(name, "splitk") == 0) { conv_set_splitk(value); return RTD_OK; }
   if (strcmp(name, "glds_drop") == 0) { conv_set_glds_drop(value); return RTD_OK; }
   if (strcmp(name, "glds_min_blocks") == 0) { conv_set_glds_min_blocks(value); return RTD_OK; }
   return RTD_E_INVALID;
@@ -1232,7 +1241,16 @@ int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* b
     a.w = wdev; a.bias = bpad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.Npad = Npad;
     a.act = act; a.res_mode = res ? res_mode : RES_NONE;
     if (res) a.res = mk(res, dtype, B, OH, OW, Cout);
+    ConvWorkspace ws;
+    ws.slab_bytes = (size_t)640 * 128 * 128 * 4; ws.cnt_entries = 1024;
+    HIP_CHECK(hipMalloc((void**)&ws.slab, ws.slab_bytes));
+    HIP_CHECK(hipMalloc((void**)&ws.cnt, ws.cnt_entries * 4));
+    HIP_CHECK(hipMemset(ws.cnt, 0, ws.cnt_entries * 4));
+    a.ws = ws;
     launch_conv(a, nullptr);
+    launch_conv(a, nullptr);          // a second launch must find the tickets back at zero
+    HIP_CHECK(hipDeviceSynchronize());
+    (void)hipFree(ws.slab); (void)hipFree(ws.cnt);
     HIP_CHECK(hipDeviceSynchronize());
     if (wdev != wpad) (void)hipFree(wdev);
     (void)hipFree(wpad); (void)hipFree(bpad);

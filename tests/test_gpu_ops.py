@@ -80,6 +80,7 @@ def test_conv(L, dt, case):
     bd = b.cuda()
     rd = nhwc(res, tdt) if res is not None else None
     from telescope_cam_detection_amd import _capi
+    _capi.debug_option("splitk", 1)        # exercise the in-launch split-K reduction on the small-grid shapes (default off: slower)
     # conv_mode 0 = auto (LDS-DMA kernel where eligible), 2 = register-staged large tile, 1 = small tiles only,
     # 3 / 4 = wave-specialised LDS-DMA kernel (4 / 3 stages)
     for out_f32, mode in (((1, 0), (1, 1), (1, 2), (1, 3)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (0, 4))):
@@ -98,6 +99,7 @@ def test_conv(L, dt, case):
             tol = dict(atol=2e-2, rtol=1e-2)       # + one bf16 rounding of the output
         torch.testing.assert_close(got, y, **tol)
     _capi.debug_option("conv_mode", 0)
+    _capi.debug_option("splitk", 0)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
