@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 CSV output (kernel trace / PMC counter collection of a bench.py run) into the small JSON summaries
+committed under profiles/.
+
+    python tools/summarize_profiles.py trace  gpurun_out/rp/runc/<pid>_kernel_trace.csv        profiles/rNN_rocprofv3_kernel_summary.json
+    python tools/summarize_profiles.py pmc    <fetch counter_collection.csv> <write counter_collection.csv> profiles/rNN_pmc_hbm_traffic.json
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def family(name: str) -> str:
+    if "conv_igemm_ws" in name or "conv_igemm_glds" in name:
+        return "conv_igemm_lds_dma"
+    if "conv_igemm" in name:
+        return "conv_igemm_v1"
+    m = re.match(r"_ZN3rtd\d+([a-zA-Z_0-9]+?)I", name)
+    if m:
+        return m.group(1)
+    name = re.sub(r"^void ", "", name).replace("rtd::", "")
+    return re.sub(r"[<(].*", "", name)
+
+
+def steady_steps(rows):
+    idx = [i for i, r in enumerate(rows) if "k_preprocess_identity" in r["Kernel_Name"]]
+    steps = [rows[idx[i]:idx[i + 1]] for i in range(len(idx) - 1)]
+    modal = collections.Counter(len(s) for s in steps).most_common(1)[0][0]
+    good = [s for s in steps if len(s) == modal]
+    return (good[2:] if len(good) > 4 else good[-1:]), modal
+
+
+def do_trace(path, out):
+    rows = list(csv.DictReader(open(path)))
+    steps, modal = steady_steps(rows)
+    fam = collections.defaultdict(lambda: [0, 0])
+    span = []
+    for st in steps:
+        span.append((int(st[-1]["End_Timestamp"]) - int(st[0]["Start_Timestamp"])) / 1e6)
+        for r in st:
+            f = fam[family(r["Kernel_Name"])]
+            f[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            f[1] += 1
+    tot = sum(v[0] for v in fam.values())
+    ks = [dict(kernel=k, us_per_step=round(d / len(steps) / 1e3, 2), launches_per_step=c / len(steps), avg_us=round(d / c / 1e3, 3),
+               pct=round(100 * d / tot, 2)) for k, (d, c) in sorted(fam.items(), key=lambda kv: -kv[1][0])]
+    conv = [k for k in ks if k["kernel"].startswith("conv_igemm")]
+    res = dict(command="rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-latency",
+               steady_graph_steps_used=len(steps), kernels_per_step=modal, step_span_ms_median=sorted(span)[len(span) // 2],
+               conv_igemm_all=dict(us_per_step=round(sum(k["us_per_step"] for k in conv), 2), launches_per_step=sum(k["launches_per_step"] for k in conv),
+                                   avg_us=round(sum(k["us_per_step"] for k in conv) / sum(k["launches_per_step"] for k in conv), 3)),
+               kernels=ks)
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res["conv_igemm_all"]), "step", res["step_span_ms_median"], "ms")
+    for k in ks[:8]:
+        print(k)
+
+
+def do_pmc(fetch, write, out):
+    def load(path):
+        rows = list(csv.DictReader(open(path)))
+        steps, _ = steady_steps(rows)
+        fam = collections.defaultdict(lambda: [0.0, 0])
+        for r in steps[-1]:
+            f = fam[family(r["Kernel_Name"])]
+            f[0] += float(r["Counter_Value"])
+            f[1] += 1
+        return fam
+    f, w = load(fetch), load(write)
+    res = {"note": "one steady graph step; FETCH_SIZE / WRITE_SIZE in KiB from separate rocprofv3 --pmc passes; FETCH_SIZE doubled "
+                   "(gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md HBM section)"}
+    for k in f:
+        fk, c = f[k]
+        wk = w[k][0]
+        res[k] = dict(launches=c, fetch_kib_raw=fk, fetch_bytes_corrected=fk * 1024 * 2, write_bytes=wk * 1024,
+                      hbm_bytes_per_launch=(fk * 2048 + wk * 1024) / c)
+    json.dump(res, open(out, "w"), indent=1)
+    for k, v in res.items():
+        if isinstance(v, dict):
+            print(k, v["launches"], round(v["hbm_bytes_per_launch"] / 1e6, 2), "MB/launch")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "trace":
+        do_trace(sys.argv[2], sys.argv[3])
+    else:
+        do_pmc(sys.argv[2], sys.argv[3], sys.argv[4])
