@@ -151,6 +151,11 @@ int rtd_op_msdeform(int dtype, const void* value, const float* offaw, const floa
                     int value_ld, float offset_scale);
 int rtd_op_topk(const float* keys, int B, int N, int K, int32_t* idx_out, float* val_out);
 int rtd_op_resize(const uint8_t* src, int sh, int sw, void* dst, int dh, int dw, int dtype);
+/* kernel micro-benchmark (tools/conv_bench.py): one conv layer on zero-filled buffers, timed with HIP events.
+ * us_out[0] = mean of `reps` back-to-back launches (operands warm in L2 / Infinity Cache),
+ * us_out[1] = mean of `reps` launches each preceded by a `flush_mb` MiB memset (operands come from HBM). */
+int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int stride, int pad, int with_res,
+                   int reps, int flush_mb, float* us_out);
 
 #ifdef __cplusplus
 }

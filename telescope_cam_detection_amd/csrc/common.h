@@ -78,6 +78,11 @@ struct ConvArgs {
   int Kpad = 0, Npad = 0;
   int act = ACT_NONE, res_mode = RES_NONE;
   ConvWorkspace ws;    // optional: enables split-K on small grids
+  // optional: bytes the launch pulls towards the Infinity Cache for a LATER launch (the next layer's filter): one dword per
+  // 128-byte line, spread over the grid, issued while the first tile is in flight (tools/conv_bench.py: cold filters cost the
+  // K-heavy small-grid layers 5-13 us each; after a whole step of activation traffic they are cold in every step)
+  const void* pf = nullptr;
+  size_t pf_bytes = 0;
 };
 void launch_conv(const ConvArgs& a, hipStream_t s);
 int conv_kpad(int K);                 // padded filter row length the kernels expect
@@ -86,6 +91,7 @@ void conv_set_force_v1(int v);      // A/B hook: 1 = never take the large-tile (
 void conv_set_glds_min_blocks(int v);
 void conv_set_splitk(int v);        // A/B hook: 0 = never split K
 void conv_set_glds_drop(int v);     // timing-only traffic probe (MI355X guide §7): drop one operand's DMA via a 0-record descriptor
+void conv_set_prefetch(int v);      // A/B hook: 0 = launches ignore ConvArgs::pf
 void conv_set_mode(int v);          // A/B hook: 0 auto, 1 = v1 only, 2 = v1 + v2 (no LDS-DMA kernel)
 
 void launch_layernorm(const Tensor& x, const Tensor* res, const float* g, const float* b, const Tensor& y,
@@ -125,7 +131,10 @@ void launch_resize_pil(const uint8_t* src, int sh, int sw, uint8_t* tmp, const T
                        hipStream_t s);
 // ---- fused decoder layer (decoder.hip) ----
 struct DecLin {
-  const float* w;   // fragment-major fp32: [tile = n/16][chunk = k/16][lane 0..63][4] = W[16 tile + (lane & 15)][16 chunk + 4 (lane >> 4) + j]
+  // DecArgs::split == 0: fragment-major fp32: [tile = n/16][chunk = k/16][lane 0..63][4] = W[16 tile + (lane & 15)][16 chunk + 4 (lane >> 4) + j]
+  // DecArgs::split == 1: fragment-major bf16 hi|lo pairs (W = hi + lo to ~2^-17): [tile = n/16][chunk = k/32][hi, lo][lane 0..63][8] =
+  //                      W[16 tile + (lane & 15)][32 chunk + 8 (lane >> 4) + j]
+  const float* w;
   const float* b;   // [Npad]
   int ldw, N, K;
 };
@@ -137,6 +146,7 @@ struct DecLN {
 struct DecArgs {
   int mode;                 // 0 = prologue (enc_bbox head + ref init + next projections), 1 = layer, 2 = last layer (+ class head),
                             // 3 = AIFI prologue (x + pos -> q, K/V fragments), 4 = AIFI encoder layer
+  int split;                // 1: the linear layers run as 3 bf16 MFMAs on hi/lo splits of both operands (bf16 engine), 0: exact fp32 MFMA
   int B, Q, D, heads, S, n_levels, n_points, ffn, C;
   float offset_scale;
   // per-row state (global, fp32)

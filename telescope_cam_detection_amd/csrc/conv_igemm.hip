@@ -39,7 +39,23 @@ struct ConvK {
   long long ldy, y_bstride, ldr, r_bstride;
   int act, res_mode, y_f32, res_f32;
   int ntn;
+  const void* pf;        // prefetch target (next layer's filter) or nullptr
+  unsigned pf_bytes;
 };
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// Touch `pf_bytes` at `pf` (one dword per 128-byte line, this block's share) with LDS-DMA into a 256-byte dummy: no VGPR is
+// written, nothing waits for the data; the lines land in this XCD's L2 and in the Infinity Cache.
+__device__ __forceinline__ void prefetch_share(const ConvK& a, unsigned block, unsigned nblocks, unsigned t, unsigned nthreads, char* dummy) {
+  if (a.pf_bytes == 0) return;
+  const unsigned lines = a.pf_bytes >> 7;
+  const unsigned per = (lines + nblocks - 1) / nblocks;
+  const unsigned l0 = block * per;
+  const unsigned l1 = min(l0 + per, lines);
+  if (l0 >= l1) return;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.pf, 0, a.pf_bytes, 0x00020000);
+  for (unsigned l = l0 + t; l < l1; l += nthreads) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dummy, 4, l << 7, 0, 0, 0);
+}
 
 __device__ __forceinline__ float act_fn(float v, int act) {
   if (act == ACT_RELU) return fmaxf(v, 0.f);
@@ -82,11 +98,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
 
   __shared__ __attribute__((aligned(16))) T As[BM * LDS_LD];
   __shared__ __attribute__((aligned(16))) T Bs[BN * LDS_LD];
+  __shared__ __attribute__((aligned(16))) char pf_dummy[256];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int wm = wv & 1, wn = wv >> 1;
   const int bid = blockIdx.x;
+  prefetch_share(a, bid, gridDim.x, tid, 256, pf_dummy);
   const int nt = bid % a.ntn, mt = bid / a.ntn;
   const int m0 = mt * BM, n0 = nt * BN;
 
@@ -467,7 +485,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvK a) {
 //    (the range check makes the DMA write zeros - probed with tools/glds_probe.hip).
 //  * 2 LDS buffers, one `vmcnt(0)` + barrier per K-step: tile k+1 streams in under tile k's MFMAs.
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 struct ConvG {
   ConvK k;
@@ -685,7 +702,11 @@ __global__ __launch_bounds__(256, (STAGES == 2 ? 2 : 1)) void conv_igemm_glds_ke
 //   loader : wait tile ks (counted vmcnt) | barrier | issue tile ks+STAGES-1
 //   compute:                                barrier | MFMA tile ks
 // ------------------------------------------------------------------------------------------------
-template <typename T, int STAGES>
+// DEEP (4 stages only): the MFMA waves hold the fragments of a WHOLE K-step in registers and read tile ks+1 from LDS
+// while the MFMAs of tile ks run, so no ds_read latency is exposed behind the barrier (tools/ingest_probe.hip: the L2 ->
+// LDS path sustains 115-150 GB/s per CU, 2.5x what the non-DEEP K-step takes in; its K-step is bound by the serial
+// ds_read -> MFMA chain after each barrier, not by the DMA).  Tiles land one barrier earlier: 2 tiles stay in flight.
+template <typename T, int STAGES, bool DEEP = false>
 __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kernel(const ConvG g) {
   const ConvK& a = g.k;
   constexpr int BM = 128, BN = 128;
@@ -696,8 +717,9 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
   constexpr int SMEM = (STAGES * STAGE > BM * SLD * 4) ? STAGES * STAGE : BM * SLD * 4;
   constexpr int AHEAD = STAGES - 1;
   static_assert(STAGES >= 2 && STAGES <= 4, "counted waits below assume 1..3 tiles ahead");
+  static_assert(!DEEP || STAGES == 4, "DEEP issues 4 tiles ahead");
   typedef typename Mma<T>::Frag Frag;
-  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+  __shared__ __attribute__((aligned(16))) char smem[SMEM + 256];   // + the prefetch dummy
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -782,6 +804,24 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
         if (++kw == a.KW) { kw = 0; ++kh; }
       }
     };
+    if (DEEP) {
+      // tile t lives in buffer t % 4.  Before barrier ks tile ks+1 must have landed (the MFMA waves read it during step
+      // ks); after barrier ks the buffer of tile ks (read during step ks-1, reads drained before the barrier) is refilled.
+      for (int t = 0; t < 4 && t < nk; ++t) issue(t);
+      if (nk >= 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (nk == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (nk == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                 // tile 0 visible
+      for (int ks = 0; ks < nk; ++ks) {
+        const int younger = nk - 2 - ks;                            // tiles after ks+1 that exist (<= 2 of them are in flight)
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ks + 4 < nk) issue(ks & 3);
+      }
+    } else {
     for (int t = 0; t < AHEAD && t < nk; ++t) issue(t);
     for (int ks = 0; ks < nk; ++ks) {
       const int younger = nk - 1 - ks;
@@ -790,6 +830,48 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (ks + AHEAD < nk) issue((ks + AHEAD) % STAGES);
+    }
+    }
+  } else if (DEEP) {
+    // ---- MFMA role, whole-K-step fragment double buffering ------------------------------------------
+    int foff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 128 + (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
+    Frag fx0[4][2], fw0[4][2], fx1[4][2], fw1[4][2];
+    const int xo = wm * 64 * 128, wo = (BM + wn * 64) * 128;
+    auto step = [&](Frag (&cx)[4][2], Frag (&cw)[4][2], Frag (&nx)[4][2], Frag (&nw)[4][2], int ks) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's reads of tile ks are in registers
+      __builtin_amdgcn_s_barrier();                                 // tile ks+1 visible; buffer of tile ks may be refilled
+      const bool more = ks + 1 < nk;
+      const char* sa = smem + ((ks + 1) & 3) * STAGE + xo;
+      const char* sb = smem + ((ks + 1) & 3) * STAGE + wo;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (more) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) nx[kk][j] = *(const Frag*)(sa + j * 4096 + foff[kk]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) nw[kk][i] = *(const Frag*)(sb + i * 4096 + foff[kk]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) Mma<T>::run(cw[kk][i], cx[kk][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);                          // keep 4 reads : 4 MFMAs interleaved
+      }
+    };
+    __builtin_amdgcn_s_barrier();                                   // tile 0 visible
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fx0[kk][j] = *(const Frag*)(smem + xo + j * 4096 + foff[kk]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fw0[kk][i] = *(const Frag*)(smem + wo + i * 4096 + foff[kk]);
+    }
+    for (int ks = 0; ks < nk; ks += 2) {
+      step(fx0, fw0, fx1, fw1, ks);
+      if (ks + 1 >= nk) break;
+      step(fx1, fw1, fx0, fw0, ks + 1);
     }
   } else {
     // ---- MFMA role ---------------------------------------------------------------------------------
@@ -957,6 +1039,8 @@ void conv_set_glds_min_blocks(int v) { g_glds_min_blocks = v; }
 void conv_set_glds_drop(int v) { g_glds_drop = v; }
 void conv_set_splitk(int v) { g_splitk_enable = v; }
 void conv_set_mode(int v) { g_conv_mode = v; g_force_v1 = (v == 1); }
+static int g_prefetch = 1;    // A/B hook (rtd_debug_option "prefetch"): 0 = no next-layer filter prefetch
+void conv_set_prefetch(int v) { g_prefetch = v; }
 template <typename T>
 static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long w_bytes, const ConvWorkspace& ws, hipStream_t s) {
   if (!ok || g_conv_mode == 1 || g_conv_mode == 2) return false;     // 5 = single-role LDS-DMA kernels (v3) for A/B
@@ -972,8 +1056,9 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
   g.w_bytes = (g_glds_drop & 2) ? 0u : (unsigned)w_bytes;
   // grids that fill every CU twice run 2 blocks/CU with a 2-deep pipeline; smaller grids get the
   // whole LDS for one block and a 4-deep pipeline
-  if (g_conv_mode == 3 || g_conv_mode == 4) {      // A/B: wave-specialised kernel everywhere (3 = 4 stages, 4 = 2 stages at 2 blocks/CU)
+  if (g_conv_mode == 3 || g_conv_mode == 4 || g_conv_mode == 6) {   // A/B: one wave-specialised variant everywhere (3 = 4 stages, 4 = 2 stages at 2 blocks/CU, 6 = DEEP)
     if (g_conv_mode == 3) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+    else if (g_conv_mode == 6) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, true>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
     else hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
     return true;
   }
@@ -1079,6 +1164,8 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
   }
   k.act = a.act; k.res_mode = a.res_mode; k.y_f32 = y.dt == F32;
   k.ntn = 1;
+  k.pf = g_prefetch ? a.pf : nullptr;
+  k.pf_bytes = (g_prefetch && a.pf && a.pf_bytes < (1ull << 31)) ? (unsigned)a.pf_bytes : 0u;
   const bool smallc = (x.c % 32) != 0;
   const int bk2 = x.dt == BF16 ? 64 : 32;
   bool v2_ok = (x.c % bk2 == 0) && (y.c % 8 == 0) && (y.ld % 8 == 0) && (((uintptr_t)y.p & 15) == 0);

@@ -35,13 +35,22 @@ __device__ __forceinline__ float dinv_sig(float x) {
 // block (tile t, 16-wide k chunk c) is 64 lanes x 16 bytes in lane order, so one wave load is one contiguous
 // 1 KiB read.  (Row-major weights put adjacent lanes on different rows: 4x the cache-line requests, and the
 // layer ran 7x slower than its MFMA time.)
+//
+// `rot` (the block's row-tile index inside its image) rotates the order in which the block walks its column-tile passes and
+// its K steps.  All blocks of a launch run the same GEMM at the same time and an XCD's blocks share one L2: in lockstep they
+// all wait for the same L2 miss on every step (one 64 KiB round of unique bytes in flight per XCD); rotated, the XCD's blocks
+// request the whole filter in their first round and later rounds hit in L2.  The fp32 summation order of a row depends only on
+// its tile index, not on the batch size (batch invariance holds bit for bit).
 template <int ACT>
-__device__ void row_gemm(const float* Xs, int ldx, const DecLin& L, float* Ys, int ldy, const float* Rs, int ldr, int wave, int lane) {
+__device__ void row_gemm(const float* Xs, int ldx, const DecLin& L, float* Ys, int ldy, const float* Rs, int ldr, int wave, int lane, int rot) {
   const int ntiles = (L.N + 15) >> 4;
   const int r16 = lane & 15, q = lane >> 4;
   const float* xrow = Xs + r16 * ldx + 4 * q;
+  const int nsteps = L.K >> 6;
+  const int npass = (ntiles - wave + 2 * NW - 1) / (2 * NW);   // passes of this wave (wave < ntiles for every layer here)
   // two column tiles (t, t+NW) per pass share the A fragment and give the MFMA pipe two independent accumulators
-  for (int t = wave; t < ntiles; t += 2 * NW) {
+  for (int ps = 0; ps < npass; ++ps) {
+    const int t = wave + 2 * NW * ((ps + rot) % npass);
     const bool has2 = t + NW < ntiles;                          // wave-uniform
     const int n0 = t << 4, n1 = has2 ? (t + NW) << 4 : n0;
     const int kc = L.K >> 4;                                   // 16-wide chunks per tile
@@ -49,15 +58,18 @@ __device__ void row_gemm(const float* Xs, int ldx, const DecLin& L, float* Ys, i
     const float* w1 = L.w + (size_t)(has2 ? t + NW : t) * kc * 256 + lane * 4;
     f32x4_ acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     f32x4_ c0[4], c1[4], p0[4], p1[4];
-    // every load is unconditional (K % 64 == 0; the prefetch past the end is clamped onto the last chunk):
+    // every load is unconditional (K % 64 == 0; the prefetch after the last step re-reads a valid step):
     // a per-element "load or zero" select makes hipcc branch and drain vmcnt(0) around each load.
+    int st = (rot + ps) % nsteps;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      c0[j] = *(const f32x4_*)(w0 + 256 * j);
-      c1[j] = *(const f32x4_*)(w1 + 256 * j);
+      c0[j] = *(const f32x4_*)(w0 + (st << 2) * 256 + 256 * j);
+      c1[j] = *(const f32x4_*)(w1 + (st << 2) * 256 + 256 * j);
     }
-    for (int k0 = 0; k0 < L.K; k0 += 64) {
-      const int kn = min(k0 + 64, L.K - 64);
+    for (int it = 0; it < nsteps; ++it) {
+      const int k0 = st << 6;
+      st = st + 1 == nsteps ? 0 : st + 1;
+      const int kn = st << 6;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         p0[j] = *(const f32x4_*)(w0 + (kn >> 4) * 256 + 256 * j);
@@ -93,6 +105,117 @@ __device__ void row_gemm(const float* Xs, int ldx, const DecLin& L, float* Ys, i
           if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
           if (ACT == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
           Ys[row * ldy + col] = v;
+        }
+      }
+    }
+  }
+}
+
+typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+
+// fp32 rows in LDS -> bf16 hi / lo rows in LDS (x = hi + lo to ~2^-17 relative), K % 8 == 0
+__device__ __forceinline__ void split_rows(const float* Xs, int ldx, int K, bf16* Xh, bf16* Xl, int ldb, int tid) {
+  const int k8 = K >> 3;
+  for (int e = tid; e < DR * k8; e += NT) {
+    const int r = e / k8, c = (e - r * k8) << 3;
+    const f32x4_ v0 = *(const f32x4_*)(Xs + r * ldx + c), v1 = *(const f32x4_*)(Xs + r * ldx + c + 4);
+    bf16x8_ h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = j < 4 ? v0[j] : v1[j - 4];
+      const bf16 hi = (bf16)x;
+      h[j] = hi;
+      l[j] = (bf16)(x - (float)hi);
+    }
+    *(bf16x8_*)(Xh + r * ldb + c) = h;
+    *(bf16x8_*)(Xl + r * ldb + c) = l;
+  }
+}
+
+// The split form of row_gemm: A = (Ah + Al) [16][K] bf16 in LDS, W = hi + lo bf16 fragments (DecLin, split layout), three
+// v_mfma_f32_16x16x32_bf16 per 32-deep chunk (lo*hi, hi*lo, hi*hi; fp32 accumulate) instead of 8 v_mfma_f32_16x16x4_f32:
+// 5x less MFMA time for the same filter bytes, products exact to ~2^-17.  A lane's fragments: A[row = lane & 15][32c + 8 (lane >> 4) .. +7],
+// W[n0 + (lane & 15)][same k].  Output: fp32 Ys and / or a hi/lo split (Yh, Yl) for a following GEMM.
+template <int ACT>
+__device__ void row_gemm_split(const bf16* Ah, const bf16* Al, int lda, const DecLin& L, float* Ys, int ldy, const float* Rs, int ldr,
+                               bf16* Yh, bf16* Yl, int ldyb, int wave, int lane, int rot) {
+  const int ntiles = (L.N + 15) >> 4;
+  const int r16 = lane & 15, q = lane >> 4;
+  const bf16* ah = Ah + r16 * lda + 8 * q;
+  const bf16* al = Al + r16 * lda + 8 * q;
+  const int kc = L.K >> 5;                                     // 32-deep chunks per tile, 2 KiB each (hi 1 KiB | lo 1 KiB)
+  const int nsteps = L.K >> 6;
+  const int npass = (ntiles - wave + 2 * NW - 1) / (2 * NW);
+  for (int ps = 0; ps < npass; ++ps) {                          // pass / K-step rotation: see row_gemm
+    const int t = wave + 2 * NW * ((ps + rot) % npass);
+    const bool has2 = t + NW < ntiles;                          // wave-uniform
+    const int n0 = t << 4, n1 = has2 ? (t + NW) << 4 : n0;
+    const char* w0 = (const char*)L.w + (size_t)t * kc * 2048 + lane * 16;
+    const char* w1 = (const char*)L.w + (size_t)(has2 ? t + NW : t) * kc * 2048 + lane * 16;
+    f32x4_ acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // Two register sets (A, B), each one 64-deep K step of both tiles (8 x 16-byte loads per lane); a set is reloaded with the
+    // step two ahead right after its MFMAs were issued, so 8-16 loads per wave stay in flight (the loop is L2-latency bound:
+    // one step in flight per wave was 0.9 us per step).
+    bf16x8_ a0h[2], a0l[2], a1h[2], a1l[2], b0h[2], b0l[2], b1h[2], b1l[2];
+    int st = (rot + ps) % nsteps;
+    auto nxt = [&](int v) { return v + 1 == nsteps ? 0 : v + 1; };
+    auto load = [&](bf16x8_ (&h0)[2], bf16x8_ (&l0)[2], bf16x8_ (&h1)[2], bf16x8_ (&l1)[2], int step) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        h0[j] = *(const bf16x8_*)(w0 + (step << 1) * 2048 + 2048 * j);
+        l0[j] = *(const bf16x8_*)(w0 + (step << 1) * 2048 + 2048 * j + 1024);
+        h1[j] = *(const bf16x8_*)(w1 + (step << 1) * 2048 + 2048 * j);
+        l1[j] = *(const bf16x8_*)(w1 + (step << 1) * 2048 + 2048 * j + 1024);
+      }
+    };
+    auto mma = [&](const bf16x8_ (&h0)[2], const bf16x8_ (&l0)[2], const bf16x8_ (&h1)[2], const bf16x8_ (&l1)[2], int step) {
+      const int k0 = step << 6;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8_ xh = *(const bf16x8_*)(ah + k0 + 32 * j), xl = *(const bf16x8_*)(al + k0 + 32 * j);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, h0[j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, h1[j], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, l0[j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, l1[j], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, h0[j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, h1[j], acc1, 0, 0, 0);
+      }
+    };
+    const int s1 = nxt(st);
+    load(a0h, a0l, a1h, a1l, st);
+    if (nsteps > 1) load(b0h, b0l, b1h, b1l, s1);
+    int sa = st, sb = s1;
+    for (int it = 0; it < nsteps; it += 2) {                     // (wave-uniform guards: no load is issued past the last step)
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0h, a0l, a1h, a1l, sa);
+      __builtin_amdgcn_sched_barrier(0);
+      sa = nxt(sb);
+      if (it + 2 < nsteps) load(a0h, a0l, a1h, a1l, sa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + 1 < nsteps) mma(b0h, b0l, b1h, b1l, sb);
+      __builtin_amdgcn_sched_barrier(0);
+      sb = nxt(sa);
+      if (it + 3 < nsteps) load(b0h, b0l, b1h, b1l, sb);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1 && !has2) break;
+      const int col = (h == 0 ? n0 : n1) + r16;
+      if (col < L.N) {
+        const float bv = L.b[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = q * 4 + r;
+          float v = (h == 0 ? acc0[r] : acc1[r]) + bv;
+          if (Rs) v += Rs[row * ldr + col];
+          if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
+          if (ACT == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+          if (Ys) Ys[row * ldy + col] = v;
+          if (Yh) {
+            const bf16 hi = (bf16)v;
+            Yh[row * ldyb + col] = hi;
+            Yl[row * ldyb + col] = (bf16)(v - (float)hi);
+          }
         }
       }
     }
@@ -291,22 +414,63 @@ __device__ void self_attention_rows(const DecArgs& a, const float* sQ, int ldq, 
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = (float)(long long)(__builtin_amdgcn_s_memrealtime() - t_start); \
   } while (0)
 
+typedef __attribute__((address_space(3))) void* dec_lds_ptr_t;
+// Ask L2 for a later GEMM's filter: one dword per 128-byte line, this block's 1/nparts share, LDS-DMA into a dummy (no VGPR,
+// nothing waits).  The blocks of an XCD together request the whole filter one phase before they stream it, so the stream
+// hits in L2 instead of every block waiting on the same misses (tools/dec_stamps.py: 137 -> 115 us per layer came from
+// de-synchronising the blocks; this removes the remaining first-touch misses).
+__device__ __forceinline__ void touch_weights(const DecLin& L, int part, int nparts, int tid, char* dummy) {
+  if (!L.w) return;
+  const unsigned bytes = (unsigned)((L.N + 15) >> 4) * (unsigned)L.K * 64u;
+  const unsigned lines = bytes >> 7;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)L.w, 0, bytes, 0x00020000);
+  for (unsigned l = part + nparts * tid; l < lines; l += nparts * NT) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (dec_lds_ptr_t)dummy, 4, l << 7, 0, 0, 0);
+}
+
+// SPLIT: the linear layers take hi/lo bf16 splits of their operands (row_gemm_split); every fp32 A operand of K <= 256 is split
+// into the sXh/sXl staging rows right before its GEMM, the two wide ones (FFN hidden 1024, qpos hidden 512) are written as
+// splits by the producing GEMM straight into the sF region (same bytes as the fp32 rows they replace).
+template <bool SPLIT>
 __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
   // LDS (floats).  Row strides are (cols + 4): ds_read_b128 of 16 rows x 4 k-groups is conflict-free.
   constexpr int LDH = 260, LDF = 1028, LDQ = 516, LDO = 292, LDR = 68;
+  constexpr int LDX = 264, LDFB = 1032, LDQB = 520;             // bf16 row strides (16-byte rows, 4-bank skew per row)
   __shared__ __attribute__((aligned(16))) float sH[DR * LDH];   // hs / running activation x
   __shared__ __attribute__((aligned(16))) float sP[DR * LDH];   // query_pos of this layer, later of the next
   __shared__ __attribute__((aligned(16))) float sA[DR * LDH];   // attention out / sampled values / scratch
-  __shared__ __attribute__((aligned(16))) float sF[DR * LDF];   // FFN hidden (1024)
+  __shared__ __attribute__((aligned(16))) float sF[DR * LDF + 64];   // FFN hidden (1024); SPLIT: bf16 hi rows | lo rows
+  __shared__ __attribute__((aligned(16))) bf16 sXh[SPLIT ? DR * LDX : 8], sXl[SPLIT ? DR * LDX : 8];
+  __shared__ __attribute__((aligned(16))) char sDummy[256];     // touch_weights target
   float* const sT = sF;                                         // 512-wide scratch (bbox hidden, qpos hidden, q|k): live only while sF is dead
+  bf16* const sFh = (bf16*)sF;
+  bf16* const sFl = sFh + DR * LDFB;
+  bf16* const sQh = (bf16*)sF;                                  // qpos hidden (512) as a split, live between qp0 and qp1
+  bf16* const sQl = sQh + DR * LDQB;
+  static_assert(2 * DR * LDFB * 2 <= (DR * LDF + 64) * 4, "split FFN hidden must fit the fp32 region");
   __shared__ __attribute__((aligned(16))) float sO[DR * LDO];   // sampling offsets | attention logits
   __shared__ __attribute__((aligned(16))) float sR[DR * LDR];   // ref boxes (cols 0..3), zero padded to 64 (K of qpos.0)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Y[16][N] = act(X[16][K] W^T + b (+ R)); X fp32 rows in LDS.  SPLIT: X is first split into sXh/sXl (all waves must have
+  // left the previous GEMM: every call site below sits behind a __syncthreads()).
+#define DEC_TOUCH(LW) touch_weights(LW, rot, tiles, tid, sDummy)
+#define DEC_GEMM(ACT, X, LDXS, LW, Y, LDY, R, LDRS, NEXT)                                                   \
+  do {                                                                                                       \
+    if (SPLIT) {                                                                                             \
+      split_rows(X, LDXS, (LW).K, sXh, sXl, LDX, tid);                                                       \
+      __syncthreads();                                                                                       \
+      row_gemm_split<ACT>(sXh, sXl, LDX, LW, Y, LDY, R, LDRS, nullptr, nullptr, 0, wave, lane, rot);         \
+    } else {                                                                                                 \
+      row_gemm<ACT>(X, LDXS, LW, Y, LDY, R, LDRS, wave, lane, rot);                                          \
+    }                                                                                                        \
+    DEC_TOUCH(NEXT);                                                                                         \
+  } while (0)
   const unsigned long long t_start = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const int tiles = (a.Q + DR - 1) / DR;
   const int b = blockIdx.x / tiles;
   const int q0 = (blockIdx.x - b * tiles) * DR;
+  const int rot = q0 / DR;                                       // GEMM pass / K-step rotation (row_gemm)
+  const DecLin no_next = {nullptr, nullptr, 0, 0, 0};
   const int D = a.D;
   const long long row0 = (long long)b * a.Q + q0;
   const int nvalid = min(DR, a.Q - q0);
@@ -315,14 +479,34 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
   const bool has_attn = a.mode == 1 || a.mode == 2 || a.mode == 4;
   const bool has_cross = a.mode == 1 || a.mode == 2;
 
-  // ---- load the block's rows --------------------------------------------------------------------
-  for (int e = tid; e < DR * D; e += NT) {
-    const int r = e / D, c = e - r * D;
-    const bool ok = r < nvalid;
-    sH[r * LDH + c] = ok ? a.hs_in[(row0 + r) * D + c] : 0.f;
-    if (has_attn) sT[r * LDQ + c] = ok ? a.q_in[(row0 + r) * D + c] : 0.f;
-    if (has_cross) sP[r * LDH + c] = ok ? a.qpos_in[(row0 + r) * D + c] : 0.f;
-    if (a.mode == 3) sP[r * LDH + c] = ok ? a.qpos_in[(long long)(q0 + r) * D + c] : 0.f;   // AIFI: one sin-cos table for every image
+  // ---- load the block's rows (16-byte loads, every load of a thread issued before the first use: the phase is pure latency) --
+  {
+    constexpr int PER = DR * 256 / 4 / NT;                       // float4 per thread and array (D == 256)
+    f32x4_ vh[PER], vq[PER], vp[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = (tid + i * NT) * 4, r = e >> 8, c = e & 255;
+      const int rr = min(r, nvalid - 1);                          // rows past the end re-read a valid row; zeroed below
+      vh[i] = *(const f32x4_*)(a.hs_in + (row0 + rr) * D + c);
+      if (has_attn) vq[i] = *(const f32x4_*)(a.q_in + (row0 + rr) * D + c);
+      if (has_cross) vp[i] = *(const f32x4_*)(a.qpos_in + (row0 + rr) * D + c);
+      if (a.mode == 3) vp[i] = *(const f32x4_*)(a.qpos_in + (long long)(q0 + rr) * D + c);   // AIFI: one sin-cos table for every image
+    }
+    // first filters of this launch (the later ones are requested one GEMM ahead, DEC_GEMM)
+    if (has_attn) { DEC_TOUCH(a.o); DEC_TOUCH(a.fc1); }
+    if (has_cross) DEC_TOUCH(a.offaw);
+    if (a.mode == 4) DEC_TOUCH(a.fc2);
+    if (a.mode == 0) { DEC_TOUCH(a.bb0); DEC_TOUCH(a.bb1); }
+    if (a.mode == 3) { DEC_TOUCH(a.qk); DEC_TOUCH(a.v); }
+    const f32x4_ z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = (tid + i * NT) * 4, r = e >> 8, c = e & 255;
+      const bool ok = r < nvalid;
+      *(f32x4_*)(sH + r * LDH + c) = ok ? vh[i] : z4;
+      if (has_attn) *(f32x4_*)(sT + r * LDQ + c) = ok ? vq[i] : z4;
+      if (has_cross || a.mode == 3) *(f32x4_*)(sP + r * LDH + c) = ok ? vp[i] : z4;
+    }
   }
   for (int e = tid; e < DR * LDR; e += NT) {
     const int r = e / LDR, c = e - r * LDR;
@@ -337,7 +521,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     __syncthreads();
     DEC_STAMP(12);  // self-attention
     // ---- self-attention output projection + residual + LN1 (HF:v2.py:395-405) ---------------------
-    row_gemm<ACT_NONE>(sA, LDH, a.o, sH, LDH, sH, LDH, wave, lane);      // x = hs + att @ Wo   (in place: each element read then written by one lane)
+    DEC_GEMM(ACT_NONE, sA, LDH, a.o, sH, LDH, sH, LDH, a.op);      // x = hs + att @ Wo   (in place: each element read then written by one lane)
     __syncthreads();
     DEC_STAMP(1);   // o_proj
     row_ln(sH, LDH, D, a.ln1, wave, lane);
@@ -351,7 +535,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
       sA[r * LDH + c] = sH[r * LDH + c] + sP[r * LDH + c];
     }
     __syncthreads();
-    row_gemm<ACT_NONE>(sA, LDH, a.offaw, sO, LDO, nullptr, 0, wave, lane);
+    DEC_GEMM(ACT_NONE, sA, LDH, a.offaw, sO, LDO, nullptr, 0, a.fc1);
     __syncthreads();
     DEC_STAMP(3);   // add + offaw
     // ---- MS-deformable sampling (HF:v2.py:44-115,203-221): 32 lanes = one (row, head) ---------------
@@ -360,7 +544,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     __syncthreads();
     DEC_STAMP(4);   // sampling
     // ---- output projection + residual + LN2 (HF:v2.py:221,418-421) ----------------------------------
-    row_gemm<ACT_NONE>(sA, LDH, a.op, sH, LDH, sH, LDH, wave, lane);
+    DEC_GEMM(ACT_NONE, sA, LDH, a.op, sH, LDH, sH, LDH, a.fc2);
     __syncthreads();
     row_ln(sH, LDH, D, a.ln2, wave, lane);
     __syncthreads();
@@ -368,11 +552,21 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
   }
   if (has_attn) {
     // ---- FFN + residual + LN3 (HF:v2.py:423-428; AIFI: GELU, :888-896) ---------------------------------
-    if (a.mode == 4) row_gemm<ACT_GELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane);
-    else row_gemm<ACT_RELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane);
+    if (SPLIT) {
+      split_rows(sH, LDH, a.fc1.K, sXh, sXl, LDX, tid);
+      __syncthreads();
+      if (a.mode == 4) row_gemm_split<ACT_GELU>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
+      else row_gemm_split<ACT_RELU>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
+    } else {
+      if (a.mode == 4) row_gemm<ACT_GELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane, rot);
+      else row_gemm<ACT_RELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane, rot);
+    }
+    DEC_TOUCH(a.bb0);
     __syncthreads();
     DEC_STAMP(6);   // fc1
-    row_gemm<ACT_NONE>(sF, LDF, a.fc2, sH, LDH, sH, LDH, wave, lane);
+    if (SPLIT) row_gemm_split<ACT_NONE>(sFh, sFl, LDFB, a.fc2, sH, LDH, sH, LDH, nullptr, nullptr, 0, wave, lane, rot);
+    else row_gemm<ACT_NONE>(sF, LDF, a.fc2, sH, LDH, sH, LDH, wave, lane, rot);
+    DEC_TOUCH(a.bb1);
     __syncthreads();
     row_ln(sH, LDH, D, a.ln3, wave, lane);
     __syncthreads();
@@ -392,11 +586,13 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
 
   if (a.mode != 3) {
   // ---- box head: mode 0 = enc_bbox_head(target) + anchors (HF:v2.py:1588-1599), else bbox_embed[i] + logit(ref) (:636-639)
-  row_gemm<ACT_RELU>(sH, LDH, a.bb0, sA, LDH, nullptr, 0, wave, lane);
+  DEC_GEMM(ACT_RELU, sH, LDH, a.bb0, sA, LDH, nullptr, 0, a.qp0);
+  DEC_TOUCH(a.bb2);
   __syncthreads();
-  row_gemm<ACT_RELU>(sA, LDH, a.bb1, sT, LDQ, nullptr, 0, wave, lane);
+  DEC_GEMM(ACT_RELU, sA, LDH, a.bb1, sT, LDQ, nullptr, 0, a.qp1);
+  DEC_TOUCH(a.cls);
   __syncthreads();
-  row_gemm<ACT_NONE>(sT, LDQ, a.bb2, sO, LDO, nullptr, 0, wave, lane);    // [16][4] deltas in sO cols 0..3
+  DEC_GEMM(ACT_NONE, sT, LDQ, a.bb2, sO, LDO, nullptr, 0, a.qk);    // [16][4] deltas in sO cols 0..3
   __syncthreads();
   if (tid < DR * 4) {
     const int r = tid >> 2, c = tid & 3;
@@ -430,7 +626,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
 
   if (a.mode == 2) {
     // ---- class head of the last layer (HF:v2.py:644-646,1880) ----------------------------------------
-    row_gemm<ACT_NONE>(sH, LDH, a.cls, sT, LDQ, nullptr, 0, wave, lane);
+    DEC_GEMM(ACT_NONE, sH, LDH, a.cls, sT, LDQ, nullptr, 0, no_next);
     __syncthreads();
     for (int e = tid; e < DR * a.C; e += NT) {
       const int r = e / a.C, c = e - r * a.C;
@@ -441,9 +637,19 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
 
   // ---- projections for the NEXT layer: qpos = MLP(ref) (HF:v2.py:613), q|k = (hs+qpos) Wqk, v = hs Wv ----
   if (a.mode != 3) {
-    row_gemm<ACT_RELU>(sR, LDR, a.qp0, sT, LDQ, nullptr, 0, wave, lane);
-    __syncthreads();
-    row_gemm<ACT_NONE>(sT, LDQ, a.qp1, sP, LDH, nullptr, 0, wave, lane);
+    if (SPLIT) {
+      split_rows(sR, LDR, a.qp0.K, sXh, sXl, LDX, tid);
+      __syncthreads();
+      row_gemm_split<ACT_RELU>(sXh, sXl, LDX, a.qp0, nullptr, 0, nullptr, 0, sQh, sQl, LDQB, wave, lane, rot);
+      DEC_TOUCH(a.v);
+      __syncthreads();
+      row_gemm_split<ACT_NONE>(sQh, sQl, LDQB, a.qp1, sP, LDH, nullptr, 0, nullptr, nullptr, 0, wave, lane, rot);
+    } else {
+      row_gemm<ACT_RELU>(sR, LDR, a.qp0, sT, LDQ, nullptr, 0, wave, lane, rot);
+      DEC_TOUCH(a.v);
+      __syncthreads();
+      row_gemm<ACT_NONE>(sT, LDQ, a.qp1, sP, LDH, nullptr, 0, wave, lane, rot);
+    }
     __syncthreads();
   }
   DEC_STAMP(9);   // hs store + qpos MLP
@@ -453,8 +659,9 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (a.mode != 3 && r < nvalid) a.qpos_out[(row0 + r) * D + c] = sP[r * LDH + c];
   }
   __syncthreads();
-  row_gemm<ACT_NONE>(sA, LDH, a.qk, sT, LDQ, nullptr, 0, wave, lane);
-  row_gemm<ACT_NONE>(sH, LDH, a.v, sO, LDO, nullptr, 0, wave, lane);
+  DEC_GEMM(ACT_NONE, sA, LDH, a.qk, sT, LDQ, nullptr, 0, no_next);
+  if (SPLIT) __syncthreads();                                   // every wave is out of the q|k GEMM before its staging rows are re-split
+  DEC_GEMM(ACT_NONE, sH, LDH, a.v, sO, LDO, nullptr, 0, no_next);
   __syncthreads();
   DEC_STAMP(10);  // qk + v
   // q rows, and K / V of these 16 rows (= key tile `tile`) in the fragment order self_attention_rows() reads
@@ -480,7 +687,8 @@ void launch_dec_layer(const DecArgs& a, hipStream_t s) {
   RTD_CHECK(a.D == 256 && a.D / a.heads == 32 && a.ffn <= 1024 && a.C <= 512, 1, "fused decoder: d_model 256, head dim 32, ffn <= 1024");
   RTD_CHECK(a.n_levels == 3 && a.n_points == 4 && a.heads == NW, 1, "fused decoder: 3 levels x 4 points, 8 heads");
   const int tiles = (a.Q + DR - 1) / DR;
-  hipLaunchKernelGGL(dec_layer_kernel, dim3(a.B * tiles), dim3(NT), 0, s, a);
+  if (a.split) hipLaunchKernelGGL(dec_layer_kernel<true>, dim3(a.B * tiles), dim3(NT), 0, s, a);
+  else hipLaunchKernelGGL(dec_layer_kernel<false>, dim3(a.B * tiles), dim3(NT), 0, s, a);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -25,6 +25,7 @@ namespace {
 
 thread_local std::string g_create_error;
 int g_dec_stamps = 0;  // plan-build switch: record per-phase stamps of decoder layer 2 into debug tensor "dec_stamps"
+int g_dec_split = 1;   // plan-build switch (rtd_debug_option "dec_split"): bf16 engine runs the fused decoder / AIFI linears as bf16 hi/lo splits
 int g_dec_fused = 1;   // plan-build switch (rtd_debug_option "dec_fused"): 0 = one launch per decoder op
 
 struct HostTensor {
@@ -188,8 +189,22 @@ DevWeight get_weight(rtd_engine* e, const std::string& name, int dt, int N, int 
 }
 
 // fp32 filter [N][K] -> fragment-major layout of decoder.hip's row_gemm (K padded to Kuse, N to 8 tiles)
-DevWeight get_weight_packed(rtd_engine* e, const std::string& name, int N, int K, int Kuse) {
-  const std::string key = name + "#packed";
+static inline uint16_t f2bf_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);     // inf / nan: truncate
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf2f(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+DevWeight get_weight_packed(rtd_engine* e, const std::string& name, int N, int K, int Kuse, bool split = false) {
+  const std::string key = name + (split ? "#split" : "#packed");
   auto it = e->wcache.find(key);
   if (it != e->wcache.end()) return it->second;
   const HostTensor& w = host_tensor(e, name + ".w");
@@ -200,16 +215,39 @@ DevWeight get_weight_packed(rtd_engine* e, const std::string& name, int N, int K
   d.N = N; d.K = Kuse; d.Kpad = Kuse; d.dt = F32;
   const int ntiles = ((N + 15) / 16 + 7) / 8 * 8, kc = Kuse / 16;
   d.Npad = ntiles * 16;
-  std::vector<float> pk((size_t)ntiles * kc * 256, 0.f);
-  for (int t = 0; t < ntiles; ++t)
+  std::vector<float> pk(split ? 0 : (size_t)ntiles * kc * 256, 0.f);
+  for (int t = 0; t < (split ? 0 : ntiles); ++t)
     for (int c = 0; c < kc; ++c)
       for (int lane = 0; lane < 64; ++lane)
         for (int j = 0; j < 4; ++j) {
           const int n = t * 16 + (lane & 15), k = c * 16 + 4 * (lane >> 4) + j;
           if (n < N && k < K) pk[(((size_t)t * kc + c) * 64 + lane) * 4 + j] = w.data[(size_t)n * K + k];
         }
+  if (split) {
+    // W = hi + lo (two bf16, round-to-nearest-even each): decoder.hip row_gemm_split multiplies both against a hi/lo split of
+    // the activations with 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi); the dropped lo*lo term is ~2^-18 relative
+    const int kc32 = Kuse / 32;
+    std::vector<uint16_t> ps((size_t)ntiles * kc32 * 2 * 512, 0);
+    for (int t = 0; t < ntiles; ++t)
+      for (int c = 0; c < kc32; ++c)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int n = t * 16 + (lane & 15), k = c * 32 + 8 * (lane >> 4) + j;
+            if (n < N && k < K) {
+              const float v = w.data[(size_t)n * K + k];
+              const uint16_t hi = f2bf_rne(v);
+              const uint16_t lo = f2bf_rne(v - bf2f(hi));
+              const size_t base = ((size_t)t * kc32 + c) * 1024;
+              ps[base + lane * 8 + j] = hi;
+              ps[base + 512 + lane * 8 + j] = lo;
+            }
+          }
+    d.w = e->dmalloc(ps.size() * 2);
+    HIP_CHECK(hipMemcpy(d.w, ps.data(), ps.size() * 2, hipMemcpyHostToDevice));
+  } else {
   d.w = e->dmalloc(pk.size() * 4);
   HIP_CHECK(hipMemcpy(d.w, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+  }
   std::vector<float> bp(d.Npad, 0.f);
   memcpy(bp.data(), b.data, (size_t)N * 4);
   d.bias = (float*)e->dmalloc(bp.size() * 4);
@@ -369,8 +407,15 @@ struct Builder {
     const double flops = 2.0 * M * y.c * kreal;
     const double bytes = (double)x.pixels() * x.c * dtype_size(x.dt) + tbytes(y) + (double)y.c * K * dtype_size(x.dt) +
                          (res ? tbytes(*res) : 0.0);
-    push(name, "conv_igemm", flops, bytes, [a](hipStream_t s) { launch_conv(a, s); });
+    auto ap = std::make_shared<ConvArgs>(a);
+    if (!dry) {
+      // chain: the previous conv launch of the plan prefetches THIS filter while it runs (ConvArgs::pf)
+      if (last_conv) { last_conv->pf = w.w; last_conv->pf_bytes = (size_t)w.Npad * w.Kpad * dtype_size(x.dt); }
+      last_conv = ap;
+    }
+    push(name, "conv_igemm", flops, bytes, [ap](hipStream_t s) { launch_conv(*ap, s); });
   }
+  std::shared_ptr<ConvArgs> last_conv;
   Tensor linear(const std::string& name, const Tensor& x, int N, int odt, int act, const Tensor* res = nullptr,
                 const std::string& tname = "") {
     Tensor y = this->act(odt, x.n, x.h, x.w, N, tname);
@@ -490,12 +535,13 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     auto elin = [&](const std::string& name, int N, int K) {
       DecLin Lw{};
       if (!B.dry) {
-        DevWeight w = get_weight_packed(e, name, N, K, K);
+        DevWeight w = get_weight_packed(e, name, N, K, K, g_dec_split && P == BF16);
         Lw.w = (const float*)w.w; Lw.b = w.bias; Lw.ldw = w.Kpad; Lw.N = N; Lw.K = w.K;
       }
       return Lw;
     };
     DecArgs a0{};
+    a0.split = g_dec_split && P == BF16;
     a0.B = n; a0.Q = L; a0.D = d; a0.heads = 8; a0.S = 0; a0.n_levels = 3; a0.n_points = 4; a0.ffn = c.enc_ffn; a0.C = 4;
     a0.hs_in = (const float*)t0.p; a0.qpos_in = e->pos_dev;
     a0.q_in = (const float*)qrows.p; a0.q_out = (float*)qrows.p;
@@ -635,7 +681,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     auto lin = [&](const std::string& name, int N, int K, int Kuse = 0) {
       DecLin L{};
       if (!B.dry) {
-        DevWeight w = get_weight_packed(e, name, N, K, Kuse ? Kuse : K);
+        DevWeight w = get_weight_packed(e, name, N, K, Kuse ? Kuse : K, g_dec_split && P == BF16);
         L.w = (const float*)w.w; L.b = w.bias; L.ldw = w.Kpad; L.N = N; L.K = w.K;
       }
       return L;
@@ -646,6 +692,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       return P;
     };
     DecArgs base{};
+    base.split = g_dec_split && P == BF16;
     base.B = n; base.Q = Q; base.D = dm; base.heads = c.dec_heads; base.S = S; base.n_levels = c.n_levels;
     base.n_points = c.n_points; base.ffn = c.dec_ffn; base.C = C; base.offset_scale = c.offset_scale;
     base.ref8 = ref8; base.ref_unact8 = ref_unact8; base.anchors = e->anchors_dev; base.tk_idx = tk;
@@ -1165,6 +1212,7 @@ int rtd_debug_force_topk(rtd_handle h, const int32_t* idx, int32_t n) {
   });
 }
 
+static int g_profile_twice = 0;
 int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int32_t capacity, int32_t* count) {
   return guarded(h, [&] {
     check_n(h, n);
@@ -1180,6 +1228,26 @@ int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int3
     std::vector<double> acc(nops, 0.0);
     for (auto& op : p->ops) op.run(h->stream);   // warm-up
     for (int r = 0; r < reps; ++r) {
+      if (g_profile_twice) {
+        // diagnostic: every op runs twice back to back and only the SECOND run is timed (operands, filter and TLB entries
+        // warm from the first) - the gap to the normal profile is what the op pays for cold operands inside the network
+        std::vector<hipEvent_t> ev2((size_t)nops);
+        for (auto& x : ev2) HIP_CHECK(hipEventCreate(&x));
+        for (int i = 0; i < nops; ++i) {
+          p->ops[i].run(h->stream);
+          HIP_CHECK(hipEventRecord(ev2[i], h->stream));
+          p->ops[i].run(h->stream);
+          HIP_CHECK(hipEventRecord(ev[i + 1], h->stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        for (int i = 0; i < nops; ++i) {
+          float ms = 0.f;
+          HIP_CHECK(hipEventElapsedTime(&ms, ev2[i], ev[i + 1]));
+          acc[i] += ms;
+        }
+        for (auto& x : ev2) (void)hipEventDestroy(x);
+        continue;
+      }
       HIP_CHECK(hipEventRecord(ev[0], h->stream));
       for (int i = 0; i < nops; ++i) {
         p->ops[i].run(h->stream);
@@ -1206,12 +1274,23 @@ int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int3
 }
 
 // ---- kernel-level test entry points ---------------------------------------------------------------
+// reads one dword per 128-byte line (bench only: does a READ bring lines into the Infinity Cache?)
+__global__ void k_touch_read(const unsigned* p, size_t lines, unsigned* sink) {
+  unsigned acc = 0;
+  for (size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x; l < lines; l += (size_t)gridDim.x * blockDim.x) acc += p[l * 32];
+  if (acc == 0x12345u) *sink = acc;
+}
+static int g_bench_rewarm = 0;   // "bench_rewarm": rtd_bench_conv rewrites 1 = activations, 2 = weights after its flush (back into the Infinity Cache)
 int rtd_debug_option(const char* name, int value) {
   if (!name) return RTD_E_INVALID;
   if (strcmp(name, "conv_v1") == 0) { conv_set_force_v1(value); return RTD_OK; }
   if (strcmp(name, "dec_stamps") == 0) { g_dec_stamps = value; return RTD_OK; }
   if (strcmp(name, "dec_fused") == 0) { g_dec_fused = value; return RTD_OK; }
+  if (strcmp(name, "dec_split") == 0) { g_dec_split = value; return RTD_OK; }
   if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
+  if (strcmp(name, "prefetch") == 0) { conv_set_prefetch(value); return RTD_OK; }
+  if (strcmp(name, "profile_twice") == 0) { g_profile_twice = value; return RTD_OK; }
+  if (strcmp(name, "bench_rewarm") == 0) { g_bench_rewarm = value; return RTD_OK; }
   if (strcmp(name, "splitk") == 0) { conv_set_splitk(value); return RTD_OK; }
   if (strcmp(name, "glds_drop") == 0) { conv_set_glds_drop(value); return RTD_OK; }
   if (strcmp(name, "glds_min_blocks") == 0) { conv_set_glds_min_blocks(value); return RTD_OK; }
@@ -1254,6 +1333,67 @@ int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* b
     HIP_CHECK(hipDeviceSynchronize());
     if (wdev != wpad) (void)hipFree(wdev);
     (void)hipFree(wpad); (void)hipFree(bpad);
+  });
+}
+
+int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int stride, int pad, int with_res, int reps,
+                   int flush_mb, float* us_out) {
+  return op_guard([&] {
+    const int K = KH * KH * Cin, Kpad = conv_kpad(K), Npad = conv_npad(Cout);
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
+    const size_t es = dtype == BF16 ? 2 : 4;
+    const size_t xb = (size_t)B * H * W * Cin * es, yb = (size_t)B * OH * OW * Cout * es, wb = (size_t)Npad * Kpad * es;
+    void *x = nullptr, *y = nullptr, *r = nullptr, *w = nullptr, *flush = nullptr; float* bias = nullptr;
+    HIP_CHECK(hipMalloc(&x, xb)); HIP_CHECK(hipMalloc(&y, yb)); HIP_CHECK(hipMalloc(&w, wb)); HIP_CHECK(hipMalloc((void**)&bias, Npad * 4));
+    HIP_CHECK(hipMemset(x, 0, xb)); HIP_CHECK(hipMemset(w, 0, wb)); HIP_CHECK(hipMemset(bias, 0, Npad * 4));
+    if (with_res) { HIP_CHECK(hipMalloc(&r, yb)); HIP_CHECK(hipMemset(r, 0, yb)); }
+    if (flush_mb > 0) HIP_CHECK(hipMalloc(&flush, (size_t)flush_mb << 20));
+    ConvArgs a;
+    a.x = mk(x, dtype, B, H, W, Cin);
+    a.y = mk(y, dtype, B, OH, OW, Cout);
+    a.w = w; a.bias = bias; a.KH = KH; a.KW = KH; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.Npad = Npad;
+    a.act = 1; a.res_mode = with_res ? RES_PRE : RES_NONE;
+    if (with_res) a.res = mk(r, dtype, B, OH, OW, Cout);
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_conv(a, nullptr);
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < reps; ++i) launch_conv(a, nullptr);
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    us_out[0] = ms * 1e3f / reps;
+    us_out[1] = 0.f;
+    if (flush) {
+      float tot = 0.f;
+      for (int i = 0; i < reps; ++i) {
+        HIP_CHECK(hipMemsetAsync(flush, i & 0xff, (size_t)flush_mb << 20, nullptr));
+        if (g_bench_rewarm & 1) { HIP_CHECK(hipMemsetAsync(x, 0, xb, nullptr)); if (r) HIP_CHECK(hipMemsetAsync(r, 0, yb, nullptr)); }
+        if (g_bench_rewarm & 2) HIP_CHECK(hipMemsetAsync(w, 0, wb, nullptr));
+        if (g_bench_rewarm & 4) hipLaunchKernelGGL(k_touch_read, dim3(64), dim3(256), 0, nullptr, (const unsigned*)w, wb / 128, (unsigned*)bias);
+        if (g_bench_rewarm & 16) {      // in-kernel prefetch path: a small unrelated conv launch carries pf = this filter
+          ConvArgs d = a;
+          d.x = mk(x, dtype, 1, H, W, Cin); d.y = mk(y, dtype, 1, OH, OW, Cout);
+          if (with_res) d.res = mk(r, dtype, 1, OH, OW, Cout);
+          d.pf = w; d.pf_bytes = wb;
+          launch_conv(d, nullptr);
+        }
+        if (g_bench_rewarm & 8) hipLaunchKernelGGL(k_touch_read, dim3(64), dim3(256), 0, nullptr, (const unsigned*)x, xb / 128, (unsigned*)bias);
+        HIP_CHECK(hipEventRecord(e0, nullptr));
+        launch_conv(a, nullptr);
+        HIP_CHECK(hipEventRecord(e1, nullptr));
+        HIP_CHECK(hipEventSynchronize(e1));
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        tot += ms;
+      }
+      us_out[1] = tot * 1e3f / reps;
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(bias);
+    if (r) (void)hipFree(r);
+    if (flush) (void)hipFree(flush);
   });
 }
 
