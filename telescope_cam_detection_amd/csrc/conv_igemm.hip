@@ -750,6 +750,25 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // bf16 residual rows of this thread's 4 epilogue iterations: every load is issued at kernel start, beside the first tile's DMA (and
+  // before any store to y, which the compiler must assume aliases res): the residual latency overlaps the K loop instead of
+  // being paid four times in series in the epilogue
+  const int c8 = tid & 15;
+  const int c = n0 + c8 * 8;
+  bf16x8 rpre[4];
+  if (a.res_mode != RES_NONE && !a.res_f32 && c < a.N) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int m = m0 + (tid >> 4) + it * 32;
+      if (m < a.M) {
+        const int b = m / a.OHW;
+        const int p = m - b * a.OHW;
+        rpre[it] = *(const bf16x8*)((const bf16*)a.res + (long long)b * a.r_bstride + (long long)p * a.ldr + c);
+      }
+    }
+  }
+  if (!loader) prefetch_share(a, blockIdx.x, gridDim.x, tid, 256, smem + SMEM);   // next layer's filter; the MFMA waves idle until tile 0 lands
+
   if (loader) {
     // ---- loader role -------------------------------------------------------------------------------
     const int lrow = w4 * 8 + (lane >> 3);
@@ -973,8 +992,6 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
     }
   }
   __syncthreads();
-  const int c8 = tid & 15;
-  const int c = n0 + c8 * 8;
   if (c < a.N) {
     const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
 #pragma unroll
@@ -989,15 +1006,14 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
       const int p = m - b * a.OHW;
       float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (a.res_mode != RES_NONE) {
-        const long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
         if (a.res_f32) {
+          const long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
           const f32x4 t0 = *(const f32x4*)((const float*)a.res + roff), t1 = *(const f32x4*)((const float*)a.res + roff + 4);
 #pragma unroll
           for (int q = 0; q < 4; ++q) { rv[q] = t0[q]; rv[4 + q] = t1[q]; }
         } else {
-          const bf16x8 t = *(const bf16x8*)((const bf16*)a.res + roff);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) rv[q] = (float)t[q];
+          for (int q = 0; q < 8; ++q) rv[q] = (float)rpre[it][q];
         }
       }
       if (a.res_mode == RES_PRE) {
