@@ -57,6 +57,24 @@ __device__ __forceinline__ void prefetch_share(const ConvK& a, unsigned block, u
   for (unsigned l = l0 + t; l < l1; l += nthreads) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dummy, 4, l << 7, 0, 0, 0);
 }
 
+// the activation is a kernel argument: the epilogue loops are instantiated once per activation (dispatch_act) so that the
+// choice costs one scalar branch per block - as a per-element switch (8 scalar branches around each of a thread's 32-64 outputs)
+// it was 4.5 us of a 20 us launch (s_memtime stamps, tools/_bin/stamp_run.py)
+template <int A> struct ActC { static constexpr int value = A; };
+template <int ACT> __device__ __forceinline__ float act_c(float v) {
+  if (ACT == ACT_RELU) return fmaxf(v, 0.f);
+  if (ACT == ACT_SILU) return v / (1.f + __expf(-v));
+  if (ACT == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  return v;
+}
+template <typename F> __device__ __forceinline__ void dispatch_act(int act, F&& f) {
+  switch (act) {
+    case ACT_RELU: f(ActC<ACT_RELU>{}); break;
+    case ACT_SILU: f(ActC<ACT_SILU>{}); break;
+    case ACT_GELU: f(ActC<ACT_GELU>{}); break;
+    default: f(ActC<ACT_NONE>{}); break;
+  }
+}
 __device__ __forceinline__ float act_fn(float v, int act) {
   if (act == ACT_RELU) return fmaxf(v, 0.f);
   if (act == ACT_SILU) return v / (1.f + __expf(-v));
@@ -225,6 +243,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
 
   // ---- epilogue: bias (+ residual) + activation, 4 consecutive channels per store --------------
   const int h = lane >> 5;
+  dispatch_act(a.act, [&](auto actc) {
+  constexpr int ACT = decltype(actc)::value;
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int m = m0 + wm * WM + j * 32 + (lane & 31);
@@ -260,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
           for (int q = 0; q < 4; ++q) v[q] += rv[q];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = act_fn(v[q], a.act);
+        for (int q = 0; q < 4; ++q) v[q] = act_c<ACT>(v[q]);
         if (a.res_mode == RES_POST) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] += rv[q];
@@ -275,6 +295,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
       }
     }
   }
+  });
 }
 
 
@@ -427,6 +448,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvK a) {
   const int c = n0 + c8 * 8;
   if (c < a.N) {
     const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
+    dispatch_act(a.act, [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int pl = (tid + it * 256) / CPP;
@@ -455,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvK a) {
         for (int q = 0; q < 8; ++q) v[q] += rv[q];
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = act_fn(v[q], a.act);
+      for (int q = 0; q < 8; ++q) v[q] = act_c<ACT>(v[q]);
       if (a.res_mode == RES_POST) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] += rv[q];
@@ -470,6 +493,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvK a) {
         *(bf16x8*)((bf16*)a.y + yoff) = o;
       }
     }
+    });
   }
 }
 
@@ -646,6 +670,8 @@ __global__ __launch_bounds__(256, (STAGES == 2 ? 2 : 1)) void conv_igemm_glds_ke
   const int c = n0 + c8 * 8;
   if (c < a.N) {
     const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
+    dispatch_act(a.act, [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int pl = (tid >> 4) + it * 16;
@@ -674,7 +700,7 @@ __global__ __launch_bounds__(256, (STAGES == 2 ? 2 : 1)) void conv_igemm_glds_ke
         for (int q = 0; q < 8; ++q) v[q] += rv[q];
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = act_fn(v[q], a.act);
+      for (int q = 0; q < 8; ++q) v[q] = act_c<ACT>(v[q]);
       if (a.res_mode == RES_POST) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] += rv[q];
@@ -689,6 +715,7 @@ __global__ __launch_bounds__(256, (STAGES == 2 ? 2 : 1)) void conv_igemm_glds_ke
         *(bf16x8*)((bf16*)a.y + yoff) = o;
       }
     }
+    });
   }
 }
 
@@ -994,6 +1021,8 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
   __syncthreads();
   if (c < a.N) {
     const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
+    dispatch_act(a.act, [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int pl = (tid >> 4) + it * 32;
@@ -1021,7 +1050,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
         for (int q = 0; q < 8; ++q) v[q] += rv[q];
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = act_fn(v[q], a.act);
+      for (int q = 0; q < 8; ++q) v[q] = act_c<ACT>(v[q]);
       if (a.res_mode == RES_POST) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] += rv[q];
@@ -1036,6 +1065,239 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
         *(bf16x8*)((bf16*)a.y + yoff) = o;
       }
     }
+    });
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// v4b: the wave-specialised kernel on a 256 pixel x 128 channel tile, 3 stages.  Each MFMA wave owns 128 x 64 outputs
+// (4 x 2 MFMA tiles): per 16-deep k slice it reads 4 + 2 fragments for 8 MFMAs (0.75 KiB of LDS per MFMA instead of 1 KiB),
+// and a K-step stages 48 KiB for twice the MACs (24 KiB per 128 x 128 x 64 unit instead of 32).  The 128 x 128 kernel's K-step
+// time tracks its LDS traffic (64 KiB of fragment reads + 32 KiB of DMA writes per unit, ~1000 cycles against 512 of MFMA;
+// whole-K-step fragment prefetch (DEEP) changed nothing, tools/ingest_probe.hip shows the L2 path has 2x headroom) - this tile
+// moves 72 KiB per unit.  Used where the grid still fills the chip with 256-pixel tiles.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_igemm_ws256_kernel(const ConvG g) {
+  const ConvK& a = g.k;
+  constexpr int BM = 256, BN = 128;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int BK = 128 / ES;
+  constexpr int STAGES = 3;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int SLD = BN + 4;
+  constexpr int SMEM = (STAGES * STAGE > BM * SLD * 4) ? STAGES * STAGE : BM * SLD * 4;
+  typedef typename Mma<T>::Frag Frag;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM + 256];   // + the prefetch dummy
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wv >= 4;
+  const int w4 = wv & 3;
+  const int wm = w4 & 1, wn = w4 >> 1;
+  int wg;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = wg % a.ntn, mt = wg / a.ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int nk = a.Kpad / BK;
+  // diagnostic (glds_drop bit 5): shader-clock stamps of the first 48 K-steps of blocks 0..63 into the split-K slab:
+  // [block][ks][0..2] loader wave 4: tile landed, barrier passed, next tile issued; [3..4] MFMA wave 0: barrier passed, MFMAs issued
+  long long* stamps = ((g.probe & 32) && g.slab && blockIdx.x < 64 && lane == 0) ? (long long*)g.slab + (size_t)blockIdx.x * 48 * 8 : nullptr;
+  const long long t_base = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  // phase stamps in slot ks = 47: [0] K loop done (MFMA wave 0) [1] staging done [2] epilogue stores issued [3] stores complete
+  // [5] 100 MHz wall clock at kernel entry [6] wall clock at the end (x10 ns)
+  if (stamps && wv == 0) stamps[47 * 8 + 5] = (long long)__builtin_amdgcn_s_memrealtime();
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // residual rows of this thread's 8 epilogue iterations, requested beside the first tiles (see conv_igemm_ws_kernel)
+  const int c8 = tid & 15;
+  const int c = n0 + c8 * 8;
+  bf16x8 rpre[8];
+  if (a.res_mode != RES_NONE && !a.res_f32 && c < a.N) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int m = m0 + (tid >> 4) + it * 32;
+      if (m < a.M) {
+        const int b = m / a.OHW;
+        const int p = m - b * a.OHW;
+        rpre[it] = *(const bf16x8*)((const bf16*)a.res + (long long)b * a.r_bstride + (long long)p * a.ldr + c);
+      }
+    }
+  }
+  if (!loader) prefetch_share(a, blockIdx.x, gridDim.x, tid, 256, smem + SMEM);
+
+  if (loader) {
+    const int lrow = w4 * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((w4 * 4 + (lane >> 4)) & 7);
+    int a_off[8], a_iy0[8], a_ix0[8], b_off[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + i * 32 + lrow;
+      if (m < a.M) {
+        const int b = m / a.OHW;
+        const int r = m - b * a.OHW;
+        const int oy = r / a.OW;
+        const int ox = r - oy * a.OW;
+        a_iy0[i] = oy * a.stride - a.pad;
+        a_ix0[i] = ox * a.stride - a.pad;
+        a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)a_iy0[i] * a.W + a_ix0[i]) * a.ldx) * ES) + chunk * 16;
+      } else {
+        a_iy0[i] = -(1 << 28);
+        a_ix0[i] = -(1 << 28);
+        a_off[i] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b_off[i] = (n0 + i * 32 + lrow) * a.Kpad * ES + chunk * 16;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
+    int k0 = 0, kh = 0, kw = 0, c0 = 0;
+    auto issue = [&](int buf) {
+      char* sa = smem + buf * STAGE + w4 * 1024;
+      const int delta = ((kh * a.W + kw) * (int)a.ldx + c0) * ES;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+        const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const unsigned vo = ok ? (unsigned)(a_off[i] + delta) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 4096), 16, vo, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sa + BM * 128 + i * 4096), 16, (unsigned)(b_off[i] + k0 * ES), 0, 0, 0);
+      k0 += BK;
+      c0 += BK;
+      if (c0 >= a.Cin) {
+        c0 = 0;
+        if (++kw == a.KW) { kw = 0; ++kh; }
+      }
+    };
+    for (int t = 0; t < STAGES - 1 && t < nk; ++t) issue(t);
+    for (int ks = 0; ks < nk; ++ks) {
+      if (nk - 1 - ks >= 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // tile ks landed; tile ks+1 (12 DMAs) may stay in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (stamps && wv == 4 && ks < 48) stamps[ks * 8 + 0] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+      __builtin_amdgcn_s_barrier();
+      if (stamps && wv == 4 && ks < 48) stamps[ks * 8 + 1] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+      if (ks + STAGES - 1 < nk) issue((ks + STAGES - 1) % STAGES);
+      if (stamps && wv == 4 && ks < 48) stamps[ks * 8 + 2] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+    }
+  } else {
+    int foff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 128 + (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
+    for (int ks = 0; ks < nk; ++ks) {
+      if (stamps && wv == 0 && ks > 0 && ks <= 48) stamps[(ks - 1) * 8 + 4] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+      __builtin_amdgcn_s_barrier();
+      if (stamps && wv == 0 && ks < 48) stamps[ks * 8 + 3] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+      const char* sa = smem + (ks % STAGES) * STAGE + wm * 128 * 128;
+      const char* sb = smem + (ks % STAGES) * STAGE + (BM + wn * 64) * 128;
+      Frag xf[2][4], wf[2][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[0][j] = *(const Frag*)(sa + j * 4096 + foff[0]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wf[0][i] = *(const Frag*)(sb + i * 4096 + foff[0]);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xf[(kk + 1) & 1][j] = *(const Frag*)(sa + j * 4096 + foff[kk + 1]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) wf[(kk + 1) & 1][i] = *(const Frag*)(sb + i * 4096 + foff[kk + 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Mma<T>::run(wf[kk & 1][i], xf[kk & 1][j], acc[i][j]);
+      }
+    }
+  }
+  if (stamps && wv == 0) stamps[47 * 8 + 0] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+  __syncthreads();                                 // every MFMA operand read is done: smem becomes the fp32 staging tile
+
+  float* st = (float*)smem;
+  if (!loader) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pl = wm * 128 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          *(f32x4*)(&st[pl * SLD + wn * 64 + i * 32 + 8 * q + 4 * h]) = v;
+        }
+    }
+  }
+  __syncthreads();
+  if (stamps && wv == 0) stamps[47 * 8 + 1] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+  if (c < a.N) {
+    const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
+    dispatch_act(a.act, [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int pl = (tid >> 4) + it * 32;
+      const int m = m0 + pl;
+      if (m >= a.M) continue;
+      const f32x4 s0 = *(const f32x4*)(&st[pl * SLD + c8 * 8]), s1 = *(const f32x4*)(&st[pl * SLD + c8 * 8 + 4]);
+      float v[8] = {s0[0] + b0[0], s0[1] + b0[1], s0[2] + b0[2], s0[3] + b0[3],
+                    s1[0] + b1[0], s1[1] + b1[1], s1[2] + b1[2], s1[3] + b1[3]};
+      const int b = m / a.OHW;
+      const int p = m - b * a.OHW;
+      float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (a.res_mode != RES_NONE) {
+        if (a.res_f32) {
+          const long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
+          const f32x4 t0 = *(const f32x4*)((const float*)a.res + roff), t1 = *(const f32x4*)((const float*)a.res + roff + 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { rv[q] = t0[q]; rv[4 + q] = t1[q]; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) rv[q] = (float)rpre[it][q];
+        }
+      }
+      if (a.res_mode == RES_PRE) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = act_c<ACT>(v[q]);
+      if (a.res_mode == RES_POST) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+      }
+      const long long yoff = (long long)b * a.y_bstride + (long long)p * a.ldy + c;
+      if (a.y_f32) {
+        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        *(f32x4*)((float*)a.y + yoff) = o0;
+        *(f32x4*)((float*)a.y + yoff + 4) = o1;
+      } else {
+        bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+        *(bf16x8*)((bf16*)a.y + yoff) = o;
+      }
+    }
+    });
+  }
+  if (stamps && wv == 0) {
+    stamps[47 * 8 + 2] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamps[47 * 8 + 3] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+    stamps[47 * 8 + 6] = (long long)__builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -1055,6 +1317,8 @@ void conv_set_glds_min_blocks(int v) { g_glds_min_blocks = v; }
 void conv_set_glds_drop(int v) { g_glds_drop = v; }
 void conv_set_splitk(int v) { g_splitk_enable = v; }
 void conv_set_mode(int v) { g_conv_mode = v; g_force_v1 = (v == 1); }
+static int g_ws256_min_blocks = 0;   // auto dispatch: 256-pixel tiles from this many blocks on (0 = never); rtd_debug_option "ws256_min_blocks"
+void conv_set_ws256_min_blocks(int v) { g_ws256_min_blocks = v; }
 static int g_prefetch = 1;    // A/B hook (rtd_debug_option "prefetch"): 0 = no next-layer filter prefetch
 void conv_set_prefetch(int v) { g_prefetch = v; }
 template <typename T>
@@ -1072,6 +1336,14 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
   g.w_bytes = (g_glds_drop & 2) ? 0u : (unsigned)w_bytes;
   // grids that fill every CU twice run 2 blocks/CU with a 2-deep pipeline; smaller grids get the
   // whole LDS for one block and a 4-deep pipeline
+  {
+    const long long mt256 = (k.M + 255) / 256;
+    if (g_conv_mode == 7 || (g_conv_mode == 0 && g_ws256_min_blocks > 0 && mt256 * ntn >= g_ws256_min_blocks)) {
+      g.slab = ws.slab;
+      hipLaunchKernelGGL((conv_igemm_ws256_kernel<T>), dim3((unsigned)(mt256 * ntn)), dim3(512), 0, s, g);
+      return true;
+    }
+  }
   if (g_conv_mode == 3 || g_conv_mode == 4 || g_conv_mode == 6) {   // A/B: one wave-specialised variant everywhere (3 = 4 stages, 4 = 2 stages at 2 blocks/CU, 6 = DEEP)
     if (g_conv_mode == 3) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
     else if (g_conv_mode == 6) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, true>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);

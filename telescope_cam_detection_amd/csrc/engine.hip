@@ -1289,6 +1289,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "dec_split") == 0) { g_dec_split = value; return RTD_OK; }
   if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
   if (strcmp(name, "prefetch") == 0) { conv_set_prefetch(value); return RTD_OK; }
+  if (strcmp(name, "ws256_min_blocks") == 0) { conv_set_ws256_min_blocks(value); return RTD_OK; }
   if (strcmp(name, "profile_twice") == 0) { g_profile_twice = value; return RTD_OK; }
   if (strcmp(name, "bench_rewarm") == 0) { g_bench_rewarm = value; return RTD_OK; }
   if (strcmp(name, "splitk") == 0) { conv_set_splitk(value); return RTD_OK; }
@@ -1354,6 +1355,9 @@ int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, in
     a.w = w; a.bias = bias; a.KH = KH; a.KW = KH; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.Npad = Npad;
     a.act = 1; a.res_mode = with_res ? RES_PRE : RES_NONE;
     if (with_res) a.res = mk(r, dtype, B, OH, OW, Cout);
+    a.ws.slab_bytes = (size_t)64 * 48 * 8 * 8;
+    HIP_CHECK(hipMalloc((void**)&a.ws.slab, a.ws.slab_bytes));
+    HIP_CHECK(hipMemset(a.ws.slab, 0, a.ws.slab_bytes));
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) launch_conv(a, nullptr);
@@ -1390,7 +1394,21 @@ int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, in
       us_out[1] = tot * 1e3f / reps;
     }
     HIP_CHECK(hipDeviceSynchronize());
+    if (getenv("RTD_CONV_STAMPS")) {           // with rtd_debug_option("glds_drop", 32) + conv_mode 7: per-K-step stamps of blocks 0..63
+      std::vector<long long> st((size_t)64 * 48 * 8);
+      HIP_CHECK(hipMemcpy(st.data(), a.ws.slab, st.size() * 8, hipMemcpyDeviceToHost));
+      for (int blk : {0, 1, 17}) {
+        fprintf(stderr, "block %d: ks | landed  barrier issued | mfma: barrier done   (shader clocks from kernel start)\n", blk);
+        for (int ks = 0; ks < 20; ++ks) {
+          const long long* q = &st[((size_t)blk * 48 + ks) * 8];
+          fprintf(stderr, "  %2d | %7lld %7lld %7lld | %7lld %7lld\n", ks, q[0], q[1], q[2], q[3], q[4]);
+        }
+        const long long* z = &st[((size_t)blk * 48 + 47) * 8];
+        fprintf(stderr, "  K loop done %lld, staged %lld, stores issued %lld, stores complete %lld clocks; wall %lld x10ns\n", z[0], z[1], z[2], z[3], z[6] - z[5]);
+      }
+    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(a.ws.slab);
     (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(bias);
     if (r) (void)hipFree(r);
     if (flush) (void)hipFree(flush);

@@ -83,8 +83,8 @@ def test_conv(L, dt, case):
     _capi.debug_option("splitk", 1)        # exercise the in-launch split-K reduction on the small-grid shapes (default off: slower)
     # conv_mode 0 = auto (LDS-DMA kernel where eligible), 2 = register-staged large tile, 1 = small tiles only,
     # 3 / 4 = wave-specialised LDS-DMA kernel (4 / 2 stages), 5 = single-role LDS-DMA kernel, 6 = wave-specialised with
-    # whole-K-step fragment prefetch
-    for out_f32, mode in (((1, 0), (1, 1), (1, 2), (1, 3), (1, 6)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (1, 6))):
+    # whole-K-step fragment prefetch, 7 = wave-specialised 256-pixel tile
+    for out_f32, mode in (((1, 0), (1, 1), (1, 2), (1, 3), (1, 6), (1, 7)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (1, 6), (0, 7), (1, 7))):
         _capi.debug_option("conv_mode", mode)
         yd = torch.full((B, OH, OW, Cout), float("nan"), dtype=torch.float32 if out_f32 else tdt, device="cuda")
         ck(L, L.rtd_op_conv(code, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None,
