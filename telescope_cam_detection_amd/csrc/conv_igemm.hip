@@ -719,6 +719,71 @@ __global__ __launch_bounds__(256, (STAGES == 2 ? 2 : 1)) void conv_igemm_glds_ke
   }
 }
 
+// Copy-out of the wave-specialised kernels: staging tile (fp32, [rows][SLD]) -> bias (+ residual) -> activation -> y, 8 channels
+// (16 bytes of bf16) per thread and iteration, 32 rows apart.  The loop is instruction-bound (2 waves per SIMD walk it), so the
+// pixel -> (image, offset) division is done once and carried, and the activation is a template parameter.
+template <int ITERS, int ACT>
+__device__ __forceinline__ void ws_copy_out(const ConvK& a, const float* st, int SLD, int tid, int m0, int n0, const bf16x8* rpre) {
+  const int c8 = tid & 15;
+  const int c = n0 + c8 * 8;
+  if (c >= a.N) return;
+  const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
+  int m = m0 + (tid >> 4);
+  int b = m / a.OHW;
+  int p = m - b * a.OHW;
+  long long yoff = (long long)b * a.y_bstride + (long long)p * a.ldy + c;
+  long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
+  const float* srow = st + (tid >> 4) * SLD + c8 * 8;
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    if (m < a.M) {
+      const f32x4 s0 = *(const f32x4*)(srow), s1 = *(const f32x4*)(srow + 4);
+      float v[8] = {s0[0] + b0[0], s0[1] + b0[1], s0[2] + b0[2], s0[3] + b0[3],
+                    s1[0] + b1[0], s1[1] + b1[1], s1[2] + b1[2], s1[3] + b1[3]};
+      float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (a.res_mode != RES_NONE) {
+        if (a.res_f32) {
+          const f32x4 t0 = *(const f32x4*)((const float*)a.res + roff), t1 = *(const f32x4*)((const float*)a.res + roff + 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { rv[q] = t0[q]; rv[4 + q] = t1[q]; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) rv[q] = (float)rpre[it][q];
+        }
+      }
+      if (a.res_mode == RES_PRE) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = act_c<ACT>(v[q]);
+      if (a.res_mode == RES_POST) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+      }
+      if (a.y_f32) {
+        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        *(f32x4*)((float*)a.y + yoff) = o0;
+        *(f32x4*)((float*)a.y + yoff + 4) = o1;
+      } else {
+        bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+        *(bf16x8*)((bf16*)a.y + yoff) = o;
+      }
+    }
+    m += 32;
+    p += 32;
+    yoff += 32 * a.ldy;
+    roff += 32 * a.ldr;
+    srow += 32 * SLD;
+    while (p >= a.OHW) {                                        // next image (maps smaller than 32 pixels wrap more than once)
+      p -= a.OHW;
+      yoff += a.y_bstride - (long long)a.OHW * a.ldy;
+      roff += a.r_bstride - (long long)a.OHW * a.ldr;
+    }
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // v4: wave-specialised LDS-DMA kernel.  Same tile / swizzle / epilogue as v3, but 8 waves per block with
 // fixed roles: waves 0-3 only read fragments and issue MFMAs (one per SIMD, 64x64 outputs each), waves 4-7
@@ -784,14 +849,15 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
   const int c = n0 + c8 * 8;
   bf16x8 rpre[4];
   if (a.res_mode != RES_NONE && !a.res_f32 && c < a.N) {
+    int m = m0 + (tid >> 4);
+    const int b = m / a.OHW;
+    int p = m - b * a.OHW;
+    long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int m = m0 + (tid >> 4) + it * 32;
-      if (m < a.M) {
-        const int b = m / a.OHW;
-        const int p = m - b * a.OHW;
-        rpre[it] = *(const bf16x8*)((const bf16*)a.res + (long long)b * a.r_bstride + (long long)p * a.ldr + c);
-      }
+    for (int it = 0; it < 4; ++it) {                                // rows 32 apart: carry (image, pixel) instead of dividing again
+      if (m < a.M) rpre[it] = *(const bf16x8*)((const bf16*)a.res + roff);
+      m += 32; p += 32; roff += 32 * a.ldr;
+      while (p >= a.OHW) { p -= a.OHW; roff += a.r_bstride - (long long)a.OHW * a.ldr; }
     }
   }
   if (!loader) prefetch_share(a, blockIdx.x, gridDim.x, tid, 256, smem + SMEM);   // next layer's filter; the MFMA waves idle until tile 0 lands
@@ -1019,54 +1085,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
     }
   }
   __syncthreads();
-  if (c < a.N) {
-    const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
-    dispatch_act(a.act, [&](auto actc) {
-    constexpr int ACT = decltype(actc)::value;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int pl = (tid >> 4) + it * 32;
-      const int m = m0 + pl;
-      if (m >= a.M) continue;
-      const f32x4 s0 = *(const f32x4*)(&st[pl * SLD + c8 * 8]), s1 = *(const f32x4*)(&st[pl * SLD + c8 * 8 + 4]);
-      float v[8] = {s0[0] + b0[0], s0[1] + b0[1], s0[2] + b0[2], s0[3] + b0[3],
-                    s1[0] + b1[0], s1[1] + b1[1], s1[2] + b1[2], s1[3] + b1[3]};
-      const int b = m / a.OHW;
-      const int p = m - b * a.OHW;
-      float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (a.res_mode != RES_NONE) {
-        if (a.res_f32) {
-          const long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
-          const f32x4 t0 = *(const f32x4*)((const float*)a.res + roff), t1 = *(const f32x4*)((const float*)a.res + roff + 4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { rv[q] = t0[q]; rv[4 + q] = t1[q]; }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) rv[q] = (float)rpre[it][q];
-        }
-      }
-      if (a.res_mode == RES_PRE) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += rv[q];
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = act_c<ACT>(v[q]);
-      if (a.res_mode == RES_POST) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += rv[q];
-      }
-      const long long yoff = (long long)b * a.y_bstride + (long long)p * a.ldy + c;
-      if (a.y_f32) {
-        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-        *(f32x4*)((float*)a.y + yoff) = o0;
-        *(f32x4*)((float*)a.y + yoff + 4) = o1;
-      } else {
-        bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-        *(bf16x8*)((bf16*)a.y + yoff) = o;
-      }
-    }
-    });
-  }
+  dispatch_act(a.act, [&](auto actc) { ws_copy_out<4, decltype(actc)::value>(a, st, SLD, tid, m0, n0, rpre); });
 }
 
 
@@ -1127,14 +1146,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws256_kernel(const ConvG g)
   const int c = n0 + c8 * 8;
   bf16x8 rpre[8];
   if (a.res_mode != RES_NONE && !a.res_f32 && c < a.N) {
+    int m = m0 + (tid >> 4);
+    const int b = m / a.OHW;
+    int p = m - b * a.OHW;
+    long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int m = m0 + (tid >> 4) + it * 32;
-      if (m < a.M) {
-        const int b = m / a.OHW;
-        const int p = m - b * a.OHW;
-        rpre[it] = *(const bf16x8*)((const bf16*)a.res + (long long)b * a.r_bstride + (long long)p * a.ldr + c);
-      }
+    for (int it = 0; it < 8; ++it) {                                // rows 32 apart: carry (image, pixel) instead of dividing again
+      if (m < a.M) rpre[it] = *(const bf16x8*)((const bf16*)a.res + roff);
+      m += 32; p += 32; roff += 32 * a.ldr;
+      while (p >= a.OHW) { p -= a.OHW; roff += a.r_bstride - (long long)a.OHW * a.ldr; }
     }
   }
   if (!loader) prefetch_share(a, blockIdx.x, gridDim.x, tid, 256, smem + SMEM);
@@ -1245,54 +1265,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws256_kernel(const ConvG g)
   }
   __syncthreads();
   if (stamps && wv == 0) stamps[47 * 8 + 1] = (long long)__builtin_amdgcn_s_memtime() - t_base;
-  if (c < a.N) {
-    const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
-    dispatch_act(a.act, [&](auto actc) {
-    constexpr int ACT = decltype(actc)::value;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int pl = (tid >> 4) + it * 32;
-      const int m = m0 + pl;
-      if (m >= a.M) continue;
-      const f32x4 s0 = *(const f32x4*)(&st[pl * SLD + c8 * 8]), s1 = *(const f32x4*)(&st[pl * SLD + c8 * 8 + 4]);
-      float v[8] = {s0[0] + b0[0], s0[1] + b0[1], s0[2] + b0[2], s0[3] + b0[3],
-                    s1[0] + b1[0], s1[1] + b1[1], s1[2] + b1[2], s1[3] + b1[3]};
-      const int b = m / a.OHW;
-      const int p = m - b * a.OHW;
-      float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (a.res_mode != RES_NONE) {
-        if (a.res_f32) {
-          const long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
-          const f32x4 t0 = *(const f32x4*)((const float*)a.res + roff), t1 = *(const f32x4*)((const float*)a.res + roff + 4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { rv[q] = t0[q]; rv[4 + q] = t1[q]; }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) rv[q] = (float)rpre[it][q];
-        }
-      }
-      if (a.res_mode == RES_PRE) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += rv[q];
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = act_c<ACT>(v[q]);
-      if (a.res_mode == RES_POST) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += rv[q];
-      }
-      const long long yoff = (long long)b * a.y_bstride + (long long)p * a.ldy + c;
-      if (a.y_f32) {
-        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-        *(f32x4*)((float*)a.y + yoff) = o0;
-        *(f32x4*)((float*)a.y + yoff + 4) = o1;
-      } else {
-        bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-        *(bf16x8*)((bf16*)a.y + yoff) = o;
-      }
-    }
-    });
-  }
+  dispatch_act(a.act, [&](auto actc) { ws_copy_out<8, decltype(actc)::value>(a, st, SLD, tid, m0, n0, rpre); });
   if (stamps && wv == 0) {
     stamps[47 * 8 + 2] = (long long)__builtin_amdgcn_s_memtime() - t_base;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
