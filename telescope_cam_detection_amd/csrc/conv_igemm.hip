@@ -1347,6 +1347,144 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Direct 3x3 / stride 1 / pad 1 convolution for the narrow, very wide-grid layers (Cin, Cout in {32, 64}: stem.1, stem.2 and
+// the stage-0 c2 convs at 320^2 / 160^2 pixels).  The implicit-GEMM kernels stage every input pixel 9 times (once per tap)
+// and are neither MFMA- nor HBM-bound there (200-350 TF/s, 1.1-1.9 TB/s).  Here
+//   * a block owns an 8 x 32 pixel output tile; its (8+2) x (32+2) pixel input patch is staged ONCE by LDS-DMA (zero padding
+//     = out-of-range buffer offset), 64- or 128-byte pixel rows with a source-side XOR swizzle so that the 32 consecutive
+//     pixels of an MFMA operand read conflict-free;
+//   * each wave keeps the WHOLE filter of its 32 TN output channels in registers (9 taps x CIN/16 fragments x TN: 72 or 144
+//     VGPRs), loaded once per persistent block; the only LDS traffic of the MFMA loop is one 16-byte pixel fragment per TN MFMAs;
+//   * blocks are persistent (block-cyclic over tiles) and two of them share a CU: one block's patch DMA runs under the
+//     other's MFMAs;
+//   * bias + activation in registers, bf16 rows through a wave-private LDS slab, 16-byte stores along NHWC's channels.
+// Cin = 64 filters do not fit one wave's registers for 64 output channels: gridDim.y splits the channels into 32-wide groups.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int TN>
+__global__ __launch_bounds__(256, 2) void conv3x3_reg_kernel(const ConvK a, unsigned x_bytes, int tiles_x, int tiles_y, int ntiles) {
+  constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2, NPIX = PW * PH;
+  constexpr int ROWB = CIN * 2;                   // bytes per patch pixel
+  constexpr int CPP = CIN / 8;                    // 16-byte chunks per pixel
+  constexpr int PPI = 1024 / ROWB;                // pixels per LDS-DMA wave instruction
+  constexpr int NINSTR = (NPIX + PPI - 1) / PPI;
+  constexpr int KC = CIN / 16;                    // 16-deep k slices per tap
+  constexpr int ROWO = 64 * TN + 16;              // staging row: 32 TN bf16 channels + 16 bytes (bank skew)
+  __shared__ __attribute__((aligned(16))) char patch[NINSTR * 1024];
+  __shared__ __attribute__((aligned(16))) char stage[4][32 * ROWO];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nbase = blockIdx.y * 32 * TN;
+  const int h = lane >> 5;
+
+  bf16x8 wf[9][KC][TN];
+  {
+    const bf16* wg = (const bf16*)a.w;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          wf[tap][kc][tn] = *(const bf16x8*)(wg + (size_t)(nbase + 32 * tn + (lane & 31)) * a.Kpad + tap * CIN + kc * 16 + 8 * h);
+  }
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
+  auto swz = [](int pi) { return CPP == 8 ? ((pi >> 1) & 7) : ((pi >> 2) & 3); };
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tx = tile % tiles_x;
+    const int t2 = tile / tiles_x;
+    const int ty = t2 % tiles_y;
+    const int b = t2 / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    __syncthreads();                                               // the previous tile's patch reads are done
+    for (int j = wv; j < NINSTR; j += 4) {
+      const int pi = j * PPI + lane / CPP;
+      const int py = pi / PW, px = pi - py * PW;
+      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+      const bool ok = pi < NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const int src_chunk = (lane % CPP) ^ swz(pi);
+      const unsigned vo = ok ? (unsigned)(((long long)b * a.x_bstride + ((long long)iy * a.W + ix) * a.ldx) * 2 + src_chunk * 16) : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(patch + j * 1024), 16, vo, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = wv * 2 + rr;
+      f32x16 acc[TN];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[tn][e] = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int pi = (r + kh) * PW + kw + (lane & 31);
+          const int sw = swz(pi);
+          const char* prow = patch + pi * ROWB;
+#pragma unroll
+          for (int kc = 0; kc < KC; ++kc) {
+            const bf16x8 xf = *(const bf16x8*)(prow + (((2 * kc + h) ^ sw) << 4));
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kh * 3 + kw][kc][tn], xf, acc[tn], 0, 0, 0);
+          }
+        }
+      // ---- epilogue of this 32-pixel row: lane = pixel (lane & 31), channels 32 tn + 8 q + 4 h + (0..3) ----
+      const int oy = y0 + r;
+      char* sw_ = stage[wv];
+      dispatch_act(a.act, [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *(const f32x4*)(a.bias + nbase + 32 * tn + 8 * q + 4 * h);   // L1-resident; registers are for the filter
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)act_c<ACT>(acc[tn][4 * q + e] + bv[e]);
+            *(bf16x4*)(sw_ + (lane & 31) * ROWO + (32 * tn + 8 * q + 4 * h) * 2) = o;
+          }
+      });
+      __builtin_amdgcn_wave_barrier();
+      if (oy < a.H) {
+        bf16* yrow = (bf16*)a.y + (long long)b * a.y_bstride + ((long long)oy * a.W + x0) * a.ldy + nbase;
+#pragma unroll
+        for (int it = 0; it < 2 * TN; ++it) {
+          const int idx = it * 64 + lane;
+          const int p = idx / (4 * TN), ch = idx - p * (4 * TN);
+          if (x0 + p < a.W) *(bf16x8*)(yrow + (long long)p * a.ldy + ch * 8) = *(const bf16x8*)(sw_ + p * ROWO + ch * 16);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();                              // the slab is rewritten by the next row
+    }
+  }
+}
+
+static int g_conv_reg = 1;    // A/B hook (rtd_debug_option "conv_reg"): 0 = narrow 3x3 layers stay on the implicit-GEMM kernels
+void conv_set_reg(int v) { g_conv_reg = v; }
+
+// returns true when the launch was taken by the direct kernel
+static bool dispatch_reg(const ConvK& k, const ConvArgs& a, long long x_bytes, hipStream_t s) {
+  if (!g_conv_reg || g_force_v1 || g_conv_mode != 0) return false;
+  const Tensor& x = a.x;
+  const Tensor& y = a.y;
+  if (x.dt != BF16 || y.dt != BF16 || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.res_mode != RES_NONE) return false;
+  if (!((x.c == 32 || x.c == 64) && (y.c == 32 || y.c == 64)) || x.ld % 8 || y.ld % 8 || ((uintptr_t)y.p & 15) || x_bytes >= (1ll << 31)) return false;
+  const int tiles_x = (x.w + 31) / 32, tiles_y = (x.h + 7) / 8;
+  const long long ntiles = (long long)x.n * tiles_x * tiles_y;
+  if (ntiles < 256 || ntiles >= (1ll << 30)) return false;        // small maps: the implicit-GEMM tiles fill the chip better
+  const unsigned gx = (unsigned)std::min<long long>(ntiles, 512);
+  if (x.c == 32 && y.c == 32) hipLaunchKernelGGL((conv3x3_reg_kernel<32, 1>), dim3(gx, 1), dim3(256), 0, s, k, (unsigned)x_bytes, tiles_x, tiles_y, (int)ntiles);
+  else if (x.c == 32) hipLaunchKernelGGL((conv3x3_reg_kernel<32, 2>), dim3(gx, 1), dim3(256), 0, s, k, (unsigned)x_bytes, tiles_x, tiles_y, (int)ntiles);
+  else hipLaunchKernelGGL((conv3x3_reg_kernel<64, 1>), dim3(gx, (unsigned)(y.c / 32)), dim3(256), 0, s, k, (unsigned)x_bytes, tiles_x, tiles_y, (int)ntiles);
+  return true;
+}
+
 template <typename T>
 static bool dispatch_v2(const ConvK& k, bool v2_ok, hipStream_t s) {
   if (!v2_ok || g_force_v1) return false;
@@ -1436,8 +1574,11 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     const long long es = (long long)dtype_size(x.dt);
     const long long x_bytes = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * es;
     const long long w_bytes = (long long)a.Npad * a.Kpad * es;
-    if (x.dt == BF16) done = dispatch_glds<bf16>(k, v2_ok, x_bytes, w_bytes, a.ws, s);
-    else done = dispatch_glds<float>(k, v2_ok, x_bytes, w_bytes, a.ws, s);
+    done = dispatch_reg(k, a, x_bytes, s);
+    if (!done) {
+      if (x.dt == BF16) done = dispatch_glds<bf16>(k, v2_ok, x_bytes, w_bytes, a.ws, s);
+      else done = dispatch_glds<float>(k, v2_ok, x_bytes, w_bytes, a.ws, s);
+    }
   }
   if (!done) {
     if (x.dt == BF16) done = dispatch_v2<bf16>(k, v2_ok, s);

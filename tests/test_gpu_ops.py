@@ -49,6 +49,11 @@ CONV_CASES = [
     (1, 26000, 1, 256, 288, 1, 1, 0, "none", 0),   # v2 token GEMM, N = 288
     (2, 96, 96, 512, 64, 1, 1, 0, "gelu", 0),      # v2 BN=64, K = 512
     (1, 67200, 1, 256, 80, 1, 1, 0, "none", 0),    # enc_score_head shape: fp32 takes the LDS-DMA kernel with a partial N tile
+    # narrow 3x3 layers on wide grids: the direct (filter-in-registers) kernel in bf16; ragged tiles in both directions
+    (4, 60, 264, 32, 32, 3, 1, 1, "relu", 0),      # stem.1 shape family
+    (4, 60, 264, 32, 64, 3, 1, 1, "silu", 0),      # stem.2
+    (4, 68, 232, 64, 64, 3, 1, 1, "relu", 0),      # stage-0 c2 (two 32-channel groups)
+    (2, 160, 160, 64, 64, 3, 1, 1, "none", 0),     # exact tiles
 ]
 
 
