@@ -1361,79 +1361,121 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
 //   * bias + activation in registers, bf16 rows through a wave-private LDS slab, 16-byte stores along NHWC's channels.
 // Cin = 64 filters do not fit one wave's registers for 64 output channels: gridDim.y splits the channels into 32-wide groups.
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int TN>
-__global__ __launch_bounds__(256, 2) void conv3x3_reg_kernel(const ConvK a, unsigned x_bytes, int tiles_x, int tiles_y, int ntiles) {
+typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+template <int CIN, int TN, int GROUPS>
+__global__ __launch_bounds__(256 * GROUPS, 2) void conv3x3_reg_kernel(const ConvK a, unsigned x_bytes, unsigned y_bytes, int tiles_x, int tiles_y, int ntiles) {
+  // GROUPS = 32 TN-channel groups handled inside the block by different wave quartets (Cin = 64: the 64 output channels need
+  // two register-resident filters; both quartets read the same staged patch)
+  constexpr int NW = 4 * GROUPS, NT_ = 64 * NW;
   constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2, NPIX = PW * PH;
   constexpr int ROWB = CIN * 2;                   // bytes per patch pixel
   constexpr int CPP = CIN / 8;                    // 16-byte chunks per pixel
   constexpr int PPI = 1024 / ROWB;                // pixels per LDS-DMA wave instruction
   constexpr int NINSTR = (NPIX + PPI - 1) / PPI;
+  constexpr int PBUF = NINSTR * 1024;             // one patch buffer
   constexpr int KC = CIN / 16;                    // 16-deep k slices per tap
   constexpr int ROWO = 64 * TN + 16;              // staging row: 32 TN bf16 channels + 16 bytes (bank skew)
-  __shared__ __attribute__((aligned(16))) char patch[NINSTR * 1024];
-  __shared__ __attribute__((aligned(16))) char stage[4][32 * ROWO];
+  constexpr int WROW = 9 * CIN * 2 + 16;          // filter row in LDS (one-time fragment fill): +16 bytes = conflict-free ds_read_b128
+  static_assert(32 * TN * GROUPS * WROW <= 2 * PBUF, "the filter is staged through the two patch buffers");
+  __shared__ __attribute__((aligned(16))) char patch[2 * PBUF];     // double buffered: tile i+1 lands while tile i is computed
+  __shared__ __attribute__((aligned(16))) char stage[NW][32 * ROWO];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nbase = blockIdx.y * 32 * TN;
+  const int grp = wv >> 2, wq = wv & 3;
+  const int nbase = grp * 32 * TN;
   const int h = lane >> 5;
 
   bf16x8 wf[9][KC][TN];
   {
+    // filter rows -> LDS with coalesced 16-byte loads (a fragment load straight from global touches 64 different 1 KiB-apart
+    // rows per instruction: 8x over-fetch, 1.2 MB of L2 traffic per block), then every wave fills its fragment registers
     const bf16* wg = (const bf16*)a.w;
+    constexpr int CPR = 9 * CIN / 8;              // 16-byte chunks per filter row
+    for (int e = tid; e < 32 * TN * GROUPS * CPR; e += NT_) {
+      const int row = e / CPR, ch = e - row * CPR;
+      *(bf16x8*)(patch + row * WROW + ch * 16) = *(const bf16x8*)(wg + (size_t)row * a.Kpad + ch * 8);
+    }
+    __syncthreads();
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
-          wf[tap][kc][tn] = *(const bf16x8*)(wg + (size_t)(nbase + 32 * tn + (lane & 31)) * a.Kpad + tap * CIN + kc * 16 + 8 * h);
+          wf[tap][kc][tn] = *(const bf16x8*)(patch + (nbase + 32 * tn + (lane & 31)) * WROW + (tap * CIN + kc * 16 + 8 * h) * 2);
+    __syncthreads();                                               // the fragments are in registers: the buffers become patches
   }
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
   auto swz = [](int pi) { return CPP == 8 ? ((pi >> 1) & 7) : ((pi >> 2) & 3); };
-
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  auto issue_patch = [&](int tile, int buf) {
     const int tx = tile % tiles_x;
     const int t2 = tile / tiles_x;
     const int ty = t2 % tiles_y;
     const int b = t2 / tiles_y;
     const int x0 = tx * TW, y0 = ty * TH;
-    __syncthreads();                                               // the previous tile's patch reads are done
-    for (int j = wv; j < NINSTR; j += 4) {
+    for (int j = wv; j < NINSTR; j += NW) {
       const int pi = j * PPI + lane / CPP;
       const int py = pi / PW, px = pi - py * PW;
       const int iy = y0 - 1 + py, ix = x0 - 1 + px;
       const bool ok = pi < NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
       const int src_chunk = (lane % CPP) ^ swz(pi);
       const unsigned vo = ok ? (unsigned)(((long long)b * a.x_bstride + ((long long)iy * a.W + ix) * a.ldx) * 2 + src_chunk * 16) : 0x80000000u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(patch + j * 1024), 16, vo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(patch + buf * PBUF + j * 1024), 16, vo, 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) issue_patch(tile, 0);
+  for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+    const int buf = it & 1;
+    // this wave's share of the tile landed.  The 4 TN stores of the previous tile were issued AFTER this tile's DMA and may
+    // stay in flight (every row issues exactly 2 TN buffer stores - rows / pixels outside the image store to an out-of-range
+    // offset, which the hardware drops - so the count is exact); waiting for their acknowledgement cost ~3 us per tile
+    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (TN == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __syncthreads();                                               // ... everybody's; the other buffer's readers are done
+    if (tile + (int)gridDim.x < ntiles) issue_patch(tile + gridDim.x, buf ^ 1);
+    const int tx = tile % tiles_x;
+    const int t2 = tile / tiles_x;
+    const int ty = t2 % tiles_y;
+    const int b = t2 / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const char* pbuf = patch + buf * PBUF;
 
 #pragma unroll 1
     for (int rr = 0; rr < 2; ++rr) {
-      const int r = wv * 2 + rr;
+      const int r = wq * 2 + rr;
       f32x16 acc[TN];
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[tn][e] = 0.f;
+      // pixel fragments of tap t+1 are read while the MFMAs of tap t issue (pinned: left alone, hipcc reads each fragment
+      // right before its MFMA - the register file is full of filter - and every MFMA waits out an LDS round trip)
+      bf16x8 xf[2][KC];
+      auto read_tap = [&](bf16x8 (&dst)[KC], int tap) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int pi = (r + kh) * PW + kw + (lane & 31);
+        const int sw = swz(pi);
+        const char* prow = pbuf + pi * ROWB;
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+        for (int kc = 0; kc < KC; ++kc) dst[kc] = *(const bf16x8*)(prow + (((2 * kc + h) ^ sw) << 4));
+      };
+      read_tap(xf[0], 0);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int pi = (r + kh) * PW + kw + (lane & 31);
-          const int sw = swz(pi);
-          const char* prow = patch + pi * ROWB;
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) read_tap(xf[(tap + 1) & 1], tap + 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int kc = 0; kc < KC; ++kc) {
-            const bf16x8 xf = *(const bf16x8*)(prow + (((2 * kc + h) ^ sw) << 4));
+        for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kh * 3 + kw][kc][tn], xf, acc[tn], 0, 0, 0);
-          }
-        }
+          for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][kc][tn], xf[tap & 1][kc], acc[tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // ---- epilogue of this 32-pixel row: lane = pixel (lane & 31), channels 32 tn + 8 q + 4 h + (0..3) ----
       const int oy = y0 + r;
       char* sw_ = stage[wv];
@@ -1451,13 +1493,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_reg_kernel(const ConvK a, unsi
           }
       });
       __builtin_amdgcn_wave_barrier();
-      if (oy < a.H) {
-        bf16* yrow = (bf16*)a.y + (long long)b * a.y_bstride + ((long long)oy * a.W + x0) * a.ldy + nbase;
+      {
+        const long long yrow = (long long)b * a.y_bstride + ((long long)oy * a.W + x0) * a.ldy + nbase;
 #pragma unroll
-        for (int it = 0; it < 2 * TN; ++it) {
-          const int idx = it * 64 + lane;
+        for (int i2 = 0; i2 < 2 * TN; ++i2) {
+          const int idx = i2 * 64 + lane;
           const int p = idx / (4 * TN), ch = idx - p * (4 * TN);
-          if (x0 + p < a.W) *(bf16x8*)(yrow + (long long)p * a.ldy + ch * 8) = *(const bf16x8*)(sw_ + p * ROWO + ch * 16);
+          const bool ok = oy < a.H && x0 + p < a.W;
+          const unsigned vo = ok ? (unsigned)((yrow + (long long)p * a.ldy + ch * 8) * 2) : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_*)(sw_ + p * ROWO + ch * 16), ry, vo, 0, 0);
         }
       }
       __builtin_amdgcn_wave_barrier();                              // the slab is rewritten by the next row
@@ -1474,14 +1518,18 @@ static bool dispatch_reg(const ConvK& k, const ConvArgs& a, long long x_bytes, h
   const Tensor& x = a.x;
   const Tensor& y = a.y;
   if (x.dt != BF16 || y.dt != BF16 || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.res_mode != RES_NONE) return false;
-  if (!((x.c == 32 || x.c == 64) && (y.c == 32 || y.c == 64)) || x.ld % 8 || y.ld % 8 || ((uintptr_t)y.p & 15) || x_bytes >= (1ll << 31)) return false;
+  if (!((x.c == 32 && (y.c == 32 || y.c == 64)) || (x.c == 64 && y.c == 64)) || x.ld % 8 || y.ld % 8 || ((uintptr_t)y.p & 15) || x_bytes >= (1ll << 31)) return false;
+  const long long y_bytes = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * 2;
+  if (y_bytes >= (1ll << 31)) return false;
   const int tiles_x = (x.w + 31) / 32, tiles_y = (x.h + 7) / 8;
   const long long ntiles = (long long)x.n * tiles_x * tiles_y;
   if (ntiles < 256 || ntiles >= (1ll << 30)) return false;        // small maps: the implicit-GEMM tiles fill the chip better
-  const unsigned gx = (unsigned)std::min<long long>(ntiles, 512);
-  if (x.c == 32 && y.c == 32) hipLaunchKernelGGL((conv3x3_reg_kernel<32, 1>), dim3(gx, 1), dim3(256), 0, s, k, (unsigned)x_bytes, tiles_x, tiles_y, (int)ntiles);
-  else if (x.c == 32) hipLaunchKernelGGL((conv3x3_reg_kernel<32, 2>), dim3(gx, 1), dim3(256), 0, s, k, (unsigned)x_bytes, tiles_x, tiles_y, (int)ntiles);
-  else hipLaunchKernelGGL((conv3x3_reg_kernel<64, 1>), dim3(gx, (unsigned)(y.c / 32)), dim3(256), 0, s, k, (unsigned)x_bytes, tiles_x, tiles_y, (int)ntiles);
+  // persistent blocks, two per CU (LDS: 2 patch buffers + the store slabs)
+  const unsigned gx = (unsigned)std::min<long long>(ntiles, x.c == 64 ? 256 : 512);
+  if (x.c == 32 && y.c == 32) hipLaunchKernelGGL((conv3x3_reg_kernel<32, 1, 1>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles);
+  else if (x.c == 32) hipLaunchKernelGGL((conv3x3_reg_kernel<32, 2, 1>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles);
+  else if (y.c == 64) hipLaunchKernelGGL((conv3x3_reg_kernel<64, 1, 2>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles);
+  else return false;
   return true;
 }
 
