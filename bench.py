@@ -11,6 +11,11 @@ preprocess -> network -> post-process on the device (the fixed [8,300,6] result 
 N > 1: one process per GPU, cameras sharded over ranks (weak scaling), and one RCCL all-gather of
 every rank's result block per step - the collate step for rank 0's web server.
 
+--streams S (default 2): S engine handles per GPU, each with its own HIP stream, hipGraph and camera group, take the K
+timed steps round-robin, so S batches are in flight - the reference's deployment shape (one inference engine per camera
+group sharing the GPU, main.py:1236-1291).  Every step is still one full bs-8 pass; the kernels of one batch fill the CUs
+the other batch's small grids and launch ramps leave idle.  `single_stream` in the JSON is the same measurement with S = 1.
+
 Prints ONE JSON line on rank 0 with the contract fields plus:
   roofline     - MFMA roofline of the dominant kernel family (conv_igemm), from HIP-event timings of
                  every launch on the engine's stream (rtd_profile) and the algorithmic FLOPs per launch
@@ -49,6 +54,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--streams", type=int, default=2, help="engine handles (batches in flight) per GPU")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
@@ -81,44 +87,54 @@ def main():
     w = synth_weights(arch, 0)
     blob = pack_blob(fold_weights(arch, w))
     prec = _capi.PREC_FP32 if args.precision == "fp32" else _capi.PREC_BF16
-    eng = _capi.Engine(arch, blob, device=local_rank, precision=prec, max_batch=B, input_size=(H, H),
-                       use_graph=not args.no_graph)
+    S = max(1, args.streams)
+    engs = [_capi.Engine(arch, blob, device=local_rank, precision=prec, max_batch=B, input_size=(H, H), use_graph=not args.no_graph)
+            for _ in range(S)]
+    eng = engs[0]
     # frame i of config c = default_rng(1000*c+i).integers(0,255,(H,W,3),uint8); camera k -> rank k
-    frames = [torch.from_numpy(noise_frame(2000 + rank * B + i, H, H)).cuda() for i in range(B)]
-    prepared = eng.make_async_args(frames)
+    frames_of = [[torch.from_numpy(noise_frame(2000 + (rank * S + si) * B + i, H, H)).cuda() for i in range(B)] for si in range(S)]
+    frames = frames_of[0]
+    prepared = [e.make_async_args(f) for e, f in zip(engs, frames_of)]
     Q = arch.num_queries
 
-    stream = torch.cuda.ExternalStream(eng.stream(), device=torch.device("cuda", local_rank))
+    streams = [torch.cuda.ExternalStream(e.stream(), device=torch.device("cuda", local_rank)) for e in engs]
     gathered = None
     if world > 1:
-        gathered = torch.empty(world * B * Q * 6, dtype=torch.float32, device="cuda")
+        gathered = [torch.empty(world * B * Q * 6, dtype=torch.float32, device="cuda") for _ in range(S)]
 
-    def step():
-        eng.infer_async_prepared(prepared)
+    def step(k, n_handles):
+        si = k % n_handles
+        engs[si].infer_async_prepared(prepared[si])
         if world > 1:
-            ptr, n = eng.result_block()
+            ptr, n = engs[si].result_block()
             block = torch.as_tensor(_DevPtr(ptr, n), device=f"cuda:{local_rank}")
-            with torch.cuda.stream(stream):                   # ordered after the forward on the engine's stream
-                collate_blocks(block, out=gathered)
+            with torch.cuda.stream(streams[si]):              # ordered after the forward on that engine's stream
+                collate_blocks(block, out=gathered[si])
 
     def fence():
-        eng.sync()
+        for e in engs:
+            e.sync()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(n_handles):
+        for k in range(args.warmup):
+            step(k, n_handles)
+        fence()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k, n_handles)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    single = timed(1) if S > 1 else None
+    elapsed = timed(S)
     fps = world * B * args.steps / elapsed
     out = {
         "metric": "frames_per_sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -127,8 +143,12 @@ def main():
         "config": {"workload": f"RT-DETR-{args.arch.upper()} {H}x{H} bs={B}/GPU, uint8 BGR frames resident in HBM -> "
                                f"[{B},{Q},6] detections in HBM; synthetic seeded weights",
                    "global_batch": world * B, "parallelism": f"camera-shard x{world}" + (" + RCCL all_gather of detections" if world > 1 else ""),
-                   "hip_graph": not args.no_graph},
+                   "streams_per_gpu": S, "batches_in_flight_per_gpu": S, "hip_graph": not args.no_graph},
     }
+    if single is not None:
+        out["single_stream"] = {"value": round(world * B * args.steps / single, 2), "unit": "frames/s",
+                                "ms_per_step": round(1000.0 * single / args.steps, 4),
+                                "note": "same K steps on ONE handle (one batch in flight); ms_per_step here is the latency of a bs-8 step"}
     if args.arch in CANON_GFLOP_PER_FRAME and H == 640:
         out["mfma_frac_whole_model"] = round(CANON_GFLOP_PER_FRAME[args.arch] * fps / world / (MFMA_PEAK_TFLOPS[args.precision] * 1e3), 4)
 
@@ -152,7 +172,7 @@ def main():
             "alg_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
             "alg_gbytes_per_s_unfused": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
             "share_of_step": round(d["ms"] / total_ms, 3),
-            "method": "rtd_profile: hipEvent pairs around every launch of one eager forward on the engine stream, mean of 5",
+            "method": "rtd_profile: hipEvent pairs around every launch of one eager forward on ONE engine stream (no second batch in flight), mean of 5",
         }
         # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
         # same command; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md) - counters cannot be read live
@@ -203,7 +223,8 @@ def main():
                                    "sample": f"CPU oracle (fp32 eager PyTorch restatement of the reference path), RT-DETR-{args.arch.upper()} "
                                              f"{H}x{H} bs={nb}, {reps} timed batches after 1 warm-up, torch threads={cores}"}
         print(json.dumps(out), flush=True)
-    eng.close()
+    for e in engs:
+        e.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
