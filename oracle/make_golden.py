@@ -58,85 +58,7 @@ CASES = {
 }
 
 
-def hf_key_map(arch):
-    """this build's un-fused tensor name -> HF state-dict key."""
-    convs, lins, lns = module_specs(arch)
-    m = {}
-
-    def conv(mine, hf_conv, hf_bn):
-        m[mine + ".conv.w"] = hf_conv + ".weight"
-        for s, h in zip("gbmv", ("weight", "bias", "running_mean", "running_var")):
-            m[mine + ".bn." + s] = hf_bn + "." + h
-
-    def lin(mine, hf):
-        m[mine + ".w"] = hf + ".weight"
-        m[mine + ".b"] = hf + ".bias"
-
-    def ln(mine, hf):
-        m[mine + ".g"] = hf + ".weight"
-        m[mine + ".b"] = hf + ".bias"
-
-    bb = "model.backbone.model."
-    for i in range(3):
-        conv(f"backbone.stem.{i}", f"{bb}embedder.embedder.{i}.convolution", f"{bb}embedder.embedder.{i}.normalization")
-    for pfx, cin, cout, stride, first in backbone_blocks(arch):
-        _, s, b = pfx.split(".")
-        base = f"{bb}encoder.stages.{s[1:]}.layers.{b[1:]}"
-        n = 3 if arch.layer_type == "bottleneck" else 2
-        for j in range(n):
-            conv(f"{pfx}.c{j + 1}", f"{base}.layer.{j}.convolution", f"{base}.layer.{j}.normalization")
-        if block_has_shortcut(arch, cin, cout, stride, first):
-            sc = f"{base}.shortcut.1" if stride == 2 else f"{base}.shortcut"
-            conv(pfx + ".sc", sc + ".convolution", sc + ".normalization")
-    for l in range(3):
-        conv(f"enc.proj.{l}", f"model.encoder_input_proj.{l}.0", f"model.encoder_input_proj.{l}.1")
-        conv(f"dec.proj.{l}", f"model.decoder_input_proj.{l}.0", f"model.decoder_input_proj.{l}.1")
-    a = "model.encoder.aifi.0.layers.0."
-    for n in "qkvo":
-        lin(f"enc.aifi.{n}", f"{a}self_attn.{n}_proj")
-    ln("enc.aifi.ln1", a + "self_attn_layer_norm")
-    lin("enc.aifi.fc1", a + "mlp.fc1")
-    lin("enc.aifi.fc2", a + "mlp.fc2")
-    ln("enc.aifi.ln2", a + "final_layer_norm")
-
-    def csp(mine, hf):
-        for c in ("1", "2"):
-            conv(f"{mine}.c{c}", f"{hf}.conv{c}.conv", f"{hf}.conv{c}.norm")
-        for j in range(3):
-            conv(f"{mine}.rep{j}.k3", f"{hf}.bottlenecks.{j}.conv1.conv", f"{hf}.bottlenecks.{j}.conv1.norm")
-            conv(f"{mine}.rep{j}.k1", f"{hf}.bottlenecks.{j}.conv2.conv", f"{hf}.bottlenecks.{j}.conv2.norm")
-        if arch.csp_hidden != arch.enc_dim:
-            conv(f"{mine}.c3", f"{hf}.conv3.conv", f"{hf}.conv3.norm")
-
-    for i in range(2):
-        conv(f"enc.lat.{i}", f"model.encoder.lateral_convs.{i}.conv", f"model.encoder.lateral_convs.{i}.norm")
-        conv(f"enc.down.{i}", f"model.encoder.downsample_convs.{i}.conv", f"model.encoder.downsample_convs.{i}.norm")
-        csp(f"enc.fpn.{i}", f"model.encoder.fpn_blocks.{i}")
-        csp(f"enc.pan.{i}", f"model.encoder.pan_blocks.{i}")
-    lin("dec.enc_out.fc", "model.enc_output.0")
-    ln("dec.enc_out.ln", "model.enc_output.1")
-    lin("dec.enc_score", "model.enc_score_head")
-    for j in range(3):
-        lin(f"dec.enc_bbox.{j}", f"model.enc_bbox_head.layers.{j}")
-    for j in range(2):
-        lin(f"dec.qpos.{j}", f"model.decoder.query_pos_head.layers.{j}")
-    for i in range(arch.dec_layers):
-        d = f"model.decoder.layers.{i}."
-        for n in "qkvo":
-            lin(f"dec.l{i}.sa.{n}", f"{d}self_attn.{n}_proj")
-        ln(f"dec.l{i}.ln1", d + "self_attn_layer_norm")
-        lin(f"dec.l{i}.ca.off", d + "encoder_attn.sampling_offsets")
-        lin(f"dec.l{i}.ca.aw", d + "encoder_attn.attention_weights")
-        lin(f"dec.l{i}.ca.vp", d + "encoder_attn.value_proj")
-        lin(f"dec.l{i}.ca.op", d + "encoder_attn.output_proj")
-        ln(f"dec.l{i}.ln2", d + "encoder_attn_layer_norm")
-        lin(f"dec.l{i}.fc1", d + "mlp.fc1")
-        lin(f"dec.l{i}.fc2", d + "mlp.fc2")
-        ln(f"dec.l{i}.ln3", d + "final_layer_norm")
-        for j in range(3):
-            lin(f"dec.bbox.{i}.{j}", f"bbox_embed.{i}.layers.{j}")
-        lin(f"dec.cls.{i}", f"class_embed.{i}")
-    return m
+from telescope_cam_detection_amd.checkpoint import hf_key_map  # noqa: E402  (mine -> HF names; one table for golden generation and the converter)
 
 
 def build_hf(arch, w):

@@ -834,6 +834,12 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
   const int ks0 = (int)((long long)slice * nk_all / g.splitk), ks1 = (int)((long long)(slice + 1) * nk_all / g.splitk);
   const int nk = ks1 - ks0;                                      // K-steps of this slice
 
+  // diagnostic (glds_drop bit 5): block-level stamps [block][0..7] (shader clocks from kernel entry; [6],[7] = 100 MHz wall clock
+  // at entry / exit): first tile landed, K loop done, staged, stores issued, stores complete
+  long long* stamps = ((g.probe & 32) && g.slab && blockIdx.x < 4096 && lane == 0 && g.splitk == 1) ? (long long*)g.slab + (size_t)blockIdx.x * 8 : nullptr;
+  const long long t_base = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  if (stamps && wv == 0) stamps[6] = (long long)__builtin_amdgcn_s_memrealtime();
+
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -940,6 +946,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
       if (STAGES == 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (STAGES >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (stamps && wv == 4 && ks == 0) stamps[0] = (long long)__builtin_amdgcn_s_memtime() - t_base;
       __builtin_amdgcn_s_barrier();
       if (ks + AHEAD < nk) issue((ks + AHEAD) % STAGES);
     }
@@ -1014,6 +1021,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
       }
     }
   }
+  if (stamps && wv == 0) stamps[1] = (long long)__builtin_amdgcn_s_memtime() - t_base;
   __syncthreads();                                 // every MFMA operand read is done: smem becomes the fp32 staging tile
 
   if (g.splitk > 1) {
@@ -1085,7 +1093,14 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
     }
   }
   __syncthreads();
+  if (stamps && wv == 0) stamps[2] = (long long)__builtin_amdgcn_s_memtime() - t_base;
   dispatch_act(a.act, [&](auto actc) { ws_copy_out<4, decltype(actc)::value>(a, st, SLD, tid, m0, n0, rpre); });
+  if (stamps && wv == 0) {
+    stamps[3] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamps[4] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+    stamps[7] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
 }
 
 
@@ -1292,6 +1307,8 @@ void conv_set_splitk(int v) { g_splitk_enable = v; }
 void conv_set_mode(int v) { g_conv_mode = v; g_force_v1 = (v == 1); }
 static int g_ws256_min_blocks = 0;   // auto dispatch: 256-pixel tiles from this many blocks on (0 = never); rtd_debug_option "ws256_min_blocks"
 void conv_set_ws256_min_blocks(int v) { g_ws256_min_blocks = v; }
+static int g_glds_min_n = 128;   // 64 measured slower on the stage-0 reduce convs (45 vs 42 us)
+void conv_set_glds_min_n(int v) { g_glds_min_n = v; }
 static int g_prefetch = 1;    // A/B hook (rtd_debug_option "prefetch"): 0 = no next-layer filter prefetch
 void conv_set_prefetch(int v) { g_prefetch = v; }
 template <typename T>
@@ -1299,7 +1316,10 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
   if (!ok || g_conv_mode == 1 || g_conv_mode == 2) return false;     // 5 = single-role LDS-DMA kernels (v3) for A/B
   const long long mt = (k.M + 127) / 128, ntn = (k.N + 127) / 128;
   // fp32 GEMMs (query-selection heads) may use a partly empty N tile: N >= 64 still beats the small-tile kernel
-  if (k.N < (sizeof(T) == 2 ? 128 : 64) || mt * ntn < (sizeof(T) == 2 ? g_glds_min_blocks : 512) || x_bytes >= (1ll << 31) || w_bytes >= (1ll << 31)) return false;
+  // N >= 64 may use a partly empty N tile (the filter is padded to 128 rows): the N = 64 reduce convs of stage 0 are HBM-bound,
+  // and the LDS-DMA pipeline (2 blocks per CU) streams their input faster than the register-staged kernel (rtd_debug_option
+  // "glds_min_n" = 128 restores the old rule for A/B)
+  if (k.N < (sizeof(T) == 2 ? g_glds_min_n : 64) || mt * ntn < (sizeof(T) == 2 ? g_glds_min_blocks : 512) || x_bytes >= (1ll << 31) || w_bytes >= (1ll << 31)) return false;
   ConvG g;
   g.k = k;
   g.k.ntn = (int)ntn;

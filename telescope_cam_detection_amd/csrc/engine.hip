@@ -1289,6 +1289,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "dec_split") == 0) { g_dec_split = value; return RTD_OK; }
   if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
   if (strcmp(name, "prefetch") == 0) { conv_set_prefetch(value); return RTD_OK; }
+  if (strcmp(name, "glds_min_n") == 0) { conv_set_glds_min_n(value); return RTD_OK; }
   if (strcmp(name, "conv_reg") == 0) { conv_set_reg(value); return RTD_OK; }
   if (strcmp(name, "ws256_min_blocks") == 0) { conv_set_ws256_min_blocks(value); return RTD_OK; }
   if (strcmp(name, "profile_twice") == 0) { g_profile_twice = value; return RTD_OK; }
@@ -1356,7 +1357,7 @@ int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, in
     a.w = w; a.bias = bias; a.KH = KH; a.KW = KH; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.Npad = Npad;
     a.act = 1; a.res_mode = with_res ? RES_PRE : RES_NONE;
     if (with_res) a.res = mk(r, dtype, B, OH, OW, Cout);
-    a.ws.slab_bytes = (size_t)64 * 48 * 8 * 8;
+    a.ws.slab_bytes = (size_t)4096 * 8 * 8 > (size_t)64 * 48 * 8 * 8 ? (size_t)4096 * 8 * 8 : (size_t)64 * 48 * 8 * 8;
     HIP_CHECK(hipMalloc((void**)&a.ws.slab, a.ws.slab_bytes));
     HIP_CHECK(hipMemset(a.ws.slab, 0, a.ws.slab_bytes));
     hipEvent_t e0, e1;
@@ -1395,7 +1396,27 @@ int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, in
       us_out[1] = tot * 1e3f / reps;
     }
     HIP_CHECK(hipDeviceSynchronize());
-    if (getenv("RTD_CONV_STAMPS")) {           // with rtd_debug_option("glds_drop", 32) + conv_mode 7: per-K-step stamps of blocks 0..63
+    if (getenv("RTD_CONV_STAMPS") && atoi(getenv("RTD_CONV_STAMPS")) == 2) {      // block-level stamps of the 128-pixel ws kernels
+      const int nb = 4096;
+      std::vector<long long> st((size_t)nb * 8);
+      HIP_CHECK(hipMemcpy(st.data(), a.ws.slab, st.size() * 8, hipMemcpyDeviceToHost));
+      long long t0 = -1;
+      for (int i = 0; i < nb; ++i) if (st[i * 8 + 6] && (t0 < 0 || st[i * 8 + 6] < t0)) t0 = st[i * 8 + 6];
+      double s_land = 0, s_k = 0, s_stage = 0, s_copy = 0, s_ack = 0; int cnt = 0; long long tend = 0;
+      for (int i = 0; i < nb; ++i) {
+        const long long* q = &st[(size_t)i * 8];
+        if (!q[6] || !q[7]) continue;
+        s_land += q[0]; s_k += q[1] - q[0]; s_stage += q[2] - q[1]; s_copy += q[3] - q[2]; s_ack += q[4] - q[3]; ++cnt;
+        if (q[7] > tend) tend = q[7];
+      }
+      fprintf(stderr, "ws blocks stamped %d: mean clocks: first tile landed %.0f | K loop %.0f | staging %.0f | copy-out %.0f | store ack %.0f ; kernel wall %.2f us\n",
+              cnt, s_land / cnt, s_k / cnt, s_stage / cnt, s_copy / cnt, s_ack / cnt, (tend - t0) * 0.01);
+      for (int i : {0, 1, 600, 1500, 3000}) {
+        const long long* q = &st[(size_t)i * 8];
+        if (q[6]) fprintf(stderr, "  block %4d: start %+8.2f us  landed %6lld  kdone %6lld  staged %6lld  stored %6lld  acked %6lld  life %.2f us\n", i,
+                          (q[6] - t0) * 0.01, q[0], q[1], q[2], q[3], q[4], (q[7] - q[6]) * 0.01);
+      }
+    } else if (getenv("RTD_CONV_STAMPS")) {           // with rtd_debug_option("glds_drop", 32) + conv_mode 7: per-K-step stamps of blocks 0..63
       std::vector<long long> st((size_t)64 * 48 * 8);
       HIP_CHECK(hipMemcpy(st.data(), a.ws.slab, st.size() * 8, hipMemcpyDeviceToHost));
       for (int blk : {0, 1, 17}) {

@@ -57,11 +57,11 @@ def load_state(model_path: str):
     if str(model_path).startswith("synthetic:"):
         _, arch_name, seed = str(model_path).split(":")
         return synth_weights(ARCHS[arch_name], int(seed)), arch_name
-    import torch
+    # this build's own files, HF `RTDetrV2ForObjectDetection` checkpoints (.safetensors / .bin) and upstream `.pth` key
+    # names are recognised and converted (checkpoint.py)
+    from .checkpoint import load_foreign_state
 
-    ckpt = torch.load(model_path, map_location="cpu", weights_only=True)
-    state = ckpt["ema"]["module"] if "ema" in ckpt else ckpt["model"]
-    return state, ckpt.get("arch")
+    return load_foreign_state(model_path)
 
 
 class RTDETRDetector:
