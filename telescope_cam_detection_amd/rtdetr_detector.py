@@ -208,6 +208,52 @@ class RTDETRDetector:
             return []
         return [self._format(rows) for rows in self._infer(list(frames))]
 
+    # ------------------------------------------------------------------ pipelined use (batching.BatchCoordinator, depth > 1)
+    def detect_batch_async(self, frames: List[Union[np.ndarray, "torch.Tensor"]]):
+        """Enqueue one batch (<= max_batch frames) on this detector's stream and return a ticket at once; `detect_batch_collect`
+        blocks for that batch only.  With two detectors a coordinator keeps two batches in flight: one batch's kernels fill the
+        CUs the other's small grids leave idle (bench.py --streams 2: +35 % frames/s on one MI355X)."""
+        import torch
+
+        if self.model is None:
+            raise RuntimeError("Model not loaded")
+        eng = self.model.engine
+        if len(frames) > eng.max_batch:
+            raise ValueError(f"detect_batch_async takes at most max_batch={eng.max_batch} frames")
+        dev_index = torch.device(self.device).index or 0
+        stream = torch.cuda.ExternalStream(eng.stream(), device=torch.device("cuda", dev_index))
+        dev = []
+        with torch.cuda.stream(stream):                  # uploads are ordered before the forward on the engine's own stream
+            for f in frames:
+                a, on_dev = self._as_frame(f)
+                if on_dev:
+                    dev.append(a)
+                else:
+                    dev.append(torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(f"cuda:{dev_index}", non_blocking=True))
+        if dev:
+            eng.infer_async(dev)
+        return {"n": len(dev), "frames": dev, "conf": self.conf_threshold, "wildlife": self.wildlife_only}
+
+    def detect_batch_collect(self, ticket) -> List[List[Dict[str, Any]]]:
+        import torch
+
+        from .shard import block_to_detections
+
+        n = ticket["n"]
+        if n == 0:
+            return []
+        eng = self.model.engine
+        eng.sync()
+        ptr, nfl = eng.result_block()
+        dev_index = torch.device(self.device).index or 0
+
+        class _Ptr:
+            __cuda_array_interface__ = {"shape": (nfl,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+        block = torch.as_tensor(_Ptr(), device=f"cuda:{dev_index}")[: n * eng.num_queries * 6].cpu().numpy()
+        ticket["frames"] = None
+        return block_to_detections(block.reshape(n, eng.num_queries, 6), ticket["conf"], ticket["wildlife"])
+
     def is_wildlife_relevant(self, class_id: int) -> bool:
         return class_id in WILDLIFE_CLASSES
 

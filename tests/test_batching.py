@@ -129,6 +129,73 @@ def test_make_coordinator_follows_reference_config_keys():
     assert System(cfg)._initialize_shared_coordinator() == "reference-path"     # yolox: reference behaviour untouched
 
 
+class FakeAsyncDetector(FakeDetector):
+    """detect_batch_async / detect_batch_collect like RTDETRDetector's pipelined API: the work 'runs' between the two calls"""
+
+    def __init__(self, delay=0.0, fail_on=None):
+        super().__init__(delay, fail_on)
+        self.outstanding = 0
+        self.max_outstanding = 0
+        self.lock = threading.Lock()
+
+    def detect_batch_async(self, frames):
+        with self.lock:
+            self.outstanding += 1
+            self.max_outstanding = max(self.max_outstanding, self.outstanding)
+        return {"frames": list(frames), "t": time.time()}
+
+    def detect_batch_collect(self, ticket):
+        left = self.delay - (time.time() - ticket["t"])
+        if left > 0:
+            time.sleep(left)
+        with self.lock:
+            self.outstanding -= 1
+        return FakeDetector.detect_batch(FakeDetector(0.0, self.fail_on), ticket["frames"])
+
+
+def test_pipelined_coordinator_keeps_two_batches_in_flight_and_preserves_routing():
+    d0, d1 = FakeAsyncDetector(delay=0.05), FakeAsyncDetector(delay=0.05)
+    got = {}
+    done = threading.Event()
+    n = 32
+    t0 = time.time()
+    with BatchCoordinator(d0, max_batch_size=4, max_batch_wait_ms=2.0, extra_detectors=[d1]) as c:
+        def cb(tag):
+            def f(d):
+                got[tag] = d
+                if len(got) == n:
+                    done.set()
+            return f
+        for i in range(n):
+            c.infer_async(frame(i), cb(i), camera_id=f"cam{i % 4}")
+        assert done.wait(10.0)
+        stats = c.get_stats()
+    elapsed = time.time() - t0
+    assert all(got[i][0]["class_id"] == i for i in range(n))
+    assert stats["total_frames"] == n
+    assert d0.max_outstanding == 1 and d1.max_outstanding == 1          # a detector never holds two batches
+    # 8 batches of 50 ms: serial = 0.4 s, two in flight ~0.2 s
+    assert elapsed < 0.34, elapsed
+
+
+def test_pipelined_coordinator_answers_every_callback_when_a_batch_fails():
+    d0, d1 = FakeAsyncDetector(fail_on=3), FakeAsyncDetector(fail_on=3)
+    got = {}
+    done = threading.Event()
+    with BatchCoordinator(d0, max_batch_size=2, max_batch_wait_ms=1.0, extra_detectors=[d1]) as c:
+        def cb(tag):
+            def f(d):
+                got[tag] = d
+                if len(got) == 8:
+                    done.set()
+            return f
+        for i in range(8):
+            c.infer_async(frame(i), cb(i))
+        assert done.wait(5.0)
+    assert got[3] == [] and sum(1 for v in got.values() if v == []) in (1, 2)     # the failing batch (<= 2 frames) got []
+    assert all(got[i][0]["class_id"] == i for i in got if got[i])
+
+
 @pytest.mark.gpu
 def test_four_camera_threads_through_the_real_detector():
     from oracle import rtdetr_oracle as orc
@@ -165,3 +232,35 @@ def test_four_camera_threads_through_the_real_detector():
         ref = want[(cam + it) % len(frames)]
         assert [x["class_id"] for x in d] == [x["class_id"] for x in ref]
         assert np.allclose([x["confidence"] for x in d], [x["confidence"] for x in ref], atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_pipelined_coordinator_on_two_real_detectors_matches_detect():
+    from telescope_cam_detection_amd.rtdetr_detector import RTDETRDetector
+    from tests.util import load_case
+    arch, wseed, input_size, frames, g = load_case("t_tinyb_192x128")
+    cfg = {"detection": {"detector_type": "rtdetr", "device": "cuda:0", "conf_threshold": 0.2, "input_size": list(input_size),
+                         "wildlife_only": False, "rtdetr": {"config_path": "tinyb", "weights": f"synthetic:tinyb:{wseed}"},
+                         "batching": {"enabled": True, "max_batch_size": 2, "max_batch_wait_ms": 2.0, "pipeline_depth": 2}}}
+    coord = make_rtdetr_coordinator(cfg)
+    assert isinstance(coord, BatchCoordinator) and len(coord.detectors) == 2
+    ref = RTDETRDetector(config_path="tinyb", model_path=f"synthetic:tinyb:{wseed}", device="cuda:0", conf_threshold=0.2,
+                         input_size=input_size, wildlife_only=False, max_batch=2)
+    assert ref.load_model()
+    want = [ref.detect(f) for f in frames]
+    results = {}
+    done = threading.Event()
+    n = 18
+    with coord:
+        for i in range(n):
+            def cb(d, key=i):
+                results[key] = d
+                if len(results) == n:
+                    done.set()
+            coord.infer_async(frames[i % len(frames)], cb, camera_id=f"cam{i % 3}")
+        assert done.wait(30.0)
+    for i in range(n):
+        r = want[i % len(frames)]
+        assert [x["class_id"] for x in results[i]] == [x["class_id"] for x in r]
+        assert np.allclose([x["confidence"] for x in results[i]], [x["confidence"] for x in r], atol=1e-5)
+        assert np.allclose([x["bbox"]["x1"] for x in results[i]], [x["bbox"]["x1"] for x in r], atol=1e-3)
