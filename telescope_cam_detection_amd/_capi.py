@@ -68,6 +68,13 @@ def lib() -> C.CDLL:
         except Exception as e:  # no hipcc on this box: use the prebuilt library if it is there
             if not os.path.exists(path):
                 raise RuntimeError(f"libmi355rtdetr.so is missing and cannot be built: {e}") from e
+    # PyTorch-ROCm bundles its own libamdhip64: load it FIRST so that this library's libamdhip64.so.7 dependency resolves
+    # to the same runtime instance.  Loaded the other way round (this library, then torch) the process holds two HIP runtimes
+    # and the second to touch the GPU reports "no ROCm-capable device" (seen with build() followed by smoke() in one process).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(path)
     vp, i32, f32, i64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
     L.rtd_version.restype = C.c_char_p

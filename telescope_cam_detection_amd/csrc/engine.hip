@@ -830,8 +830,13 @@ Plan* get_plan(rtd_engine* e, int n) {
 void run_plan(rtd_engine* e, Plan* p) {
   if (e->cfg.use_graph) {
     if (!p->exec) {
-      // one eager pass first: faults and shape errors surface outside capture
-      for (auto& op : p->ops) op.run(e->stream);
+      // one eager pass first: faults and shape errors surface outside capture (RTD_TRACE_OPS=1: name + sync per op)
+      const bool trace = getenv("RTD_TRACE_OPS") != nullptr;
+      for (auto& op : p->ops) {
+        if (trace) { fprintf(stderr, "[rtd] %s (%s)\n", op.name.c_str(), op.kernel); fflush(stderr); }
+        op.run(e->stream);
+        if (trace) HIP_CHECK(hipStreamSynchronize(e->stream));
+      }
       HIP_CHECK(hipStreamSynchronize(e->stream));
       HIP_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
       try {
@@ -855,12 +860,17 @@ void run_plan(rtd_engine* e, Plan* p) {
 void enqueue_frames(rtd_engine* e, Plan* p, int n, const uint8_t* const* frames, const int32_t* hw, bool on_device) {
   const int H = e->cfg.input_h, W = e->cfg.input_w;
   size_t total = 0, max_tmp = 0;
+  bool any_resize = false;
   for (int i = 0; i < n; ++i) {
     RTD_CHECK(frames[i] != nullptr && hw[2 * i] > 0 && hw[2 * i + 1] > 0 && hw[2 * i] <= 16384 && hw[2 * i + 1] <= 16384,
               RTD_E_INVALID, "frame pointer / size");
     total += ((size_t)hw[2 * i] * hw[2 * i + 1] * 3 + 255) / 256 * 256;
-    if (hw[2 * i] != H || hw[2 * i + 1] != W) max_tmp = std::max(max_tmp, (size_t)hw[2 * i] * W * 3);
+    if (hw[2 * i] != H || hw[2 * i + 1] != W) any_resize = true;
   }
+  // one frame of another size sends EVERY frame of the batch through the resampler (identity-sized ones with 1-tap
+  // coefficients): the horizontal pass' intermediate [src_h][W][3] must fit the largest of them, not only the resized ones
+  if (any_resize)
+    for (int i = 0; i < n; ++i) max_tmp = std::max(max_tmp, (size_t)hw[2 * i] * W * 3);
   if (!on_device && total > e->frame_stage_bytes) {
     HIP_CHECK(hipStreamSynchronize(e->stream));
     if (e->frame_stage) (void)hipFree(e->frame_stage);

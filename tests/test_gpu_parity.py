@@ -235,3 +235,31 @@ def test_detector_class_end_to_end():
     assert det.get_class_category(0) == "person" and det.get_class_category(16) == "mammal" and det.get_class_category(5) == "other"
     with pytest.raises(RuntimeError):
         det.model.to("cpu")
+
+
+@pytest.mark.parametrize("shapes", [[(160, 160), (120, 200)], [(90, 70), (160, 160), (50, 300)], [(400, 40), (160, 160)]])
+def test_mixed_frame_sizes_go_through_the_resampler_like_the_oracle(shapes):
+    """A batch with at least one odd-sized frame sends every frame through the PIL-exact resampler; its horizontal-pass
+    intermediate must fit the tallest frame of the batch (regression: it was sized from the resized frames only, an
+    identity-sized frame taller than them wrote past it - a GPU memory fault in __graft_entry__.smoke)."""
+    from oracle import rtdetr_oracle as orc
+    from telescope_cam_detection_amd import _capi
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.synth import scene_frame
+    from telescope_cam_detection_amd.weights import fold_weights, pack_blob, synth_weights
+
+    arch = ARCHS["tiny"]
+    w = synth_weights(arch, 1)
+    frames = [scene_frame(20 + i, h, ww) for i, (h, ww) in enumerate(shapes)]
+    eng = _capi.Engine(arch, pack_blob(fold_weights(arch, w)), 0, _capi.PREC_FP32, len(frames), (160, 160), True)
+    for _ in range(2):
+        labels, boxes, scores = eng.infer_raw(frames)
+    got = eng.debug_tensor("input")[:, :, :, :3]
+    for i, f in enumerate(frames):
+        x, _ = orc.preprocess(f, (160, 160))
+        np.testing.assert_array_equal(got[i], x[0].permute(1, 2, 0).numpy())          # bit-exact preprocessing
+    xs, sizes = zip(*[orc.preprocess(f, (160, 160)) for f in frames])
+    ol, ob, osc = orc.model_forward(arch, w, torch.cat(xs, 0), list(sizes))
+    for b in range(len(frames)):
+        assert np.abs(np.sort(scores[b])[::-1][:10] - np.sort(osc[b].numpy())[::-1][:10]).max() < 1e-3
+    eng.close()
