@@ -121,7 +121,16 @@ void launch_box_refine(const Tensor& delta, float* ref8, hipStream_t s);
 void launch_postprocess_scores(const Tensor& logits, float* scores, hipStream_t s);
 void launch_postprocess_gather(const float* topv, const int32_t* topi, const float* ref8, const float* scale_wh,
                                int B, int Q, int C, float* block6, hipStream_t s);
-void launch_preprocess_identity(const uint8_t* const* frames, int n, int H, int W, const Tensor& y, hipStream_t s);
+// per-call frame arguments travel as KERNEL ARGUMENTS (captured at launch): an async host->device copy of them would read the
+// host staging when it executes, i.e. possibly after the next call has overwritten it, and puts two copies on the stream per step
+constexpr int RTD_MAX_BATCH = 64;
+struct FrameArgs {
+  const uint8_t* ptr[RTD_MAX_BATCH];   // HWC uint8 BGR frames on the device
+  float scale_wh[2 * RTD_MAX_BATCH];   // (w, h) of each original frame (src/rtdetr_detector.py:234)
+  int n;
+};
+void launch_preprocess_identity(const FrameArgs& fa, int H, int W, const Tensor& y, float* scale_wh_dev, hipStream_t s);
+void launch_set_scale(const FrameArgs& fa, float* scale_wh_dev, hipStream_t s);
 // device-resident coefficient tables of one (src size -> dst size) PIL resize
 struct ResizeCoef {
   const int32_t* hb;  // [dw][2] xmin, count

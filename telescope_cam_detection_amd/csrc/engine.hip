@@ -89,8 +89,6 @@ struct rtd_engine {
   // per-call staging
   uint8_t* frame_stage = nullptr; size_t frame_stage_bytes = 0;
   uint8_t* resize_tmp = nullptr; size_t resize_tmp_bytes = 0;
-  const uint8_t** ptrs_dev = nullptr; const uint8_t** ptrs_host = nullptr;
-  float* scale_host = nullptr;
   float* block_host = nullptr;
   int32_t* forced_idx = nullptr; int32_t* force_flag = nullptr;
   // geometry
@@ -887,6 +885,9 @@ void enqueue_frames(rtd_engine* e, Plan* p, int n, const uint8_t* const* frames,
   }
   size_t off = 0;
   bool all_identity = true;
+  FrameArgs fa;
+  memset(&fa, 0, sizeof fa);
+  fa.n = n;
   for (int i = 0; i < n; ++i) {
     const size_t bytes = (size_t)hw[2 * i] * hw[2 * i + 1] * 3;
     const uint8_t* dev = frames[i];
@@ -895,20 +896,19 @@ void enqueue_frames(rtd_engine* e, Plan* p, int n, const uint8_t* const* frames,
       dev = e->frame_stage + off;
       off += (bytes + 255) / 256 * 256;
     }
-    e->ptrs_host[i] = dev;
-    e->scale_host[2 * i] = (float)hw[2 * i + 1];   // orig_size = [w, h]  (src/rtdetr_detector.py:234)
-    e->scale_host[2 * i + 1] = (float)hw[2 * i];
+    fa.ptr[i] = dev;
+    fa.scale_wh[2 * i] = (float)hw[2 * i + 1];      // orig_size = [w, h]  (src/rtdetr_detector.py:234)
+    fa.scale_wh[2 * i + 1] = (float)hw[2 * i];
     if (hw[2 * i] != H || hw[2 * i + 1] != W) all_identity = false;
   }
-  HIP_CHECK(hipMemcpyAsync(p->scale_wh, e->scale_host, (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
   if (all_identity) {
-    HIP_CHECK(hipMemcpyAsync((void*)e->ptrs_dev, e->ptrs_host, (size_t)n * sizeof(void*), hipMemcpyHostToDevice, e->stream));
-    launch_preprocess_identity(e->ptrs_dev, n, H, W, p->input, e->stream);
+    launch_preprocess_identity(fa, H, W, p->input, p->scale_wh, e->stream);
   } else {
+    launch_set_scale(fa, p->scale_wh, e->stream);
     for (int i = 0; i < n; ++i) {
       // the same resampler handles an identity-sized frame exactly (1-tap coefficients of 1.0)
       const ResizeCoef& rc = resize_tables(e, hw[2 * i], hw[2 * i + 1]);
-      launch_resize_pil(e->ptrs_host[i], hw[2 * i], hw[2 * i + 1], e->resize_tmp, p->input, i, rc, e->stream);
+      launch_resize_pil(fa.ptr[i], hw[2 * i], hw[2 * i + 1], e->resize_tmp, p->input, i, rc, e->stream);
     }
   }
 }
@@ -1063,9 +1063,6 @@ int rtd_load_weights(rtd_handle h, const void* blob, size_t nbytes) {
     e->forced_idx = (int32_t*)e->dmalloc((size_t)c.max_batch * c.num_queries * 4);
     e->force_flag = (int32_t*)e->dmalloc(16);
     HIP_CHECK(hipMemset(e->force_flag, 0, 16));
-    e->ptrs_dev = (const uint8_t**)e->dmalloc((size_t)c.max_batch * sizeof(void*));
-    HIP_CHECK(hipHostMalloc((void**)&e->ptrs_host, (size_t)c.max_batch * sizeof(void*), hipHostMallocDefault));
-    HIP_CHECK(hipHostMalloc((void**)&e->scale_host, (size_t)c.max_batch * 8, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void**)&e->block_host, (size_t)c.max_batch * c.num_queries * 6 * 4, hipHostMallocDefault));
     e->loaded = true;
     // build the bs=1 plan now: validates every tensor name / shape of the blob against the graph
@@ -1167,8 +1164,6 @@ void rtd_destroy(rtd_handle h) {
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->frame_stage) (void)hipFree(h->frame_stage);
     if (h->resize_tmp) (void)hipFree(h->resize_tmp);
-    if (h->ptrs_host) (void)hipHostFree((void*)h->ptrs_host);
-    if (h->scale_host) (void)hipHostFree(h->scale_host);
     if (h->block_host) (void)hipHostFree(h->block_host);
     if (h->stream) (void)hipStreamDestroy(h->stream);
   }

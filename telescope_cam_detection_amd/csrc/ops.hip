@@ -754,13 +754,14 @@ void launch_postprocess_gather(const float* topv, const int32_t* topi, const flo
 // src/rtdetr_detector.py:224-231 for a frame that already has the network's input size: BGR->RGB,
 // ToTensor (uint8 / 255), written as NHWC with the 3 channels padded to 8 (one 16-byte bf16 chunk).
 template <typename T>
-__global__ void k_preprocess_identity(const uint8_t* const* __restrict__ frames, int H, int W, T* __restrict__ y, int64_t total) {
+__global__ void k_preprocess_identity(const FrameArgs fa, int H, int W, T* __restrict__ y, float* __restrict__ scale_wh, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * fa.n) scale_wh[i] = fa.scale_wh[i];               // the post-processor's orig_target_sizes
   if (i >= total) return;
   const int64_t hw = (int64_t)H * W;
   const int b = (int)(i / hw);
   const int64_t p = i - (int64_t)b * hw;
-  const uint8_t* f = frames[b] + p * 3;
+  const uint8_t* f = fa.ptr[b] + p * 3;
   const float bl = (float)f[0], g = (float)f[1], r = (float)f[2];
   T* o = y + i * 8;
   o[0] = (T)(r / 255.0f);
@@ -769,10 +770,18 @@ __global__ void k_preprocess_identity(const uint8_t* const* __restrict__ frames,
 #pragma unroll
   for (int k = 3; k < 8; ++k) o[k] = (T)0.f;
 }
-void launch_preprocess_identity(const uint8_t* const* frames, int n, int H, int W, const Tensor& y, hipStream_t s) {
-  RTD_CHECK(y.c == 8 && y.ld == 8 && y.h == H && y.w == W && y.n >= n, 1, "preprocess: output must be [n,H,W,8]");
-  const int64_t total = (int64_t)n * H * W;
-  DISPATCH_T(y.dt, hipLaunchKernelGGL(k_preprocess_identity<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, frames, H, W, (T*)y.p, total));
+void launch_preprocess_identity(const FrameArgs& fa, int H, int W, const Tensor& y, float* scale_wh_dev, hipStream_t s) {
+  RTD_CHECK(y.c == 8 && y.ld == 8 && y.h == H && y.w == W && y.n >= fa.n, 1, "preprocess: output must be [n,H,W,8]");
+  const int64_t total = (int64_t)fa.n * H * W;
+  DISPATCH_T(y.dt, hipLaunchKernelGGL(k_preprocess_identity<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, fa, H, W, (T*)y.p, scale_wh_dev, total));
+  HIP_CHECK(hipGetLastError());
+}
+__global__ void k_set_scale(const FrameArgs fa, float* __restrict__ scale_wh) {
+  const int i = threadIdx.x;
+  if (i < 2 * fa.n) scale_wh[i] = fa.scale_wh[i];
+}
+void launch_set_scale(const FrameArgs& fa, float* scale_wh_dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_scale, dim3(1), dim3(2 * RTD_MAX_BATCH), 0, s, fa, scale_wh_dev);
   HIP_CHECK(hipGetLastError());
 }
 
