@@ -154,6 +154,8 @@ int rtd_op_resize(const uint8_t* src, int sh, int sw, void* dst, int dh, int dw,
 /* kernel micro-benchmark (tools/conv_bench.py): one conv layer on zero-filled buffers, timed with HIP events.
  * us_out[0] = mean of `reps` back-to-back launches (operands warm in L2 / Infinity Cache),
  * us_out[1] = mean of `reps` launches each preceded by a `flush_mb` MiB memset (operands come from HBM). */
+/* two convs on two streams: shape = {B, HW, Cin, Cout, K, stride, pad}; us_out = {A alone, B alone, A and B together} per repetition */
+int rtd_bench_conv_pair(const int* shape_a, const int* shape_b, int reps, float* us_out);
 int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int stride, int pad, int with_res,
                    int reps, int flush_mb, float* us_out);
 

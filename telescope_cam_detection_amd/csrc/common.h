@@ -192,6 +192,22 @@ struct DecArgs {
 
 void launch_dec_layer(const DecArgs& a, hipStream_t s);
 
+// Query selection scores (HF:v2.py:1580-1586): per memory token LayerNorm(enc_output.fc) -> enc_score_head -> max over classes,
+// one launch; neither the normalised memory nor the class logits are written (the 300 selected rows are normalised again by
+// launch_gather_ln).  x: [rows][256] fp32.
+struct SelArgs {
+  const float* x;
+  int64_t ldx;
+  int rows, C, rows_per_image;
+  DecLin score;      // fragment-major fp32 (DecArgs::split == 0 layout)
+  DecLN ln;
+  float* mx;         // [rows]
+};
+void launch_select_score(const SelArgs& a, hipStream_t s);
+// dst[b][q][:] = LayerNorm(x[b][idx[b][q]][:]) (dim 256)
+void launch_gather_ln(const float* x, int64_t ldx, int rows_per_image, const int32_t* idx, int B, int Q, const DecLN& ln, float* dst, int64_t ldd,
+                      hipStream_t s);
+
 // ---- Stage-2 crop batcher (ops.hip): up to 64 crops per launch, parameters by value ----
 struct CropBatch {
   const uint8_t* frame[64];   // HWC uint8 BGR frames on the device
@@ -202,5 +218,34 @@ void launch_crop_resize(const CropBatch& cb, int n, int out_size, const float me
 
 void launch_f32_to(const float* src, void* dst, int dt, int64_t n, hipStream_t s);
 void launch_to_f32(const void* src, int dt, float* dst, int64_t n, hipStream_t s);
+
+#if defined(__HIPCC__)
+// Wave-wide sum / max without LDS traffic: `__shfl_xor` compiles to ds_bpermute_b32 (an LDS-crossbar round trip, ~100+ cycles,
+// six in a dependent chain per reduction); here four DPP steps reduce each 16-lane row in the VALU and four v_readlane combine
+// the rows.  Every lane receives the result.  (Summation order differs from a butterfly - callers are not bit-pinned to one.)
+#define RTD_DPP_ROW_REDUCE(OP)                                                           \
+  v = OP(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)));  /* quad_perm [1,0,3,2] */ \
+  v = OP(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));  /* quad_perm [2,3,0,1] */ \
+  v = OP(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false))); /* row_ror:4 */ \
+  v = OP(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false))); /* row_ror:8 */
+__device__ __forceinline__ float rtd_addf(float a, float b) { return a + b; }
+__device__ __forceinline__ float wave_sum64(float v) {
+  RTD_DPP_ROW_REDUCE(rtd_addf)
+  const int iv = __builtin_bit_cast(int, v);
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48)));
+}
+__device__ __forceinline__ float wave_max64(float v) {
+  RTD_DPP_ROW_REDUCE(fmaxf)
+  const int iv = __builtin_bit_cast(int, v);
+  return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16))),
+               fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48))));
+}
+// sum / max over each 16-lane row only (the result is in every lane of the row)
+__device__ __forceinline__ float row16_max(float v) {
+  RTD_DPP_ROW_REDUCE(fmaxf)
+  return v;
+}
+#endif
 
 }  // namespace rtd

@@ -233,8 +233,7 @@ __device__ void row_ln(float* Xs, int ldx, int D, const DecLN& P, int wave, int 
       v[i] = c < D ? Xs[r * ldx + c] : 0.f;
       s += v[i];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    s = wave_sum64(s);
     const float mean = s / (float)D;
     float sq = 0.f;
 #pragma unroll
@@ -243,8 +242,7 @@ __device__ void row_ln(float* Xs, int ldx, int D, const DecLN& P, int wave, int 
       const float d = c < D ? v[i] - mean : 0.f;
       sq += d * d;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    sq = wave_sum64(sq);
     const float rstd = rsqrtf(sq / (float)D + 1e-5f);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -681,6 +679,131 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     }
   }
   DEC_STAMP(11);  // stores
+}
+
+// ---- query selection scores: LayerNorm + enc_score_head + class max in one launch (exact fp32 MFMA) ----------------------------
+// One WAVE owns a 16-row tile end to end (no block-level barrier): load 16 x 256 fp32 (load i of a lane = row i, columns
+// 4 lane..+3), LayerNorm in registers, rows to the wave's LDS slab as the MFMA A operand, score GEMM with the filter fragments
+// streamed from L2 one 16-deep chunk ahead, + bias, max over the classes straight from the accumulators.  The chunk order is
+// rotated by the tile's index inside its image (de-synchronises the waves' filter streams; a row's summation order then depends
+// only on its position in the image - batch order invariance).
+constexpr int SEL_WAVES = 4;
+__global__ __launch_bounds__(64 * SEL_WAVES, 2) void select_score_kernel(const SelArgs a) {
+  constexpr int LDH = 260;
+  __shared__ __attribute__((aligned(16))) float sX[SEL_WAVES][DR * LDH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long tile = (long long)blockIdx.x * SEL_WAVES + wave;
+  const long long row0 = tile * DR;
+  if (row0 >= a.rows) return;
+  const int nvalid = (int)min((long long)DR, (long long)a.rows - row0);
+  float* xs = sX[wave];
+  {
+    f32x4_ v[DR];
+#pragma unroll
+    for (int i = 0; i < DR; ++i) v[i] = *(const f32x4_*)(a.x + (row0 + min(i, nvalid - 1)) * a.ldx + lane * 4);
+    const f32x4_ g4 = *(const f32x4_*)(a.ln.g + lane * 4), b4 = *(const f32x4_*)(a.ln.b + lane * 4);
+#pragma unroll
+    for (int i = 0; i < DR; ++i) {
+      const float s = wave_sum64(v[i][0] + v[i][1] + v[i][2] + v[i][3]);
+      const float mean = s / 256.f;
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sq += (v[i][j] - mean) * (v[i][j] - mean);
+      sq = wave_sum64(sq);
+      const float rstd = rsqrtf(sq / 256.f + 1e-5f);
+      f32x4_ o4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o4[j] = (v[i][j] - mean) * rstd * g4[j] + b4[j];
+      *(f32x4_*)(xs + i * LDH + lane * 4) = o4;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  constexpr int MAXT = 5;                                         // <= 80 classes per pass; more classes: further passes
+  const int ntiles = (a.C + 15) >> 4;
+  const int r16 = lane & 15, q = lane >> 4;
+  const float* xrow = xs + r16 * LDH + 4 * q;
+  const int kc = a.score.K >> 4;                                  // 16 chunks
+  const int rot = (a.rows_per_image % DR == 0) ? (int)((row0 % a.rows_per_image) / DR) % kc : 0;
+  float best[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+  for (int t0 = 0; t0 < ntiles; t0 += MAXT) {
+    const int nt = min(MAXT, ntiles - t0);
+    f32x4_ acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = f32x4_{0.f, 0.f, 0.f, 0.f};
+    // filter fragments two chunks ahead (a chunk's 20 MFMAs are ~0.3 us, an L2 round trip under load 0.5-1 us)
+    f32x4_ cur[MAXT], n1[MAXT], n2[MAXT];
+    auto wrap = [&](int v) { return v >= kc ? v - kc : v; };
+    auto ldw = [&](f32x4_ (&dst)[MAXT], int chunk) {
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) dst[t] = *(const f32x4_*)(a.score.w + ((size_t)(t0 + min(t, nt - 1)) * kc + chunk) * 256 + lane * 4);
+    };
+    int c = rot;
+    ldw(cur, c);
+    ldw(n1, wrap(c + 1));
+    for (int it = 0; it < kc; ++it) {
+      const int k0 = c << 4;
+      ldw(n2, wrap(c + 2));
+      c = wrap(c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x4_ x4 = *(const f32x4_*)(xrow + k0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x4[u], cur[t][u], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) { cur[t] = n1[t]; n1[t] = n2[t]; }
+    }
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int col = (t0 + t) * 16 + r16;
+      if (t < nt && col < a.C) {
+        const float bv = a.score.b[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) best[r] = fmaxf(best[r], acc[t][r] + bv);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v = row16_max(best[r]);                            // the 16 lanes of this q group = the 16 columns of a tile
+    if (r16 == 0 && q * 4 + r < nvalid) a.mx[row0 + q * 4 + r] = v;
+  }
+}
+
+void launch_select_score(const SelArgs& a, hipStream_t s) {
+  RTD_CHECK(a.score.K == 256 && a.score.N == a.C && a.rows_per_image > 0, 1, "select_score: 256-wide rows");
+  const long long tiles = (a.rows + DR - 1) / DR;
+  hipLaunchKernelGGL(select_score_kernel, dim3((unsigned)((tiles + SEL_WAVES - 1) / SEL_WAVES)), dim3(64 * SEL_WAVES), 0, s, a);
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ void k_gather_ln(const float* __restrict__ x, long long ldx, int rows_per_image, const int32_t* __restrict__ idx, int total, int Q,
+                            DecLN ln, float* __restrict__ dst, long long ldd) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per selected row
+  const int lane = threadIdx.x & 63;
+  if (t >= total) return;
+  const int b = t / Q;
+  int r = idx[t];
+  r = min(max(r, 0), rows_per_image - 1);
+  const f32x4_ v = *(const f32x4_*)(x + ((long long)b * rows_per_image + r) * ldx + lane * 4);
+  const float s = wave_sum64(v[0] + v[1] + v[2] + v[3]);
+  const float mean = s / 256.f;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sq += (v[j] - mean) * (v[j] - mean);
+  sq = wave_sum64(sq);
+  const float rstd = rsqrtf(sq / 256.f + 1e-5f);
+  f32x4_ o4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o4[j] = (v[j] - mean) * rstd * ln.g[lane * 4 + j] + ln.b[lane * 4 + j];
+  *(f32x4_*)(dst + (long long)t * ldd + lane * 4) = o4;
+}
+void launch_gather_ln(const float* x, int64_t ldx, int rows_per_image, const int32_t* idx, int B, int Q, const DecLN& ln, float* dst, int64_t ldd,
+                      hipStream_t s) {
+  const int total = B * Q;
+  hipLaunchKernelGGL(k_gather_ln, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, x, (long long)ldx, rows_per_image, idx, total, Q, ln, dst, (long long)ldd);
+  HIP_CHECK(hipGetLastError());
 }
 
 void launch_dec_layer(const DecArgs& a, hipStream_t s) {

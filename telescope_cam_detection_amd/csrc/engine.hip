@@ -8,6 +8,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <chrono>
 #include <functional>
 #include <map>
 #include <memory>
@@ -26,6 +27,7 @@ namespace {
 thread_local std::string g_create_error;
 int g_dec_stamps = 0;  // plan-build switch: record per-phase stamps of decoder layer 2 into debug tensor "dec_stamps"
 int g_dec_split = 1;   // plan-build switch (rtd_debug_option "dec_split"): bf16 engine runs the fused decoder / AIFI linears as bf16 hi/lo splits
+int g_sel_fused = 1;   // plan-build switch (rtd_debug_option "sel_fused"): LayerNorm + score head + class max of the query selection in one launch
 int g_dec_fused = 1;   // plan-build switch (rtd_debug_option "dec_fused"): 0 = one launch per decoder op
 
 struct HostTensor {
@@ -634,14 +636,33 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     const int nr = e->n_invalid;
     B.push("dec.mask_rows", "set_rows", 0.0, (double)n * nr * dm * 4, [eo, rows, nr, S, bias](hipStream_t s) { launch_set_rows(eo, rows, nr, S, bias, s); });
   }
-  Tensor om = B.layernorm("dec.enc_out.ln", eo, F32, "output_memory");
-  Tensor cls = B.linear("dec.enc_score", om, C, F32, ACT_NONE);
+  const bool fused = g_dec_fused && dm == 256 && c.dec_heads == 8 && c.dec_ffn <= 1024 && C <= 512 && c.n_levels == 3 && c.n_points == 4;
+  const bool sel_fused = fused && g_sel_fused && eo.ld == dm;
   float* mx = (float*)B.alloc((size_t)n * S * 4);
   {
     Tensor t; t.p = mx; t.dt = F32; t.n = n; t.h = S; t.w = 1; t.c = 1; t.ld = 1; t.bstride = S;
     plan->named["enc_cls_max"] = t;
   }
-  B.push("dec.enc_rowmax", "rowmax", (double)n * S * C, (double)n * S * C * 4, [cls, mx](hipStream_t s) { launch_rowmax(cls, mx, s); });
+  Tensor om;
+  DecLN sel_ln{};
+  if (sel_fused) {
+    // LayerNorm + enc_score_head + class max in one launch: the normalised memory (69 MB fp32 at R50 bs 8) and the logits are
+    // never written; the selected rows are normalised again in the gather
+    SelArgs sa{};
+    if (!B.dry) {
+      DevWeight w = get_weight_packed(e, "dec.enc_score", C, dm, dm, false);
+      sa.score.w = (const float*)w.w; sa.score.b = w.bias; sa.score.ldw = w.Kpad; sa.score.N = C; sa.score.K = w.K;
+      sel_ln.g = get_vec(e, "dec.enc_out.ln.g", dm); sel_ln.b = get_vec(e, "dec.enc_out.ln.b", dm);
+      sa.ln = sel_ln;
+    }
+    sa.x = (const float*)eo.p; sa.ldx = eo.ld; sa.rows = n * S; sa.C = C; sa.rows_per_image = S; sa.mx = mx;
+    B.push("dec.select_score", "select_score", (double)n * S * (2.0 * C * dm + 8.0 * dm), (double)n * S * dm * 4 + (double)n * S * 4,
+           [sa](hipStream_t s) { launch_select_score(sa, s); });
+  } else {
+    om = B.layernorm("dec.enc_out.ln", eo, F32, "output_memory");
+    Tensor cls = B.linear("dec.enc_score", om, C, F32, ACT_NONE);
+    B.push("dec.enc_rowmax", "rowmax", (double)n * S * C, (double)n * S * C * 4, [cls, mx](hipStream_t s) { launch_rowmax(cls, mx, s); });
+  }
   int32_t* tk = (int32_t*)B.alloc((size_t)n * Q * 4);
   plan->tk_idx = tk;
   {
@@ -652,7 +673,14 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     });
   }
   Tensor target = B.act(F32, n, Q, 1, dm, "target");
-  B.push("dec.gather_target", "gather", 0.0, 2.0 * n * Q * dm * 4, [om, tk, S, target](hipStream_t s) { launch_gather_rows(om, tk, S, target, s); });
+  if (sel_fused) {
+    const float* xp = (const float*)eo.p; const int64_t ldx = eo.ld; float* tp = (float*)target.p; const int64_t ldt = target.ld;
+    B.push("dec.gather_target", "gather", 8.0 * n * Q * dm, 2.0 * n * Q * dm * 4, [xp, ldx, S, tk, n, Q, sel_ln, tp, ldt](hipStream_t s) {
+      launch_gather_ln(xp, ldx, S, tk, n, Q, sel_ln, tp, ldt, s);
+    });
+  } else {
+    B.push("dec.gather_target", "gather", 0.0, 2.0 * n * Q * dm * 4, [om, tk, S, target](hipStream_t s) { launch_gather_rows(om, tk, S, target, s); });
+  }
   const int npts = c.dec_heads * c.n_levels * c.n_points;
   float* ref_unact8 = (float*)B.alloc((size_t)n * Q * 8 * 4);
   float* ref8 = (float*)B.alloc((size_t)n * Q * 8 * 4);
@@ -664,7 +692,6 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   }
   Tensor hs = target;
   Tensor logits;
-  const bool fused = g_dec_fused && dm == 256 && c.dec_heads == 8 && c.dec_ffn <= 1024 && C <= 512 && c.n_levels == 3 && c.n_points == 4;
   if (fused) {
     // ---- fused decoder: 1 prologue + per layer (self-attention kernel + one fused kernel), decoder.hip -----
     Tensor qpos = B.act(F32, n, Q, 1, dm);
@@ -1291,6 +1318,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "conv_v1") == 0) { conv_set_force_v1(value); return RTD_OK; }
   if (strcmp(name, "dec_stamps") == 0) { g_dec_stamps = value; return RTD_OK; }
   if (strcmp(name, "dec_fused") == 0) { g_dec_fused = value; return RTD_OK; }
+  if (strcmp(name, "sel_fused") == 0) { g_sel_fused = value; return RTD_OK; }
   if (strcmp(name, "dec_split") == 0) { g_dec_split = value; return RTD_OK; }
   if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
   if (strcmp(name, "prefetch") == 0) { conv_set_prefetch(value); return RTD_OK; }
@@ -1439,6 +1467,52 @@ int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, in
     (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(bias);
     if (r) (void)hipFree(r);
     if (flush) (void)hipFree(flush);
+  });
+}
+
+// Concurrency micro-benchmark (tools/pair_bench.py): conv A on one stream, conv B on another; us_out = {A alone, B alone,
+// A and B issued together} per repetition (`reps` launches of each, events on both streams).
+struct BenchConv {
+  ConvArgs a;
+  void *x = nullptr, *y = nullptr, *w = nullptr; float* bias = nullptr;
+};
+static void bench_conv_make(BenchConv& c, const int* sh) {   // sh: B, HW, Cin, Cout, K, stride, pad
+  const int B = sh[0], H = sh[1], W = sh[1], Cin = sh[2], Cout = sh[3], KH = sh[4], stride = sh[5], pad = sh[6];
+  const int K = KH * KH * Cin, Kpad = conv_kpad(K), Npad = conv_npad(Cout);
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
+  const size_t xb = (size_t)B * H * W * Cin * 2, yb = (size_t)B * OH * OW * Cout * 2, wb = (size_t)Npad * Kpad * 2;
+  HIP_CHECK(hipMalloc(&c.x, xb)); HIP_CHECK(hipMalloc(&c.y, yb)); HIP_CHECK(hipMalloc(&c.w, wb)); HIP_CHECK(hipMalloc((void**)&c.bias, Npad * 4));
+  HIP_CHECK(hipMemset(c.x, 0, xb)); HIP_CHECK(hipMemset(c.w, 0, wb)); HIP_CHECK(hipMemset(c.bias, 0, Npad * 4));
+  c.a.x = mk(c.x, BF16, B, H, W, Cin);
+  c.a.y = mk(c.y, BF16, B, OH, OW, Cout);
+  c.a.w = c.w; c.a.bias = c.bias; c.a.KH = KH; c.a.KW = KH; c.a.stride = stride; c.a.pad = pad; c.a.Kpad = Kpad; c.a.Npad = Npad;
+  c.a.act = 1; c.a.res_mode = RES_NONE;
+}
+int rtd_bench_conv_pair(const int* shape_a, const int* shape_b, int reps, float* us_out) {
+  return op_guard([&] {
+    BenchConv A, B;
+    bench_conv_make(A, shape_a);
+    bench_conv_make(B, shape_b);
+    hipStream_t s1, s2;
+    HIP_CHECK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    hipEvent_t e0, e1, f0, f1;
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); HIP_CHECK(hipEventCreate(&f0)); HIP_CHECK(hipEventCreate(&f1));
+    auto run = [&](bool ra, bool rb) {
+      for (int i = 0; i < 3; ++i) { if (ra) launch_conv(A.a, s1); if (rb) launch_conv(B.a, s2); }
+      HIP_CHECK(hipDeviceSynchronize());
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < reps; ++i) { if (ra) launch_conv(A.a, s1); if (rb) launch_conv(B.a, s2); }
+      HIP_CHECK(hipStreamSynchronize(s1));
+      HIP_CHECK(hipStreamSynchronize(s2));
+      return (float)(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps);
+    };
+    us_out[0] = run(true, false);
+    us_out[1] = run(false, true);
+    us_out[2] = run(true, true);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(f0); (void)hipEventDestroy(f1);
+    (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2);
+    for (BenchConv* c : {&A, &B}) { (void)hipFree(c->x); (void)hipFree(c->y); (void)hipFree(c->w); (void)hipFree(c->bias); }
   });
 }
 

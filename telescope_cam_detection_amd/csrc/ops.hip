@@ -12,11 +12,7 @@ namespace rtd {
 template <typename T> __device__ __forceinline__ float ldf(const T* p) { return (float)(*p); }
 template <typename T> __device__ __forceinline__ void stf(T* p, float v) { *p = (T)v; }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum64(v); }
 
 static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
