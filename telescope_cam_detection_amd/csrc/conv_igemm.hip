@@ -41,6 +41,7 @@ struct ConvK {
   int ntn;
   const void* pf;        // prefetch target (next layer's filter) or nullptr
   unsigned pf_bytes;
+  int reg_epi;           // 1: the ws kernels may finish residual-free bf16 tiles in registers (A/B: rtd_debug_option "reg_epilogue")
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -719,6 +720,28 @@ __global__ __launch_bounds__(256, (STAGES == 2 ? 2 : 1)) void conv_igemm_glds_ke
   }
 }
 
+__device__ __forceinline__ bool g_reg_epilogue_ok(const ConvK& a) { return a.res_mode == RES_NONE && !a.y_f32 && a.reg_epi; }
+
+// Copy-out of a tile that is already final (bias + activation applied in the MFMA waves' registers, bf16 rows in LDS): pure
+// 16-byte LDS -> global moves, 32 rows apart per iteration.
+template <int ITERS>
+__device__ __forceinline__ void ws_copy_out_bf16(const ConvK& a, const bf16* sb, int SLB, int tid, int m0, int n0) {
+  const int c8 = tid & 15;
+  const int c = n0 + c8 * 8;
+  if (c >= a.N) return;
+  int m = m0 + (tid >> 4);
+  const int b = m / a.OHW;
+  int p = m - b * a.OHW;
+  long long yoff = (long long)b * a.y_bstride + (long long)p * a.ldy + c;
+  const bf16* srow = sb + (tid >> 4) * SLB + c8 * 8;
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    if (m < a.M) *(bf16x8*)((bf16*)a.y + yoff) = *(const bf16x8*)srow;
+    m += 32; p += 32; yoff += 32 * a.ldy; srow += 32 * SLB;
+    while (p >= a.OHW) { p -= a.OHW; yoff += a.y_bstride - (long long)a.OHW * a.ldy; }
+  }
+}
+
 // Copy-out of the wave-specialised kernels: staging tile (fp32, [rows][SLD]) -> bias (+ residual) -> activation -> y, 8 channels
 // (16 bytes of bf16) per thread and iteration, 32 rows apart.  The loop is instruction-bound (2 waves per SIMD walk it), so the
 // pixel -> (image, offset) division is done once and carried, and the activation is a template parameter.
@@ -1077,6 +1100,35 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
     __syncthreads();                               // the ticket word in smem is dead before staging overwrites it
   }
 
+  if (g_reg_epilogue_ok(a) && g.splitk == 1) {
+    // no residual, bf16 output: bias + activation on the accumulators, bf16 rows through LDS (half the staging bytes), then a
+    // plain copy-out - the fp32 staging + per-element epilogue was ~2 us of every launch
+    constexpr int SLB = BN + 8;
+    bf16* sb = (bf16*)smem;
+    if (!loader) {
+      const int h = lane >> 5;
+      dispatch_act(a.act, [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *(const f32x4*)(a.bias + n0 + wn * 64 + i * 32 + 8 * q + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int pl = wm * 64 + j * 32 + (lane & 31);
+              bf16x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (bf16)act_c<ACT>(acc[i][j][4 * q + e] + bv[e]);
+              *(bf16x4*)(sb + pl * SLB + wn * 64 + i * 32 + 8 * q + 4 * h) = o;
+            }
+          }
+      });
+    }
+    __syncthreads();
+    ws_copy_out_bf16<4>(a, sb, SLB, tid, m0, n0);
+    return;
+  }
   float* st = (float*)smem;
   if (!loader) {
     const int h = lane >> 5;
@@ -1309,6 +1361,8 @@ static int g_ws256_min_blocks = 0;   // auto dispatch: 256-pixel tiles from this
 void conv_set_ws256_min_blocks(int v) { g_ws256_min_blocks = v; }
 static int g_glds_min_n = 128;   // 64 measured slower on the stage-0 reduce convs (45 vs 42 us)
 void conv_set_glds_min_n(int v) { g_glds_min_n = v; }
+static int g_reg_epilogue = 1;
+void conv_set_reg_epilogue(int v) { g_reg_epilogue = v; }
 static int g_prefetch = 1;    // A/B hook (rtd_debug_option "prefetch"): 0 = no next-layer filter prefetch
 void conv_set_prefetch(int v) { g_prefetch = v; }
 template <typename T>
@@ -1631,6 +1685,7 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
   }
   k.act = a.act; k.res_mode = a.res_mode; k.y_f32 = y.dt == F32;
   k.ntn = 1;
+  k.reg_epi = g_reg_epilogue;
   k.pf = g_prefetch ? a.pf : nullptr;
   k.pf_bytes = (g_prefetch && a.pf && a.pf_bytes < (1ull << 31)) ? (unsigned)a.pf_bytes : 0u;
   const bool smallc = (x.c % 32) != 0;
