@@ -180,9 +180,9 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as fh:
                 pmc = json.load(fh)
             if dom == "conv_igemm" and args.arch == "r50" and B == 8 and H == 640 and args.precision == "bf16":
-                tb = pmc["conv_igemm_lds_dma"]["fetch_bytes_corrected"] + pmc["conv_igemm_lds_dma"]["write_bytes"] + \
-                     pmc["conv_igemm_v1"]["fetch_bytes_corrected"] + pmc["conv_igemm_v1"]["write_bytes"]
-                nl = pmc["conv_igemm_lds_dma"]["launches"] + pmc["conv_igemm_v1"]["launches"]
+                fams = [v for k, v in pmc.items() if isinstance(v, dict) and k.startswith("conv")]   # LDS-DMA, direct 3x3 and v1 kernels
+                tb = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in fams)
+                nl = sum(v["launches"] for v in fams)
                 out["roofline"]["traffic"] = round(tb / nl / 1e6, 2)
                 out["roofline"]["traffic_unit"] = "MB HBM per launch (PMC, profiles/r01_pmc_hbm_traffic.json)"
                 out["roofline"]["alg_mbytes_per_launch_unfused"] = round(d["bytes"] / d["launches"] / 1e6, 2)

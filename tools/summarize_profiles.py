@@ -13,6 +13,8 @@ import sys
 
 
 def family(name: str) -> str:
+    if "conv3x3_reg" in name:
+        return "conv3x3_direct"
     if "conv_igemm_ws" in name or "conv_igemm_glds" in name:
         return "conv_igemm_lds_dma"
     if "conv_igemm" in name:
@@ -46,8 +48,8 @@ def do_trace(path, out):
     tot = sum(v[0] for v in fam.values())
     ks = [dict(kernel=k, us_per_step=round(d / len(steps) / 1e3, 2), launches_per_step=c / len(steps), avg_us=round(d / c / 1e3, 3),
                pct=round(100 * d / tot, 2)) for k, (d, c) in sorted(fam.items(), key=lambda kv: -kv[1][0])]
-    conv = [k for k in ks if k["kernel"].startswith("conv_igemm")]
-    res = dict(command="rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-latency",
+    conv = [k for k in ks if k["kernel"].startswith("conv")]
+    res = dict(command="rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --streams 1 --no-cpu-baseline --no-latency",
                steady_graph_steps_used=len(steps), kernels_per_step=modal, step_span_ms_median=sorted(span)[len(span) // 2],
                conv_igemm_all=dict(us_per_step=round(sum(k["us_per_step"] for k in conv), 2), launches_per_step=sum(k["launches_per_step"] for k in conv),
                                    avg_us=round(sum(k["us_per_step"] for k in conv) / sum(k["launches_per_step"] for k in conv), 3)),
