@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""In-kernel s_memtime stamps of one conv layer (rtd_bench_conv with rtd_debug_option("glds_drop", 32)).
+
+    RTD_CONV_STAMPS=1 python tools/conv_stamps.py s1c2 ws256    # per-K-step stamps of the 256-pixel tile kernel (blocks 0, 1, 17)
+    RTD_CONV_STAMPS=2 python tools/conv_stamps.py s0c3          # block-level phases of the default 128-pixel ws kernels
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from telescope_cam_detection_amd import _capi
+
+SHAPES = {  # HW, Cin, Cout, k, stride, pad, residual
+    "s0c3": (160, 64, 256, 1, 1, 0, 1), "s1c3": (80, 128, 512, 1, 1, 0, 1), "s0sc": (160, 64, 256, 1, 1, 0, 0),
+    "fpn1": (80, 256, 256, 3, 1, 1, 0), "s1c1": (80, 512, 128, 1, 1, 0, 0), "s1c2": (80, 128, 128, 3, 1, 1, 0),
+    "lat": (20, 256, 256, 1, 1, 0, 0), "s3c2": (20, 512, 512, 3, 1, 1, 0),
+}
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "s1c2"
+    L = _capi.lib()
+    if "ws256" in sys.argv[2:]:
+        _capi.debug_option("conv_mode", 7)
+    _capi.debug_option("glds_drop", 32)
+    hw, cin, cout, k, st, pad, res = SHAPES[which]
+    out = (C.c_float * 2)()
+    rc = L.rtd_bench_conv(0, 8, hw, hw, cin, cout, k, st, pad, res, 3, 0, out)
+    print(which, "warm us per launch", round(out[0], 2), "rc", rc)
+
+
+if __name__ == "__main__":
+    main()
