@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--profile-out", default="")
+    ap.add_argument("--opt", action="append", default=[], help="rtd_debug_option name=value (A/B runs)")
     args = ap.parse_args()
 
     import numpy as np
@@ -82,6 +83,9 @@ def main():
     from telescope_cam_detection_amd.synth import noise_frame
     from telescope_cam_detection_amd.weights import fold_weights, pack_blob, synth_weights
 
+    for o in args.opt:
+        name, val = o.split("=")
+        _capi.debug_option(name, int(val))
     arch = ARCHS[args.arch]
     B, H = args.batch, args.size
     w = synth_weights(arch, 0)

@@ -60,7 +60,7 @@ __device__ __forceinline__ void prefetch_share(const ConvK& a, unsigned block, u
 
 // the activation is a kernel argument: the epilogue loops are instantiated once per activation (dispatch_act) so that the
 // choice costs one scalar branch per block - as a per-element switch (8 scalar branches around each of a thread's 32-64 outputs)
-// it was 4.5 us of a 20 us launch (s_memtime stamps, tools/_bin/stamp_run.py)
+// it was 4.5 us of a 20 us launch (s_memtime stamps, tools/conv_stamps.py)
 template <int A> struct ActC { static constexpr int value = A; };
 template <int ACT> __device__ __forceinline__ float act_c(float v) {
   if (ACT == ACT_RELU) return fmaxf(v, 0.f);
@@ -1361,6 +1361,8 @@ static int g_ws256_min_blocks = 0;   // auto dispatch: 256-pixel tiles from this
 void conv_set_ws256_min_blocks(int v) { g_ws256_min_blocks = v; }
 static int g_glds_min_n = 128;   // 64 measured slower on the stage-0 reduce convs (45 vs 42 us)
 void conv_set_glds_min_n(int v) { g_glds_min_n = v; }
+static int g_ws2_min_blocks = 257;   // grids that do not fit one block per CU run the 2-stage kernel at 2 blocks per CU (A/B: 512 was 2 % slower; "ws2_min_blocks")
+void conv_set_ws2_min_blocks(int v) { g_ws2_min_blocks = v; }
 static int g_reg_epilogue = 1;
 void conv_set_reg_epilogue(int v) { g_reg_epilogue = v; }
 static int g_prefetch = 1;    // A/B hook (rtd_debug_option "prefetch"): 0 = no next-layer filter prefetch
@@ -1412,7 +1414,7 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
     }
     g.splitk = sk; g.slab = ws.slab; g.cnt = ws.cnt;
     const long long blocks = tiles * sk;
-    if (blocks < 512) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)blocks), dim3(512), 0, s, g);
+    if (blocks < g_ws2_min_blocks) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)blocks), dim3(512), 0, s, g);
     else hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)blocks), dim3(512), 0, s, g);
     return true;
   }

@@ -1322,6 +1322,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "dec_split") == 0) { g_dec_split = value; return RTD_OK; }
   if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
   if (strcmp(name, "prefetch") == 0) { conv_set_prefetch(value); return RTD_OK; }
+  if (strcmp(name, "ws2_min_blocks") == 0) { conv_set_ws2_min_blocks(value); return RTD_OK; }
   if (strcmp(name, "reg_epilogue") == 0) { conv_set_reg_epilogue(value); return RTD_OK; }
   if (strcmp(name, "glds_min_n") == 0) { conv_set_glds_min_n(value); return RTD_OK; }
   if (strcmp(name, "conv_reg") == 0) { conv_set_reg(value); return RTD_OK; }
