@@ -133,6 +133,13 @@ struct FrameArgs {
 };
 void launch_preprocess_identity(const FrameArgs& fa, int H, int W, const Tensor& y, float* scale_wh_dev, hipStream_t s);
 void launch_set_scale(const FrameArgs& fa, float* scale_wh_dev, hipStream_t s);
+// fused uint8 stem (bf16 engine): the per-call frame pointers are written to a DEVICE table by a tiny launch outside the
+// hipGraph; the captured stem kernel reads its frames through that table (fixed address, per-call contents)
+void launch_set_frame_table(const FrameArgs& fa, const uint8_t** table_dev, float* scale_wh_dev, hipStream_t s);
+// backbone.stem.0 straight from HWC uint8 BGR frames: BGR->RGB, /255, bf16, 3x3 stride-2 conv (K = 27 padded to 32, two
+// MFMA steps), bias + activation; w = the packed [Npad][Kpad] filter with k = tap * 8 + channel (Cin padded 3 -> 8)
+void launch_stem0_u8(const uint8_t* const* table_dev, int n, int H, int W, const void* w, int Kpad, const float* bias, const Tensor& y, int act,
+                     hipStream_t s);
 // device-resident coefficient tables of one (src size -> dst size) PIL resize
 struct ResizeCoef {
   const int32_t* hb;  // [dw][2] xmin, count
@@ -143,6 +150,7 @@ struct ResizeCoef {
 };
 void launch_resize_pil(const uint8_t* src, int sh, int sw, uint8_t* tmp, const Tensor& y, int image, const ResizeCoef& coef,
                        hipStream_t s);
+void launch_resize_pil_u8(const uint8_t* src, int sh, int sw, uint8_t* tmp, uint8_t* dst, int dh, int dw, const ResizeCoef& c, hipStream_t s);
 // ---- fused decoder layer (decoder.hip) ----
 struct DecLin {
   // DecArgs::split == 0: fragment-major fp32: [tile = n/16][chunk = k/16][lane 0..63][4] = W[16 tile + (lane & 15)][16 chunk + 4 (lane >> 4) + j]

@@ -27,6 +27,9 @@ namespace {
 thread_local std::string g_create_error;
 int g_dec_stamps = 0;  // plan-build switch: record per-phase stamps of decoder layer 2 into debug tensor "dec_stamps"
 int g_dec_split = 1;   // plan-build switch (rtd_debug_option "dec_split"): bf16 engine runs the fused decoder / AIFI linears as bf16 hi/lo splits
+int g_stem_fused = 0;  // plan-build switch (rtd_debug_option "stem_fused"): bf16 engine runs backbone.stem.0 straight from the uint8 frames.
+                       // Measured neutral (same-box A/B: +0.2 % / 0 %: the kernel is latency-bound at 44 us against 56 + 20 us of
+                       // preprocess + generic stem) -> off by default, kept tested
 int g_sel_fused = 1;   // plan-build switch (rtd_debug_option "sel_fused"): LayerNorm + score head + class max of the query selection in one launch
 int g_dec_fused = 1;   // plan-build switch (rtd_debug_option "dec_fused"): 0 = one launch per decoder op
 
@@ -60,6 +63,8 @@ struct Plan {
   std::vector<Op> ops;
   std::map<std::string, Tensor> named;
   Tensor input;            // [n,H,W,8]
+  const uint8_t** frame_table = nullptr;   // fused uint8 stem: device table of the n frame pointers of the current call
+  bool stem_fused = false;
   float* block6 = nullptr; // [n,Q,6]
   float* scale_wh = nullptr;
   int32_t* tk_idx = nullptr;
@@ -91,6 +96,8 @@ struct rtd_engine {
   // per-call staging
   uint8_t* frame_stage = nullptr; size_t frame_stage_bytes = 0;
   uint8_t* resize_tmp = nullptr; size_t resize_tmp_bytes = 0;
+  uint8_t* u8_stage = nullptr;             // fused uint8 stem: resized frames, max_batch x H x W x 3
+  FrameArgs last_fa;                       // frame table of the last call (rtd_debug_tensor("input") re-runs the preprocess from it)
   float* block_host = nullptr;
   int32_t* forced_idx = nullptr; int32_t* force_flag = nullptr;
   // geometry
@@ -450,7 +457,20 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   const int eh = c.embedding_size / 2;
   int h = down2(H), w = down2(W);
   Tensor s0 = B.act(P, n, h, w, eh);
-  B.conv("backbone.stem.0", x, s0, 3, 2, 1, ACT_RELU, nullptr, RES_NONE, 3);
+  plan->stem_fused = g_stem_fused && P == BF16 && eh == 32;
+  if (plan->stem_fused) {
+    // straight from the uint8 frames (ops.hip stem0_u8_kernel); `x` is only materialised on demand for rtd_debug_tensor("input")
+    const uint8_t** table = (const uint8_t**)B.alloc((size_t)c.max_batch * sizeof(void*));
+    plan->frame_table = table;
+    if (!B.dry) {
+      DevWeight w0 = get_weight(e, "backbone.stem.0", P, eh, 9 * 8);
+      const void* wp = w0.w; const float* bp = w0.bias; const int kp = w0.Kpad;
+      B.push("backbone.stem.0", "conv_igemm", 2.0 * n * h * w * eh * 27.0, (double)n * H * W * 3 + Builder::tbytes(s0),
+             [table, n, H, W, wp, kp, bp, s0](hipStream_t st) { launch_stem0_u8(table, n, H, W, wp, kp, bp, s0, ACT_RELU, st); });
+    }
+  } else {
+    B.conv("backbone.stem.0", x, s0, 3, 2, 1, ACT_RELU, nullptr, RES_NONE, 3);
+  }
   Tensor s1 = B.act(P, n, h, w, eh);
   B.conv("backbone.stem.1", s0, s1, 3, 1, 1, ACT_RELU);
   Tensor s2 = B.act(P, n, h, w, c.embedding_size);
@@ -895,7 +915,7 @@ void enqueue_frames(rtd_engine* e, Plan* p, int n, const uint8_t* const* frames,
   // one frame of another size sends EVERY frame of the batch through the resampler (identity-sized ones with 1-tap
   // coefficients): the horizontal pass' intermediate [src_h][W][3] must fit the largest of them, not only the resized ones
   if (any_resize)
-    for (int i = 0; i < n; ++i) max_tmp = std::max(max_tmp, (size_t)hw[2 * i] * W * 3);
+    for (int i = 0; i < n; ++i) max_tmp = std::max(max_tmp, (size_t)hw[2 * i] * W * 3);   // (the fused uint8 stem resamples only the odd-sized ones)
   if (!on_device && total > e->frame_stage_bytes) {
     HIP_CHECK(hipStreamSynchronize(e->stream));
     if (e->frame_stage) (void)hipFree(e->frame_stage);
@@ -927,6 +947,20 @@ void enqueue_frames(rtd_engine* e, Plan* p, int n, const uint8_t* const* frames,
     fa.scale_wh[2 * i] = (float)hw[2 * i + 1];      // orig_size = [w, h]  (src/rtdetr_detector.py:234)
     fa.scale_wh[2 * i + 1] = (float)hw[2 * i];
     if (hw[2 * i] != H || hw[2 * i + 1] != W) all_identity = false;
+  }
+  if (p->stem_fused) {
+    // frames of the network's size are read in place; the others are resampled (PIL-exact, uint8) into the staging slots
+    if (!all_identity && !e->u8_stage) HIP_CHECK(hipMalloc((void**)&e->u8_stage, (size_t)e->cfg.max_batch * H * W * 3));
+    for (int i = 0; i < n; ++i) {
+      if (hw[2 * i] == H && hw[2 * i + 1] == W) continue;
+      const ResizeCoef& rc = resize_tables(e, hw[2 * i], hw[2 * i + 1]);
+      uint8_t* dst = e->u8_stage + (size_t)i * H * W * 3;
+      launch_resize_pil_u8(fa.ptr[i], hw[2 * i], hw[2 * i + 1], e->resize_tmp, dst, H, W, rc, e->stream);
+      fa.ptr[i] = dst;
+    }
+    launch_set_frame_table(fa, p->frame_table, p->scale_wh, e->stream);
+    e->last_fa = fa;
+    return;
   }
   if (all_identity) {
     launch_preprocess_identity(fa, H, W, p->input, p->scale_wh, e->stream);
@@ -1191,6 +1225,7 @@ void rtd_destroy(rtd_handle h) {
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->frame_stage) (void)hipFree(h->frame_stage);
     if (h->resize_tmp) (void)hipFree(h->resize_tmp);
+    if (h->u8_stage) (void)hipFree(h->u8_stage);
     if (h->block_host) (void)hipHostFree(h->block_host);
     if (h->stream) (void)hipStreamDestroy(h->stream);
   }
@@ -1204,6 +1239,10 @@ int rtd_debug_tensor(rtd_handle h, const char* name, float* out, int64_t capacit
     auto it = p->named.find(name);
     RTD_CHECK(it != p->named.end(), RTD_E_INVALID, std::string("unknown debug tensor ") + name);
     const Tensor& t = it->second;
+    if (p->stem_fused && strcmp(name, "input") == 0 && out) {      // the fused stem never wrote it: run the stand-alone preprocess now
+      HIP_CHECK(hipSetDevice(h->cfg.device));
+      launch_preprocess_identity(h->last_fa, h->cfg.input_h, h->cfg.input_w, p->input, p->scale_wh, h->stream);
+    }
     shape[0] = t.n; shape[1] = t.h; shape[2] = t.w; shape[3] = t.c;
     const int64_t numel = t.pixels() * t.c;
     if (!out) return;
@@ -1254,6 +1293,19 @@ int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int3
     const int nops = (int)p->ops.size();
     *count = nops;
     if (!out) return;
+    if (p->stem_fused && (h->last_n != n || h->last_fa.n != n)) {
+      // the fused stem reads its frames through the device table: without a preceding forward of this batch size point it at
+      // zero-filled staging frames (timings do not depend on pixel values)
+      const size_t fb = (size_t)h->cfg.input_h * h->cfg.input_w * 3;
+      if (!h->u8_stage) HIP_CHECK(hipMalloc((void**)&h->u8_stage, (size_t)h->cfg.max_batch * fb));
+      HIP_CHECK(hipMemsetAsync(h->u8_stage, 0, (size_t)h->cfg.max_batch * fb, h->stream));
+      FrameArgs fa;
+      memset(&fa, 0, sizeof fa);
+      fa.n = n;
+      for (int i = 0; i < n; ++i) { fa.ptr[i] = h->u8_stage + (size_t)i * fb; fa.scale_wh[2 * i] = (float)h->cfg.input_w; fa.scale_wh[2 * i + 1] = (float)h->cfg.input_h; }
+      launch_set_frame_table(fa, p->frame_table, p->scale_wh, h->stream);
+      h->last_fa = fa;
+    }
     RTD_CHECK(capacity >= nops, RTD_E_INVALID, "profile: capacity too small");
     std::vector<hipEvent_t> ev((size_t)nops + 1);
     for (auto& x : ev) HIP_CHECK(hipEventCreate(&x));
@@ -1319,6 +1371,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "dec_stamps") == 0) { g_dec_stamps = value; return RTD_OK; }
   if (strcmp(name, "dec_fused") == 0) { g_dec_fused = value; return RTD_OK; }
   if (strcmp(name, "sel_fused") == 0) { g_sel_fused = value; return RTD_OK; }
+  if (strcmp(name, "stem_fused") == 0) { g_stem_fused = value; return RTD_OK; }
   if (strcmp(name, "dec_split") == 0) { g_dec_split = value; return RTD_OK; }
   if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
   if (strcmp(name, "prefetch") == 0) { conv_set_prefetch(value); return RTD_OK; }

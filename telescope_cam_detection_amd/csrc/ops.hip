@@ -837,6 +837,158 @@ void launch_resize_pil(const uint8_t* src, int sh, int sw, uint8_t* tmp, const T
 }
 
 
+__global__ void k_set_frame_table(const FrameArgs fa, const uint8_t** __restrict__ table, float* __restrict__ scale_wh) {
+  const int i = threadIdx.x;
+  if (i < 2 * fa.n) scale_wh[i] = fa.scale_wh[i];
+  if (i < fa.n) table[i] = fa.ptr[i];
+}
+void launch_set_frame_table(const FrameArgs& fa, const uint8_t** table_dev, float* scale_wh_dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_frame_table, dim3(1), dim3(2 * RTD_MAX_BATCH), 0, s, fa, table_dev, scale_wh_dev);
+  HIP_CHECK(hipGetLastError());
+}
+
+// vertical pass of the PIL resampler with a uint8 HWC result in the SOURCE channel order (the fused stem does BGR->RGB itself)
+__global__ void k_resize_v_u8(const uint8_t* __restrict__ tmp, int sh, int dw, uint8_t* __restrict__ y, int dh, ResizeCoef c) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)dh * dw) return;
+  const int yy = (int)(i / dw), x = (int)(i - (int64_t)yy * dw);
+  const int ymin = c.vb[yy * 2], cnt = c.vb[yy * 2 + 1];
+  const int32_t* k = c.vk + (int64_t)yy * c.vks;
+  int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+  for (int j = 0; j < cnt; ++j) {
+    const uint8_t* p = tmp + ((int64_t)(ymin + j) * dw + x) * 3;
+    s0 += (int)p[0] * k[j];
+    s1 += (int)p[1] * k[j];
+    s2 += (int)p[2] * k[j];
+  }
+  uint8_t* o = y + i * 3;
+  o[0] = (uint8_t)clip8(s0); o[1] = (uint8_t)clip8(s1); o[2] = (uint8_t)clip8(s2);
+}
+void launch_resize_pil_u8(const uint8_t* src, int sh, int sw, uint8_t* tmp, uint8_t* dst, int dh, int dw, const ResizeCoef& c, hipStream_t s) {
+  hipLaunchKernelGGL(k_resize_h, dim3(blocks_for((int64_t)sh * dw, 256)), dim3(256), 0, s, src, sh, sw, tmp, dw, c);
+  hipLaunchKernelGGL(k_resize_v_u8, dim3(blocks_for((int64_t)dh * dw, 256)), dim3(256), 0, s, tmp, sh, dw, dst, dh, c);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- backbone.stem.0 from uint8 frames -------------------------------------------------------------------------------------
+// The generic path writes every frame as bf16 NHWC with 3 -> 8 channel padding (16 bytes per pixel: 52 MB at 640^2 bs 8) and the
+// stem conv reads it back with K = 72 of which 27 taps are real.  Here a block stages the (2*8+1) x (2*32+1) pixel uint8 patch of
+// its 8 x 32 output tile (3.3 KB), every lane gathers the 27 real taps of its output pixel as bytes, converts them exactly like
+// the preprocess kernel ((T)(v / 255.0f)) and feeds two v_mfma_f32_32x32x16_bf16 steps (K = 32).  HBM: 3 bytes per input pixel.
+typedef __bf16 bf16x8_s __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_s __attribute__((ext_vector_type(4)));
+typedef float f32x16_s __attribute__((ext_vector_type(16)));
+typedef float f32x4_s __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __restrict__ table, int H, int W, const bf16* __restrict__ wq, int Kpad,
+                                                        const float* __restrict__ bias, bf16* __restrict__ y, long long y_bstride, long long ldy,
+                                                        int OH, int OW, int tiles_x, int tiles_y, int act) {
+  constexpr int TH = 8, TW = 32, PR = 2 * TH + 1, PC = 2 * TW + 1, ROWE = 200;        // 65 px * 3 = 195 elements per patch row -> 200
+  constexpr int NDW = (PC * 3 + 3 + 3) / 4;                                            // aligned dwords that cover one patch row
+  constexpr int ROWO = 64 + 16;                                                        // store slab row: 32 bf16 + skew
+  __shared__ __attribute__((aligned(16))) bf16 patch[PR * ROWE];                        // already normalised: (bf16)(v / 255.0f)
+  __shared__ __attribute__((aligned(16))) char stage[4][32 * ROWO];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int b = t / tiles_y;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const uint8_t* __restrict__ f = table[b];
+  const long long fbytes = (long long)H * W * 3;
+  const bool aligned4 = (((uintptr_t)f) & 3) == 0;
+  // patch: input rows 2*y0-1 .. 2*y0+15, cols 2*x0-1 .. 2*x0+63; zero outside the frame (the conv's zero padding of the
+  // normalised image).  One aligned dword of the frame per thread and step, each byte converted ONCE.
+  for (int e = tid; e < PR * NDW; e += 256) {
+    const int r = e / NDW, d = e - r * NDW;
+    const int iy = 2 * y0 - 1 + r;
+    const long long g0 = ((long long)iy * W + (2 * x0 - 1)) * 3;                       // frame byte of patch element (r, 0); may be < 0
+    const long long a0 = (g0 & ~3ll) + 4ll * d;                                         // this thread's aligned dword
+    unsigned dw = 0;
+    const bool row_ok = (unsigned)iy < (unsigned)H;
+    if (row_ok) {
+      if (aligned4 && a0 >= 0 && a0 + 4 <= fbytes) dw = *(const unsigned*)(f + a0);
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (a0 + q >= 0 && a0 + q < fbytes) dw |= (unsigned)f[a0 + q] << (8 * q);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int el = (int)(a0 + q - g0);                                                // element index inside the patch row
+      if (el < 0 || el >= PC * 3) continue;
+      const int ix = 2 * x0 - 1 + el / 3;
+      const float v = (row_ok && (unsigned)ix < (unsigned)W) ? (float)((dw >> (8 * q)) & 0xffu) : 0.f;
+      patch[r * ROWE + el] = (bf16)(v / 255.0f);
+    }
+  }
+  // filter fragments: lane = output channel (lane & 31), k = 16 s + 8 (lane >> 5) + j with k = tap * 3 + c  (27 real, 5 zero)
+  bf16x8_s wf[2];
+  int off[2][8];                      // element offset of tap k inside the patch relative to the pixel's (2 r, 2 p) corner
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * s + 8 * h + j;
+      const int tap = k / 3, c = k - tap * 3;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      wf[s][j] = k < 27 ? wq[(size_t)(lane & 31) * Kpad + tap * 8 + c] : (bf16)0.f;    // zero filter taps: the pixel operand may be anything finite
+      off[s][j] = k < 27 ? kh * ROWE + kw * 3 + (2 - c) : 0;                            // model channel c (RGB) = frame byte 2 - c (BGR)
+    }
+  __syncthreads();
+#pragma unroll 1
+  for (int rr = 0; rr < 2; ++rr) {
+    const int r = wv * 2 + rr;
+    const bf16* base = patch + (2 * r) * ROWE + (2 * (lane & 31)) * 3;
+    f32x16_s acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_s xf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xf[j] = base[off[s][j]];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], xf, acc, 0, 0, 0);
+    }
+    const int oy = y0 + r;
+    char* sw_ = stage[wv];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4_s bv = *(const f32x4_s*)(bias + 8 * q + 4 * h);
+      bf16x4_s o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[4 * q + e] + bv[e];
+        if (act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == ACT_SILU) v = v / (1.f + __expf(-v));
+        o[e] = (bf16)v;
+      }
+      *(bf16x4_s*)(sw_ + (lane & 31) * ROWO + (8 * q + 4 * h) * 2) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (oy < OH) {
+      bf16* yrow = y + (long long)b * y_bstride + ((long long)oy * OW + x0) * ldy;
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) {
+        const int idx = i2 * 64 + lane;
+        const int p = idx >> 2, ch = idx & 3;
+        if (x0 + p < OW) *(bf16x8_s*)(yrow + (long long)p * ldy + ch * 8) = *(const bf16x8_s*)(sw_ + p * ROWO + ch * 16);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+void launch_stem0_u8(const uint8_t* const* table_dev, int n, int H, int W, const void* w, int Kpad, const float* bias, const Tensor& y, int act,
+                     hipStream_t s) {
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  RTD_CHECK(y.dt == BF16 && y.c == 32 && y.h == OH && y.w == OW && y.n >= n && y.ld % 8 == 0 && (act == ACT_RELU || act == ACT_NONE || act == ACT_SILU), 1,
+            "stem0_u8: output must be bf16 [n, H/2, W/2, 32]");
+  const int tiles_x = (OW + 31) / 32, tiles_y = (OH + 7) / 8;
+  hipLaunchKernelGGL(stem0_u8_kernel, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, table_dev, H, W, (const bf16*)w, Kpad, bias, (bf16*)y.p,
+                     (long long)y.bstride, (long long)y.ld, OH, OW, tiles_x, tiles_y, act);
+  HIP_CHECK(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------ Stage-2 crop batcher
 // SpeciesClassifier.preprocess (/root/reference/src/species_classifier.py:298-352) for a whole batch of crops in one
 // launch: slice frame[y1:y2, x1:x2] (src/two_stage_pipeline_yolox.py:289), BGR->RGB, bilinear resize to S x S with

@@ -263,3 +263,33 @@ def test_mixed_frame_sizes_go_through_the_resampler_like_the_oracle(shapes):
     for b in range(len(frames)):
         assert np.abs(np.sort(scores[b])[::-1][:10] - np.sort(osc[b].numpy())[::-1][:10]).max() < 1e-3
     eng.close()
+
+
+def test_fused_uint8_stem_matches_the_generic_preprocess_plus_conv():
+    """rtd_debug_option("stem_fused", 1): backbone.stem.0 reads the uint8 frames itself (identity-sized frames in place, others
+    through the uint8 resampler).  Same arithmetic per element, other summation order: detections agree to bf16 noise, and the
+    on-demand "input" tensor is the stand-alone preprocess of the same frames."""
+    from telescope_cam_detection_amd import _capi
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.synth import scene_frame
+    from telescope_cam_detection_amd.weights import fold_weights, pack_blob, synth_weights
+
+    arch = ARCHS["r18"]
+    w = synth_weights(arch, 3)
+    blob = pack_blob(fold_weights(arch, w))
+    frames = [scene_frame(70, 640, 640), scene_frame(71, 480, 600), scene_frame(72, 640, 640)]
+    out = {}
+    try:
+        for fused in (0, 1):
+            _capi.debug_option("stem_fused", fused)
+            eng = _capi.Engine(arch, blob, 0, _capi.PREC_BF16, 3, (640, 640), True)
+            for _ in range(2):
+                out[fused] = eng.infer_raw(frames)
+            out[("input", fused)] = eng.debug_tensor("input")[:, :, :, :3]
+            eng.close()
+    finally:
+        _capi.debug_option("stem_fused", 0)
+    np.testing.assert_array_equal(out[("input", 0)], out[("input", 1)])
+    for b in range(len(frames)):
+        m, n, ws, wb = match_detections(out[0][0][b], out[0][1][b], out[0][2][b], out[1][0][b], out[1][1][b], out[1][2][b], 2e-2, 2.0)
+        assert m >= n - 30, (b, m, n, ws, wb)
