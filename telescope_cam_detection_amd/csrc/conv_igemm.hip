@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws256_kernel(const ConvG g)
 int conv_kpad(int K) { return (K + 63) / 64 * 64; }
 int conv_npad(int N) { return (N + 127) / 128 * 128; }
 
-static int g_glds_min_blocks = 40;    // bf16: the LDS-DMA tile wins down to ~40 blocks (measured); fp32 GEMMs: 512
+static int g_glds_min_blocks = 4;     // bf16: the wave-specialised LDS-DMA tile beats the register-staged kernels down to a handful of tiles (bs 1: 3.03 -> 2.36 ms per frame vs the old threshold of 40); fp32 GEMMs: 512
 // In-launch split-K is implemented and correct (op tests run it) but OFF: on R50 bs8 it made every 100-200 tile layer
 // 1.3-2x SLOWER (tools/profile_layers.py --ab splitk: 28 -> 56 us on the 3x3 256ch convs): publishing a 64 KiB fp32 slab per
 // block behind an agent-scope release costs more than the shorter K loop saves (MI355X guide: splitk-seam 5-13 us).
