@@ -1348,7 +1348,7 @@ static int g_glds_min_blocks = 4;     // bf16: the wave-specialised LDS-DMA tile
 // In-launch split-K is implemented and correct (op tests run it) but OFF: on R50 bs8 it made every 100-200 tile layer
 // 1.3-2x SLOWER (tools/profile_layers.py --ab splitk: 28 -> 56 us on the 3x3 256ch convs): publishing a 64 KiB fp32 slab per
 // block behind an agent-scope release costs more than the shorter K loop saves (MI355X guide: splitk-seam 5-13 us).
-static int g_splitk_enable = 0;       // A/B hook (rtd_debug_option "splitk")
+static int g_splitk_enable = 1;       // rtd_debug_option "splitk": 0 off, 1 auto (tiny grids with long K only), 2 aggressive (every grid < 512 tiles)
 static int g_glds_drop = 0;           // timing-only probe: 1 = x descriptor has 0 records, 2 = w, 3 = both (results wrong)
 static int g_conv_mode = 0;   // 0 auto, 1 = v1 only, 2 = v1 + v2 (no LDS-DMA path)
 static int g_force_v1 = 0;   // test / A-B hook (rtd_debug_option "conv_v1"): keep every layer on the v1 kernels
@@ -1407,8 +1407,12 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
     // small grids leave CUs idle and run long serial K loops: split K so that ~600 blocks exist (>= 4 K-steps per slice)
     int sk = 1;
     if (g_splitk_enable && ws.slab && tiles < 512) {
-      sk = (int)((600 + tiles - 1) / tiles);
-      sk = std::min(sk, std::min(8, nk / 4));
+      if (g_splitk_enable == 2) {                 // aggressive (tests / A-B): ~600 blocks, >= 4 K-steps per slice
+        sk = (int)((600 + tiles - 1) / tiles);
+        sk = std::min(sk, std::min(8, nk / 4));
+      } else if (tiles <= 32 && nk >= 16) {       // auto: only the handful-of-tiles, long-K layers of bs 1-2 (s3 3x3: 16 tiles x 72 steps)
+        sk = std::min(8, std::min((int)(192 / tiles), nk / 8));
+      }
       sk = std::max(sk, 1);
       if ((size_t)tiles * sk * (128 * 128 * 4) > ws.slab_bytes || (size_t)tiles > ws.cnt_entries) sk = 1;
     }

@@ -85,7 +85,7 @@ def test_conv(L, dt, case):
     bd = b.cuda()
     rd = nhwc(res, tdt) if res is not None else None
     from telescope_cam_detection_amd import _capi
-    _capi.debug_option("splitk", 1)        # exercise the in-launch split-K reduction on the small-grid shapes (default off: slower)
+    _capi.debug_option("splitk", 2)        # exercise the in-launch split-K reduction on every small-grid shape (default: tiny grids only)
     # conv_mode 0 = auto (LDS-DMA kernel where eligible), 2 = register-staged large tile, 1 = small tiles only,
     # 3 / 4 = wave-specialised LDS-DMA kernel (4 / 2 stages), 5 = single-role LDS-DMA kernel, 6 = wave-specialised with
     # whole-K-step fragment prefetch, 7 = wave-specialised 256-pixel tile
@@ -105,7 +105,7 @@ def test_conv(L, dt, case):
             tol = dict(atol=2e-2, rtol=1e-2)       # + one bf16 rounding of the output
         torch.testing.assert_close(got, y, **tol)
     _capi.debug_option("conv_mode", 0)
-    _capi.debug_option("splitk", 0)
+    _capi.debug_option("splitk", 1)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
