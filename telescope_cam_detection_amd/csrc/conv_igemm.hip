@@ -1348,7 +1348,8 @@ static int g_glds_min_blocks = 4;     // bf16: the wave-specialised LDS-DMA tile
 // In-launch split-K is implemented and correct (op tests run it) but OFF: on R50 bs8 it made every 100-200 tile layer
 // 1.3-2x SLOWER (tools/profile_layers.py --ab splitk: 28 -> 56 us on the 3x3 256ch convs): publishing a 64 KiB fp32 slab per
 // block behind an agent-scope release costs more than the shorter K loop saves (MI355X guide: splitk-seam 5-13 us).
-static int g_splitk_enable = 1;       // rtd_debug_option "splitk": 0 off, 1 auto (tiny grids with long K only), 2 aggressive (every grid < 512 tiles)
+static int g_splitk_enable = 0;       // rtd_debug_option "splitk": 0 off (default), 1 auto (tiny grids with long K only: -3 % bs-1 latency, but a frame's
+                                      // results then depend on the batch size it ran in beyond bf16 noise), 2 aggressive (every grid < 512 tiles)
 static int g_glds_drop = 0;           // timing-only probe: 1 = x descriptor has 0 records, 2 = w, 3 = both (results wrong)
 static int g_conv_mode = 0;   // 0 auto, 1 = v1 only, 2 = v1 + v2 (no LDS-DMA path)
 static int g_force_v1 = 0;   // test / A-B hook (rtd_debug_option "conv_v1"): keep every layer on the v1 kernels

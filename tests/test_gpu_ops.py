@@ -105,7 +105,7 @@ def test_conv(L, dt, case):
             tol = dict(atol=2e-2, rtol=1e-2)       # + one bf16 rounding of the output
         torch.testing.assert_close(got, y, **tol)
     _capi.debug_option("conv_mode", 0)
-    _capi.debug_option("splitk", 1)
+    _capi.debug_option("splitk", 0)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
