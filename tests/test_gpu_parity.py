@@ -293,3 +293,36 @@ def test_fused_uint8_stem_matches_the_generic_preprocess_plus_conv():
     for b in range(len(frames)):
         m, n, ws, wb = match_detections(out[0][0][b], out[0][1][b], out[0][2][b], out[1][0][b], out[1][1][b], out[1][2][b], 2e-2, 2.0)
         assert m >= n - 30, (b, m, n, ws, wb)
+
+
+def test_non_square_input_with_partial_tiles_bf16_and_fp32():
+    """416 x 736 (multiples of 32, but 208 x 368 and 104 x 184 are not multiples of the 8 x 32 / 128-pixel tiles): every conv
+    kernel family meets ragged tiles.  fp32 engine vs oracle at the north-star tolerance, bf16 engine vs fp32 engine to bf16 noise."""
+    from oracle import rtdetr_oracle as orc
+    from telescope_cam_detection_amd import _capi
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.synth import scene_frame
+    from telescope_cam_detection_amd.weights import fold_weights, pack_blob, synth_weights
+
+    torch.set_num_threads(8)
+    arch = ARCHS["r18"]
+    w = synth_weights(arch, 4)
+    blob = pack_blob(fold_weights(arch, w))
+    size = (416, 736)
+    frames = [scene_frame(80 + i, size[0], size[1]) for i in range(3)]
+    xs, sizes = zip(*[orc.preprocess(f, size) for f in frames])
+    ol, ob, osc = orc.model_forward(arch, w, torch.cat(xs, 0), list(sizes))
+    res = {}
+    for prec in (_capi.PREC_FP32, _capi.PREC_BF16):
+        eng = _capi.Engine(arch, blob, 0, prec, 3, size, True)
+        for _ in range(2):
+            res[prec] = eng.infer_raw(frames)
+        eng.close()
+    for b in range(3):
+        l, bx, sc = (t[b] for t in res[_capi.PREC_FP32])
+        m, n, ws, wb = match_detections(ol[b].numpy(), ob[b].numpy(), osc[b].numpy(), l, bx, sc, 1e-3, 1e-2)
+        assert m == n, ("fp32", b, m, n, ws, wb)
+        l2, bx2, sc2 = (t[b] for t in res[_capi.PREC_BF16])
+        assert np.isfinite(bx2).all() and (np.diff(sc2) <= 0).all()
+        m, n, ws, wb = match_detections(l, bx, sc, l2, bx2, sc2, 3e-2, 4.0)
+        assert m >= n - 60, ("bf16", b, m, n, ws, wb)
