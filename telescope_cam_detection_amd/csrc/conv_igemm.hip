@@ -45,6 +45,7 @@ struct ConvK {
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
 // Touch `pf_bytes` at `pf` (one dword per 128-byte line, this block's share) with LDS-DMA into a 256-byte dummy: no VGPR is
 // written, nothing waits for the data; the lines land in this XCD's L2 and in the Infinity Cache.
 __device__ __forceinline__ void prefetch_share(const ConvK& a, unsigned block, unsigned nblocks, unsigned t, unsigned nthreads, char* dummy) {
@@ -514,6 +515,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvK a) {
 struct ConvG {
   ConvK k;
   unsigned x_bytes, w_bytes;   // extents of the two buffers from their base pointers (buffer descriptors)
+  unsigned y_bytes;            // extent of the output (A-stationary kernel: buffer stores), 0 = not provided
   int probe;                   // timing-only probes (results wrong): bit 2 = issue no DMA at all
   // split-K (ws kernel): grid = tiles x splitk; every slice publishes its fp32 accumulators to `slab`, the block that
   // draws the last ticket of a tile sums them and runs the epilogue
@@ -1341,6 +1343,199 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws256_kernel(const ConvG g)
   }
 }
 
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ------------------------------------------------------------------------------------------------
+// v4c: A-STATIONARY wave-specialised kernel for 1x1 convs / token GEMMs with a short K (<= 256) and many channel tiles
+// (the decoder's value projections: 67200 tokens x 256 -> 1536 = 12 channel tiles, 123 us as 6300 independent 4-step tiles).
+// A block loads its 128-pixel A tile ONCE (K/64 chunks, <= 64 KiB), then walks `npb` consecutive channel tiles: the loader waves
+// stream the filter tiles through a 3-stage ring without stopping at tile boundaries, the MFMA waves finish each channel tile
+// in registers (bias + activation -> bf16 -> a separate LDS slab -> 16-byte stores) while the ring refills behind them.
+// One s_barrier per K-step plus one per channel tile (slab written -> slab copied), executed by both roles.
+// Residual-free bf16 outputs only (the launch falls back to the independent-tile kernels otherwise).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NK>
+__global__ __launch_bounds__(512, 2) void conv_igemm_wsa_kernel(const ConvG g, int npb) {
+  // NK = K / (128 bytes): the A tile lives in the MFMA waves' REGISTERS (2 x 4 NK fragments = 32 NK VGPRs), which leaves the
+  // LDS to a 6-stage filter ring (5 tiles = 80 KiB in flight: with 2 in flight the K-step was 1060 cycles, DMA-latency bound)
+  const ConvK& a = g.k;
+  constexpr int BM = 128, BN = 128;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int BK = 128 / ES;
+  constexpr int STAGES = 6, AHEAD = 5;
+  constexpr int ACHUNK = BM * 128;                 // one 128-byte-of-K chunk of the A tile (staged through the ring once)
+  constexpr int BSTAGE = BN * 128;
+  constexpr int SLB = BN + 8;                      // bf16 slab row
+  constexpr int SLAB = BM * SLB * 2;
+  static_assert(NK * ACHUNK <= STAGES * BSTAGE, "the A tile is staged through the ring region");
+  typedef typename Mma<T>::Frag Frag;
+  constexpr int MAXNPB = 8;                        // channel tiles per block (launch: npb <= 8)
+  __shared__ __attribute__((aligned(16))) char smem[STAGES * BSTAGE + SLAB + MAXNPB * BN * 4 + 256];
+  char* const sB = smem;
+  bf16* const sb = (bf16*)(smem + STAGES * BSTAGE);
+  float* const sbias = (float*)(smem + STAGES * BSTAGE + SLAB);   // this block's bias slice (registers are full of A fragments)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wv >= 4;
+  const int w4 = wv & 3;
+  const int wm = w4 & 1, wn = w4 >> 1;
+  int wg;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int ngroups = (a.ntn + npb - 1) / npb;
+  const int grp = wg % ngroups, mt = wg / ngroups;
+  const int m0 = mt * BM;
+  const int nt0 = grp * npb;
+  const int nts = min(npb, a.ntn - nt0);           // channel tiles of this block
+  const int S = nts * NK;                          // filter tiles to stream
+
+  // diagnostic (glds_drop bit 5): [block][tile][0..3] = shader clocks at: K steps done, slab written (barrier passed), copy-out issued;
+  // [block][15][0] = A tile + first filter tile landed (loader wave 4)
+  long long* stamps = ((g.probe & 32) && g.slab && blockIdx.x < 64 && lane == 0) ? (long long*)g.slab + (size_t)blockIdx.x * 16 * 4 : nullptr;
+  const long long t_base = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  if (!loader) prefetch_share(a, blockIdx.x, gridDim.x, tid, 256, smem + STAGES * BSTAGE + SLAB + MAXNPB * BN * 4);
+
+  if (loader) {
+    const int lrow = w4 * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((w4 * 4 + (lane >> 4)) & 7);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
+    // A tile (1x1 / stride 1 / pad 0: pixel m reads row m of x) into the ring region, chunk c at c * 16 KiB
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + i * 32 + lrow;
+      unsigned vo = 0x80000000u;
+      if (m < a.M) {
+        const int b = m / a.OHW;
+        const int p = m - b * a.OHW;
+        vo = (unsigned)(((long long)b * a.x_bstride + (long long)p * a.ldx) * ES) + chunk * 16;
+      }
+#pragma unroll
+      for (int c = 0; c < NK; ++c)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sB + c * ACHUNK + w4 * 1024 + i * 4096), 16, m < a.M ? vo + c * 128 : vo, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                                // A tile visible
+    __builtin_amdgcn_s_barrier();                                                // ... and in the MFMA waves' registers: the ring is free
+    auto issue_b = [&](int s) {
+      const int nt = nt0 + s / NK, ks = s - (s / NK) * NK;
+      char* dst = sB + (s % STAGES) * BSTAGE + w4 * 1024;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + i * 4096), 16,
+                                                 (unsigned)(((nt * BN + i * 32 + lrow) * a.Kpad + ks * BK) * ES + chunk * 16), 0, 0, 0);
+    };
+    for (int s = 0; s < AHEAD && s < S; ++s) issue_b(s);
+    for (int s = 0; s < S; ++s) {
+      switch (min(AHEAD - 1, S - 1 - s)) {                                       // filter tiles issued after tile s that may stay in flight
+        case 4: wait_vmcnt<16>(); break;
+        case 3: wait_vmcnt<12>(); break;
+        case 2: wait_vmcnt<8>(); break;
+        case 1: wait_vmcnt<4>(); break;
+        default: wait_vmcnt<0>(); break;
+      }
+      if (stamps && wv == 4 && s == 0) stamps[15 * 4] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+      __builtin_amdgcn_s_barrier();
+      if (s + AHEAD < S) issue_b(s + AHEAD);
+      if ((s + 1) % NK == 0) __builtin_amdgcn_s_barrier();                       // channel-tile boundary: the MFMA waves' slab barrier
+    }
+  } else {
+    int foff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 128 + (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
+    const int h = lane >> 5;
+    // the block's A fragments, once
+    Frag xa[2][NK * 4];
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int c = 0; c < NK; ++c)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xa[j][c * 4 + kk] = *(const Frag*)(sB + c * ACHUNK + wm * 64 * 128 + j * 4096 + foff[kk]);
+    if (tid * 4 < nts * BN) *(f32x4*)(sbias + tid * 4) = *(const f32x4*)(a.bias + nt0 * BN + tid * 4);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nts; ++t) {
+      const int n0 = (nt0 + t) * BN;
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        const int s = t * NK + ks;
+        __builtin_amdgcn_s_barrier();
+        const char* sbt = sB + (s % STAGES) * BSTAGE + wn * 64 * 128;
+        Frag wf[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[0][i] = *(const Frag*)(sbt + i * 4096 + foff[0]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          if (kk < 3) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[(kk + 1) & 1][i] = *(const Frag*)(sbt + i * 4096 + foff[kk + 1]);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) Mma<T>::run(wf[kk & 1][i], xa[j][ks * 4 + kk], acc[i][j]);
+        }
+      }
+      // ---- this channel tile is complete: finish it in registers, slab, copy-out (the ring refills meanwhile) ----
+      if (stamps && wv == 0 && t < 12) stamps[t * 4 + 0] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+      dispatch_act(a.act, [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *(const f32x4*)(sbias + t * BN + wn * 64 + i * 32 + 8 * q + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int pl = wm * 64 + j * 32 + (lane & 31);
+              bf16x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (bf16)act_c<ACT>(acc[i][j][4 * q + e] + bv[e]);
+              *(bf16x4*)(sb + pl * SLB + wn * 64 + i * 32 + 8 * q + 4 * h) = o;
+            }
+          }
+      });
+      __builtin_amdgcn_s_barrier();                                              // slab complete (all four MFMA waves wrote it)
+      if (stamps && wv == 0 && t < 12) stamps[t * 4 + 1] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+      {
+        // copy-out by the 256 MFMA-role threads: 16 channel chunks x 16 rows per pass, 8 passes.  (Handing the copy to the loader
+        // waves, a few passes per K-step with exact-count buffer stores, was measured SLOWER: their stores and DMA issues share
+        // one vmcnt queue and the K-step went from 700 to 1140 cycles.)
+        const int c8 = tid & 15;
+        const int c = n0 + c8 * 8;
+        if (c < a.N) {
+          int m = m0 + (tid >> 4);
+          const int b = m / a.OHW;
+          int p = m - b * a.OHW;
+          long long yoff = (long long)b * a.y_bstride + (long long)p * a.ldy + c;
+          const bf16* srow = sb + (tid >> 4) * SLB + c8 * 8;
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            if (m < a.M) *(bf16x8*)((bf16*)a.y + yoff) = *(const bf16x8*)srow;
+            m += 16; p += 16; yoff += 16 * a.ldy; srow += 16 * SLB;
+            while (p >= a.OHW) { p -= a.OHW; yoff += a.y_bstride - (long long)a.OHW * a.ldy; }
+          }
+        }
+      }
+      if (stamps && wv == 0 && t < 12) stamps[t * 4 + 2] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+    }
+  }
+}
+
 int conv_kpad(int K) { return (K + 63) / 64 * 64; }
 int conv_npad(int N) { return (N + 127) / 128 * 128; }
 
@@ -1362,6 +1557,8 @@ static int g_ws256_min_blocks = 0;   // auto dispatch: 256-pixel tiles from this
 void conv_set_ws256_min_blocks(int v) { g_ws256_min_blocks = v; }
 static int g_glds_min_n = 128;   // 64 measured slower on the stage-0 reduce convs (45 vs 42 us)
 void conv_set_glds_min_n(int v) { g_glds_min_n = v; }
+static int g_wsa_min_ntn = 8;   // A-stationary kernel from this many channel tiles on (0 = never; 4 was slower on the 4-tile s1 shortcut); "wsa_min_ntn"
+void conv_set_wsa_min_ntn(int v) { g_wsa_min_ntn = v; }
 static int g_ws2_min_blocks = 257;   // grids that do not fit one block per CU run the 2-stage kernel at 2 blocks per CU (A/B: 512 was 2 % slower; "ws2_min_blocks")
 void conv_set_ws2_min_blocks(int v) { g_ws2_min_blocks = v; }
 static int g_reg_epilogue = 1;
@@ -1369,7 +1566,7 @@ void conv_set_reg_epilogue(int v) { g_reg_epilogue = v; }
 static int g_prefetch = 1;    // A/B hook (rtd_debug_option "prefetch"): 0 = no next-layer filter prefetch
 void conv_set_prefetch(int v) { g_prefetch = v; }
 template <typename T>
-static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long w_bytes, const ConvWorkspace& ws, hipStream_t s) {
+static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long w_bytes, unsigned y_bytes, const ConvWorkspace& ws, hipStream_t s) {
   if (!ok || g_conv_mode == 1 || g_conv_mode == 2) return false;     // 5 = single-role LDS-DMA kernels (v3) for A/B
   const long long mt = (k.M + 127) / 128, ntn = (k.N + 127) / 128;
   // fp32 GEMMs (query-selection heads) may use a partly empty N tile: N >= 64 still beats the small-tile kernel
@@ -1381,11 +1578,28 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
   g.k = k;
   g.k.ntn = (int)ntn;
   g.probe = g_glds_drop;
-  g.splitk = 1; g.slab = nullptr; g.cnt = nullptr;
+  g.splitk = 1; g.slab = nullptr; g.cnt = nullptr; g.y_bytes = 0;
   g.x_bytes = (g_glds_drop & 1) ? 0u : (unsigned)x_bytes;
   g.w_bytes = (g_glds_drop & 2) ? 0u : (unsigned)w_bytes;
   // grids that fill every CU twice run 2 blocks/CU with a 2-deep pipeline; smaller grids get the
   // whole LDS for one block and a 4-deep pipeline
+  if (sizeof(T) == 2 && g_wsa_min_ntn > 0 && (g_conv_mode == 0 || g_conv_mode == 8) && k.KH == 1 && k.KW == 1 && k.stride == 1 && k.pad == 0 &&
+      k.Kpad <= 256 && k.res_mode == RES_NONE && !k.y_f32 && y_bytes > 0 && ntn >= (g_conv_mode == 8 ? 1 : g_wsa_min_ntn)) {
+    // channel tiles per block: keep >= ~1000 blocks when the grid allows (two rounds of one block per CU ... four), never more than 8
+    int npb = (int)std::min<long long>(8, std::max<long long>(1, (mt * ntn) / 1024));
+    npb = std::max(npb, std::min<int>((int)ntn, 3));
+    npb = std::min<int>(npb, (int)ntn);
+    const long long groups = (ntn + npb - 1) / npb;
+    g.slab = ws.slab;
+    const dim3 grid((unsigned)(mt * groups));
+    g.y_bytes = y_bytes;
+    switch (k.Kpad / (128 / (int)sizeof(T))) {
+      case 1: hipLaunchKernelGGL((conv_igemm_wsa_kernel<T, 1>), grid, dim3(512), 0, s, g, npb); return true;
+      case 2: hipLaunchKernelGGL((conv_igemm_wsa_kernel<T, 2>), grid, dim3(512), 0, s, g, npb); return true;
+      case 4: hipLaunchKernelGGL((conv_igemm_wsa_kernel<T, 4>), grid, dim3(512), 0, s, g, npb); return true;
+      default: break;                             // K = 192: the independent-tile kernels
+    }
+  }
   {
     const long long mt256 = (k.M + 255) / 256;
     if (g_conv_mode == 7 || (g_conv_mode == 0 && g_ws256_min_blocks > 0 && mt256 * ntn >= g_ws256_min_blocks)) {
@@ -1442,7 +1656,6 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
 //   * bias + activation in registers, bf16 rows through a wave-private LDS slab, 16-byte stores along NHWC's channels.
 // Cin = 64 filters do not fit one wave's registers for 64 output channels: gridDim.y splits the channels into 32-wide groups.
 // ------------------------------------------------------------------------------------------------
-typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
 template <int CIN, int TN, int GROUPS>
 __global__ __launch_bounds__(256 * GROUPS, 2) void conv3x3_reg_kernel(const ConvK a, unsigned x_bytes, unsigned y_bytes, int tiles_x, int tiles_y, int ntiles) {
   // GROUPS = 32 TN-channel groups handled inside the block by different wave quartets (Cin = 64: the 64 output channels need
@@ -1706,8 +1919,10 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     const long long w_bytes = (long long)a.Npad * a.Kpad * es;
     done = dispatch_reg(k, a, x_bytes, s);
     if (!done) {
-      if (x.dt == BF16) done = dispatch_glds<bf16>(k, v2_ok, x_bytes, w_bytes, a.ws, s);
-      else done = dispatch_glds<float>(k, v2_ok, x_bytes, w_bytes, a.ws, s);
+      const long long yb = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * (long long)dtype_size(y.dt);
+      const unsigned y_bytes = yb < (1ll << 31) ? (unsigned)yb : 0u;
+      if (x.dt == BF16) done = dispatch_glds<bf16>(k, v2_ok, x_bytes, w_bytes, y_bytes, a.ws, s);
+      else done = dispatch_glds<float>(k, v2_ok, x_bytes, w_bytes, y_bytes, a.ws, s);
     }
   }
   if (!done) {

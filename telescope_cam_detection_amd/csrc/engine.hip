@@ -1375,6 +1375,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "dec_split") == 0) { g_dec_split = value; return RTD_OK; }
   if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
   if (strcmp(name, "prefetch") == 0) { conv_set_prefetch(value); return RTD_OK; }
+  if (strcmp(name, "wsa_min_ntn") == 0) { conv_set_wsa_min_ntn(value); return RTD_OK; }
   if (strcmp(name, "ws2_min_blocks") == 0) { conv_set_ws2_min_blocks(value); return RTD_OK; }
   if (strcmp(name, "reg_epilogue") == 0) { conv_set_reg_epilogue(value); return RTD_OK; }
   if (strcmp(name, "glds_min_n") == 0) { conv_set_glds_min_n(value); return RTD_OK; }
@@ -1484,7 +1485,15 @@ int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, in
       us_out[1] = tot * 1e3f / reps;
     }
     HIP_CHECK(hipDeviceSynchronize());
-    if (getenv("RTD_CONV_STAMPS") && atoi(getenv("RTD_CONV_STAMPS")) == 2) {      // block-level stamps of the 128-pixel ws kernels
+    if (getenv("RTD_CONV_STAMPS") && atoi(getenv("RTD_CONV_STAMPS")) == 3) {      // A-stationary kernel: per channel tile of blocks 0, 1, 40
+      std::vector<long long> st((size_t)64 * 16 * 4);
+      HIP_CHECK(hipMemcpy(st.data(), a.ws.slab, st.size() * 8, hipMemcpyDeviceToHost));
+      for (int blk : {0, 1, 40}) {
+        fprintf(stderr, "block %d: first tile landed %lld | per channel tile: K steps done, slab barrier passed, copy-out issued (shader clocks)\n", blk,
+                st[((size_t)blk * 16 + 15) * 4]);
+        for (int t = 0; t < 8; ++t) fprintf(stderr, "  tile %d: %7lld %7lld %7lld\n", t, st[((size_t)blk * 16 + t) * 4], st[((size_t)blk * 16 + t) * 4 + 1], st[((size_t)blk * 16 + t) * 4 + 2]);
+      }
+    } else if (getenv("RTD_CONV_STAMPS") && atoi(getenv("RTD_CONV_STAMPS")) == 2) {      // block-level stamps of the 128-pixel ws kernels
       const int nb = 4096;
       std::vector<long long> st((size_t)nb * 8);
       HIP_CHECK(hipMemcpy(st.data(), a.ws.slab, st.size() * 8, hipMemcpyDeviceToHost));

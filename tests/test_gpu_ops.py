@@ -54,6 +54,10 @@ CONV_CASES = [
     (4, 60, 264, 32, 64, 3, 1, 1, "silu", 0),      # stem.2
     (4, 68, 232, 64, 64, 3, 1, 1, "relu", 0),      # stage-0 c2 (two 32-channel groups)
     (2, 160, 160, 64, 64, 3, 1, 1, "none", 0),     # exact tiles
+    # short K, many channel tiles, no residual: the A-stationary kernel (auto in mode 0 from 4 channel tiles on)
+    (2, 64, 66, 128, 640, 1, 1, 0, "silu", 0),     # K = 128 (2 chunks), 5 channel tiles, ragged M
+    (1, 8400, 1, 256, 1536, 1, 1, 0, "none", 0),   # one image of the value projection
+    (3, 40, 40, 64, 520, 1, 1, 0, "relu", 0),      # K = 64 (1 chunk), partial last channel tile
 ]
 
 
@@ -88,8 +92,8 @@ def test_conv(L, dt, case):
     _capi.debug_option("splitk", 2)        # exercise the in-launch split-K reduction on every small-grid shape (default: tiny grids only)
     # conv_mode 0 = auto (LDS-DMA kernel where eligible), 2 = register-staged large tile, 1 = small tiles only,
     # 3 / 4 = wave-specialised LDS-DMA kernel (4 / 2 stages), 5 = single-role LDS-DMA kernel, 6 = wave-specialised with
-    # whole-K-step fragment prefetch, 7 = wave-specialised 256-pixel tile
-    for out_f32, mode in (((1, 0), (1, 1), (1, 2), (1, 3), (1, 6), (1, 7)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (1, 6), (0, 7), (1, 7))):
+    # whole-K-step fragment prefetch, 7 = wave-specialised 256-pixel tile, 8 = A-stationary kernel wherever it is eligible (1x1, K <= 256, no residual)
+    for out_f32, mode in (((1, 0), (1, 1), (1, 2), (1, 3), (1, 6), (1, 7)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (1, 6), (0, 7), (1, 7), (0, 8))):
         _capi.debug_option("conv_mode", mode)
         yd = torch.full((B, OH, OW, Cout), float("nan"), dtype=torch.float32 if out_f32 else tdt, device="cuda")
         ck(L, L.rtd_op_conv(code, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None,

@@ -3,6 +3,7 @@
 
     RTD_CONV_STAMPS=1 python tools/conv_stamps.py s1c2 ws256    # per-K-step stamps of the 256-pixel tile kernel (blocks 0, 1, 17)
     RTD_CONV_STAMPS=2 python tools/conv_stamps.py s0c3          # block-level phases of the default 128-pixel ws kernels
+    RTD_CONV_STAMPS=3 python tools/conv_stamps.py vpall wsa     # per channel tile of the A-stationary kernel
 """
 import ctypes as C
 import os
@@ -14,7 +15,7 @@ from telescope_cam_detection_amd import _capi
 SHAPES = {  # HW, Cin, Cout, k, stride, pad, residual
     "s0c3": (160, 64, 256, 1, 1, 0, 1), "s1c3": (80, 128, 512, 1, 1, 0, 1), "s0sc": (160, 64, 256, 1, 1, 0, 0),
     "fpn1": (80, 256, 256, 3, 1, 1, 0), "s1c1": (80, 512, 128, 1, 1, 0, 0), "s1c2": (80, 128, 128, 3, 1, 1, 0),
-    "lat": (20, 256, 256, 1, 1, 0, 0), "s3c2": (20, 512, 512, 3, 1, 1, 0),
+    "lat": (20, 256, 256, 1, 1, 0, 0), "s3c2": (20, 512, 512, 3, 1, 1, 0), "vpall": (-8400, 256, 1536, 1, 1, 0, 0),
 }
 
 
@@ -26,7 +27,12 @@ def main():
     _capi.debug_option("glds_drop", 32)
     hw, cin, cout, k, st, pad, res = SHAPES[which]
     out = (C.c_float * 2)()
-    rc = L.rtd_bench_conv(0, 8, hw, hw, cin, cout, k, st, pad, res, 3, 0, out)
+    if "wsa" in sys.argv[2:]:
+        _capi.debug_option("conv_mode", 8)
+    if hw < 0:      # token GEMM: 1 x (-hw) "image"
+        rc = L.rtd_bench_conv(0, 8, 1, -hw, cin, cout, k, st, pad, res, 3, 0, out)
+    else:
+        rc = L.rtd_bench_conv(0, 8, hw, hw, cin, cout, k, st, pad, res, 3, 0, out)
     print(which, "warm us per launch", round(out[0], 2), "rc", rc)
 
 
