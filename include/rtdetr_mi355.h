@@ -143,6 +143,11 @@ int rtd_crop_resize_batch(int32_t n, const uint8_t* const* frames_dev, const int
 int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* bias, const void* res,
                 void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                 int act, int res_mode, int out_f32);
+/* conv with a second input x2 [B,OH,OW,C2] read as an extra 1x1 tap at output resolution; w_f32 = [Cout][KH*KH*Cin + C2]
+ * (how the plan folds a bottleneck's projection shortcut into its last conv) */
+int rtd_op_conv_dual(int dtype, const void* x, const void* x2, const void* w_f32, const float* bias, const void* res,
+                     void* y, int B, int H, int W, int Cin, int C2, int Cout, int KH, int stride, int pad,
+                     int act, int res_mode, int out_f32);
 int rtd_op_layernorm(int dtype, const void* x, const void* res, const float* g, const float* b,
                      void* y, int rows, int dim, int out_f32);
 int rtd_op_attention(int dtype, const void* qk, const void* v, void* o, int B, int L, int heads, int hd);

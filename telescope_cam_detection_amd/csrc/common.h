@@ -73,6 +73,11 @@ struct ConvArgs {
   const void* w;       // filter [Npad][Kpad] in x.dt, K = KH*KW*Cin (tap-major, channel-minor)
   const float* bias;   // [Npad] fp32
   Tensor res;          // optional residual, indexed like y
+  // optional SECOND input [B,OH,OW,C2] read as an extra 1x1 / stride 1 tap at output resolution: the filter rows are
+  // [taps of x | C2 of x2] (K = KH*KW*Cin + C2).  This is how a bottleneck's projection shortcut is folded into its last conv:
+  // y = act(W3 * t + Wsc * x_in + (b3 + bsc)) without writing / re-reading the shortcut tensor.  KH*KW*Cin must be a multiple of
+  // one K-step (64 bf16 / 32 fp32); see conv_dual_supported().
+  Tensor x2;
   Tensor y;            // output [B,OH,OW,N] (view)
   int KH = 1, KW = 1, stride = 1, pad = 0;
   int Kpad = 0, Npad = 0;
@@ -85,6 +90,7 @@ struct ConvArgs {
   size_t pf_bytes = 0;
 };
 void launch_conv(const ConvArgs& a, hipStream_t s);
+bool conv_dual_supported(const ConvArgs& a);   // can this build's kernels run `a` with its second input? (the plan builder asks before fusing)
 int conv_kpad(int K);                 // padded filter row length the kernels expect
 int conv_npad(int N);
 void conv_set_force_v1(int v);      // A/B hook: 1 = never take the large-tile (v2) path
@@ -93,6 +99,8 @@ void conv_set_splitk(int v);        // A/B hook: 0 = never split K
 void conv_set_glds_drop(int v);     // timing-only traffic probe (MI355X guide §7): drop one operand's DMA via a 0-record descriptor
 void conv_set_ws256_min_blocks(int v);   // A/B hook: grid size from which the 256-pixel tile is used
 void conv_set_reg(int v);           // A/B hook: 0 = no direct 3x3 kernel for the narrow layers
+void conv_set_stream(int v);        // A/B hook: 0 = no streaming 1x1 kernel for the thin wide-grid layers
+void conv_set_stream_min_tiles(int v);
 void conv_set_glds_min_n(int v);    // A/B hook: smallest Cout the LDS-DMA kernels take (bf16)
 void conv_set_reg_epilogue(int v);   // A/B hook: 0 = every ws tile goes through the fp32 staging epilogue
 void conv_set_ws2_min_blocks(int v);

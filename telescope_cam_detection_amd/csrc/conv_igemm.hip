@@ -42,6 +42,9 @@ struct ConvK {
   const void* pf;        // prefetch target (next layer's filter) or nullptr
   unsigned pf_bytes;
   int reg_epi;           // 1: the ws kernels may finish residual-free bf16 tiles in registers (A/B: rtd_debug_option "reg_epilogue")
+  const void* x2;        // second input (ConvArgs::x2) or nullptr; K elements k2_start.. come from it
+  long long ldx2, x2_bstride;
+  int k2_start;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -515,6 +518,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvK a) {
 struct ConvG {
   ConvK k;
   unsigned x_bytes, w_bytes;   // extents of the two buffers from their base pointers (buffer descriptors)
+  unsigned x2_bytes;           // extent of the second input (ws kernel only)
   unsigned y_bytes;            // extent of the output (A-stationary kernel: buffer stores), 0 = not provided
   int probe;                   // timing-only probes (results wrong): bit 2 = issue no DMA at all
   // split-K (ws kernel): grid = tiles x splitk; every slice publishes its fp32 accumulators to `slab`, the block that
@@ -916,7 +920,20 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
       }
       b_off[i] = (n0 + i * 32 + lrow) * a.Kpad * ES + chunk * 16;
     }
+    // dual input: K elements from k2_start on are channels of x2 at the OUTPUT pixel (a 1x1 tap of another tensor)
+    int a2_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + i * 32 + lrow;
+      a2_off[i] = (int)0x80000000;
+      if (a.x2 && m < a.M) {
+        const int b = m / a.OHW;
+        const int r = m - b * a.OHW;
+        a2_off[i] = (int)(((long long)b * a.x2_bstride + (long long)r * a.ldx2) * ES) + chunk * 16;
+      }
+    }
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x), 0, a.x2 ? g.x2_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
     int k0 = ks0 * BK;                                            // first K element of this slice
     int kh, kw, c0;
@@ -929,13 +946,20 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
     auto issue = [&](int buf) {
       if (g.probe & 4) return;
       char* sa = smem + buf * STAGE + w4 * 1024;
-      const int delta = ((kh * a.W + kw) * (int)a.ldx + c0) * ES;
+      if (a.x2 && k0 >= a.k2_start) {
+        const int d2 = (k0 - a.k2_start) * ES;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-        const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        const unsigned vo = ok ? (unsigned)(a_off[i] + delta) : 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 4096), 16, vo, 0, 0, 0);
+        for (int i = 0; i < 4; ++i)                                 // rows past M keep the out-of-range bit: zeros
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, (lds_ptr_t)(sa + i * 4096), 16, (unsigned)a2_off[i] + (a2_off[i] < 0 ? 0u : (unsigned)d2), 0, 0, 0);
+      } else {
+        const int delta = ((kh * a.W + kw) * (int)a.ldx + c0) * ES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+          const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+          const unsigned vo = ok ? (unsigned)(a_off[i] + delta) : 0x80000000u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 4096), 16, vo, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -1566,8 +1590,8 @@ void conv_set_reg_epilogue(int v) { g_reg_epilogue = v; }
 static int g_prefetch = 1;    // A/B hook (rtd_debug_option "prefetch"): 0 = no next-layer filter prefetch
 void conv_set_prefetch(int v) { g_prefetch = v; }
 template <typename T>
-static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long w_bytes, unsigned y_bytes, const ConvWorkspace& ws, hipStream_t s) {
-  if (!ok || g_conv_mode == 1 || g_conv_mode == 2) return false;     // 5 = single-role LDS-DMA kernels (v3) for A/B
+static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long w_bytes, unsigned y_bytes, unsigned x2_bytes, const ConvWorkspace& ws, hipStream_t s) {
+  if (!ok || ((g_conv_mode == 1 || g_conv_mode == 2) && !k.x2)) return false;     // 5 = single-role LDS-DMA kernels (v3) for A/B
   const long long mt = (k.M + 127) / 128, ntn = (k.N + 127) / 128;
   // fp32 GEMMs (query-selection heads) may use a partly empty N tile: N >= 64 still beats the small-tile kernel
   // N >= 64 may use a partly empty N tile (the filter is padded to 128 rows): the N = 64 reduce convs of stage 0 are HBM-bound,
@@ -1581,6 +1605,14 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
   g.splitk = 1; g.slab = nullptr; g.cnt = nullptr; g.y_bytes = 0;
   g.x_bytes = (g_glds_drop & 1) ? 0u : (unsigned)x_bytes;
   g.w_bytes = (g_glds_drop & 2) ? 0u : (unsigned)w_bytes;
+  g.x2_bytes = x2_bytes;
+  if (k.x2) {
+    // dual-input launches exist in the wave-specialised kernel only (every conv_mode): 4 stages on small grids, 2 above
+    g.slab = ws.slab;
+    if (mt * ntn < g_ws2_min_blocks) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+    return true;
+  }
   // grids that fill every CU twice run 2 blocks/CU with a 2-deep pipeline; smaller grids get the
   // whole LDS for one block and a 4-deep pipeline
   if (sizeof(T) == 2 && g_wsa_min_ntn > 0 && (g_conv_mode == 0 || g_conv_mode == 8) && k.KH == 1 && k.KW == 1 && k.stride == 1 && k.pad == 0 &&
@@ -1827,6 +1859,163 @@ static bool dispatch_reg(const ConvK& k, const ConvArgs& a, long long x_bytes, h
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streaming 1x1 convolution for the thin, very wide-grid layers of the first backbone stages (K = 64 / 128 input channels,
+// 200k / 50k pixels: stage-0/1 c3 + shortcut).  These move 120-240 MB per launch with 7-13 GFLOP: the tiled kernels run them at
+// ~3 TB/s because every 128-pixel block pays a prologue, a staging round trip and a slab epilogue for ONE K-step, while a
+// plain streaming kernel with the same byte mix reaches 6.5-7 TB/s and one with MFMA-fragment-shaped accesses 5 TB/s
+// (tools/stream_probe.hip).  Here there is no LDS tile, no barrier and no role split:
+//   * a WAVE owns 64 output channels and keeps their whole filter in registers (2 x K/16 fragments); it walks 32-pixel tiles
+//     block-cyclically (persistent grid);
+//   * the pixel fragments are read straight from global memory in MFMA B-operand shape (lane = pixel, 16 bytes of K each);
+//     the CG = N/64 waves of a block read the same pixels, the copies hit in the CU's L1;
+//   * the filter rows are PERMUTED when the fragments are loaded (MFMA row 8q+4h+e <- channel 32h+16i+4q+e) so that a lane's
+//     32 accumulators are 32 CONSECUTIVE channels of its pixel: residual and output move as 4 x 16 bytes per lane with no
+//     transpose, and the two lane halves complete one 128-byte line per pixel;
+//   * bias (LDS, broadcast reads) + residual + activation in fp32 registers, one rounding to bf16, `buffer_store` (an
+//     out-of-range offset drops the store: ragged last tile).
+// Arithmetic per output is the tiled kernels' (K in order into a zero accumulator, + bias, + residual, activation).
+// ------------------------------------------------------------------------------------------------
+template <int NKK, int THREADS, bool DUAL = false>   // DUAL: the second half of K comes from ConvK::x2 (same channel count as x)
+__global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kernel(const ConvK a, unsigned x_bytes, unsigned r_bytes, unsigned y_bytes, unsigned x2_bytes, int CG, int ntiles) {
+  constexpr int NW = THREADS / 64;
+  __shared__ __attribute__((aligned(16))) float sbias[512];
+  __shared__ __attribute__((aligned(16))) char pf_dummy[256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, pl = lane & 31;
+  const int cg = wv % CG, ps = wv / CG, PG = NW / CG;
+  const int cb = cg * 64;
+  for (int i = tid; i < a.N; i += THREADS) sbias[i] = a.bias[i];
+
+  bf16x8 wf[2][NKK];
+  {
+    const bf16* wg = (const bf16*)a.w;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = cb + 32 * ((pl >> 2) & 1) + 16 * i + 4 * (pl >> 3) + (pl & 3);
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) wf[i][kk] = *(const bf16x8*)(wg + (size_t)row * a.Kpad + kk * 16 + 8 * h);
+    }
+  }
+  __syncthreads();
+  prefetch_share(a, blockIdx.x, gridDim.x, tid, THREADS, pf_dummy);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.x), 0, a.res ? r_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? a.x2 : a.x), 0, DUAL ? x2_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
+  const float* bl = sbias + cb + 32 * h;
+
+  dispatch_act(a.act, [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+      const int m = (t * PG + ps) * 32 + pl;
+      const bool ok = m < a.M;
+      const int b = m / a.OHW;
+      const int p = m - b * a.OHW;
+      const unsigned xo = ok ? (unsigned)(((long long)b * a.x_bstride + (long long)p * a.ldx) * 2 + 16 * h) : 0x80000000u;
+      u32x4_ xr[NKK];
+      if (DUAL) {
+        const unsigned xo2 = ok ? (unsigned)(((long long)b * a.x2_bstride + (long long)p * a.ldx2) * 2 + 16 * h) : 0x80000000u;
+#pragma unroll
+        for (int kk = 0; kk < NKK / 2; ++kk) xr[kk] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xo + 32 * kk : xo, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < NKK / 2; ++kk) xr[NKK / 2 + kk] = __builtin_amdgcn_raw_buffer_load_b128(rx2, ok ? xo2 + 32 * kk : xo2, 0, 0);
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) xr[kk] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xo + 32 * kk : xo, 0, 0);
+      }
+      u32x4_ rv[4];
+      if (a.res_mode != RES_NONE) {
+        const unsigned ro = ok ? (unsigned)(((long long)b * a.r_bstride + (long long)p * a.ldr + cb + 32 * h) * 2) : 0x80000000u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rv[q] = __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? ro + 16 * q : ro, 0, 0);
+      }
+      f32x16 acc[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][kk], __builtin_bit_cast(bf16x8, xr[kk]), acc[i], 0, 0, 0);
+      const unsigned yo = ok ? (unsigned)(((long long)b * a.y_bstride + (long long)p * a.ldy + cb + 32 * h) * 2) : 0x80000000u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b0 = *(const f32x4*)(bl + 8 * q), b1 = *(const f32x4*)(bl + 8 * q + 4);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[q >> 1][8 * (q & 1) + e] + (e < 4 ? b0[e & 3] : b1[e & 3]);
+        float r[8];
+        if (a.res_mode != RES_NONE) {
+          const bf16x8 rb = __builtin_bit_cast(bf16x8, rv[q]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r[e] = (float)rb[e];
+        }
+        if (a.res_mode == RES_PRE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = act_c<ACT>(v[e]);
+        if (a.res_mode == RES_POST) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        const bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o), ry, ok ? yo + 16 * q : yo, 0, 0);
+      }
+    }
+  });
+}
+
+static int g_conv_stream = 1;    // A/B hook (rtd_debug_option "conv_stream"): 0 = the thin 1x1 layers stay on the tiled kernels
+static int g_stream_min_tiles = 2048;
+void conv_set_stream(int v) { g_conv_stream = v; }
+void conv_set_stream_min_tiles(int v) { g_stream_min_tiles = v; }
+
+// returns true when the launch was taken by the streaming kernel
+static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes, long long x2_bytes, hipStream_t s) {
+  if (!g_conv_stream || g_force_v1 || (g_conv_mode != 0 && g_conv_mode != 9)) return false;
+  const Tensor& x = a.x;
+  const Tensor& y = a.y;
+  const bool dual = a.x2.p != nullptr;
+  if (x.dt != BF16 || y.dt != BF16 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0) return false;
+  if (a.res_mode != RES_NONE && a.res.dt != BF16) return false;
+  if (dual && !(x.c == 64 && a.x2.c == 64)) return false;
+  const int K = x.c + (dual ? a.x2.c : 0);
+  if (!(K == 64 || K == 128) || a.Kpad != K || y.c % 64 || y.c > 512 || x.ld % 8 || y.ld % 8 || ((uintptr_t)y.p & 15)) return false;
+  if (a.res_mode != RES_NONE && (a.res.ld % 8 || ((uintptr_t)a.res.p & 15))) return false;
+  const long long y_bytes = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * 2;
+  long long r_bytes = 0;
+  if (a.res_mode != RES_NONE) r_bytes = ((long long)(a.res.n - 1) * a.res.bstride + ((long long)a.res.h * a.res.w - 1) * a.res.ld + a.res.c) * 2;
+  if (x_bytes >= (1ll << 31) || y_bytes >= (1ll << 31) || r_bytes >= (1ll << 31) || x2_bytes >= (1ll << 31)) return false;
+  const int CG = y.c / 64;
+  if (CG != 1 && CG != 2 && CG != 4 && CG != 8) return false;
+  const int NW = CG == 8 ? 8 : 4;
+  const int PG = NW / CG;
+  const long long ntiles = ((long long)k.M + 32 * PG - 1) / (32 * PG);
+  if ((ntiles * NW < g_stream_min_tiles && g_conv_mode != 9) || ntiles >= (1ll << 30)) return false;
+  // persistent blocks, as many as the register budget keeps resident (K = 64: 3 waves per SIMD, K = 128: 2)
+  const unsigned gx = (unsigned)std::min<long long>(ntiles, K == 64 ? (NW == 8 ? 256 : 768) : (NW == 8 ? 256 : 512));
+#define RTD_STREAM(NKK, THREADS, DUAL)                                                                                   \
+  hipLaunchKernelGGL((conv1x1_stream_kernel<NKK, THREADS, DUAL>), dim3(gx), dim3(THREADS), 0, s, k, (unsigned)x_bytes, \
+                     (unsigned)r_bytes, (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles)
+  if (K == 64) {
+    if (NW == 8) RTD_STREAM(4, 512, false);
+    else RTD_STREAM(4, 256, false);
+  } else if (dual) {
+    if (NW == 8) RTD_STREAM(8, 512, true);
+    else RTD_STREAM(8, 256, true);
+  } else {
+    if (NW == 8) RTD_STREAM(8, 512, false);
+    else RTD_STREAM(8, 256, false);
+  }
+#undef RTD_STREAM
+  return true;
+}
+
 template <typename T>
 static bool dispatch_v2(const ConvK& k, bool v2_ok, hipStream_t s) {
   if (!v2_ok || g_force_v1) return false;
@@ -1872,6 +2061,28 @@ static void dispatch(const ConvK& k, bool smallc, hipStream_t s) {
 #undef RTD_LAUNCH
 }
 
+// The second input exists in the wave-specialised LDS-DMA kernel (and, for 64 + 64 channels, the streaming kernel): the shapes
+// dispatch_glds accepts, a K-step-aligned split point and whole K-steps of x2.
+bool conv_dual_supported(const ConvArgs& a) {
+  const Tensor& x = a.x;
+  const Tensor& y = a.y;
+  const Tensor& x2 = a.x2;
+  if (!x2.p || x2.dt != x.dt) return false;
+  const int OH = (x.h + 2 * a.pad - a.KH) / a.stride + 1, OW = (x.w + 2 * a.pad - a.KW) / a.stride + 1;
+  if (x2.n != x.n || x2.h != OH || x2.w != OW) return false;
+  const int es = (int)dtype_size(x.dt), bk = 128 / es, epc = 16 / es;
+  if ((a.KH * a.KW * x.c) % bk || x2.c % bk || x.c % bk || x2.ld % epc || ((uintptr_t)x2.p & 15)) return false;
+  if (!(y.c % 8 == 0 && y.ld % 8 == 0 && ((uintptr_t)y.p & 15) == 0)) return false;                       // v2_ok
+  if (a.res_mode != RES_NONE && !(a.res.ld % 8 == 0 && ((uintptr_t)a.res.p & 15) == 0)) return false;
+  const long long M = (long long)x.n * OH * OW;
+  const long long mt = (M + 127) / 128, ntn = (y.c + 127) / 128;
+  if (y.c < (es == 2 ? g_glds_min_n : 64) || mt * ntn < (es == 2 ? g_glds_min_blocks : 512)) return false;
+  const long long x_bytes = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * es;
+  const long long x2_bytes = ((long long)(x2.n - 1) * x2.bstride + ((long long)x2.h * x2.w - 1) * x2.ld + x2.c) * es;
+  const long long w_bytes = (long long)conv_npad(y.c) * conv_kpad(a.KH * a.KW * x.c + x2.c) * es;
+  return x_bytes < (1ll << 31) && x2_bytes < (1ll << 31) && w_bytes < (1ll << 31);
+}
+
 void launch_conv(const ConvArgs& a, hipStream_t s) {
   const Tensor& x = a.x;
   const Tensor& y = a.y;
@@ -1885,7 +2096,9 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
   RTD_CHECK(((uintptr_t)x.p & 15) == 0 && ((uintptr_t)a.w & 15) == 0, 1, "conv: 16-byte alignment");
   RTD_CHECK(y.c % 4 == 0 && y.ld % 4 == 0, 1, "conv: Cout / output stride must be multiples of 4");
   RTD_CHECK(((uintptr_t)y.p & (y.dt == BF16 ? 7 : 15)) == 0, 1, "conv: output alignment");
-  const int K = a.KH * a.KW * x.c;
+  const bool dual = a.x2.p != nullptr;
+  const int K = a.KH * a.KW * x.c + (dual ? a.x2.c : 0);
+  if (dual) RTD_CHECK(conv_dual_supported(a), 1, "conv: second input not supported for this shape (see conv_dual_supported)");
   RTD_CHECK(a.Kpad == conv_kpad(K) && a.Npad >= y.c && a.Npad % 128 == 0, 1, "conv: filter padding");
   RTD_CHECK((long long)x.n * OH * OW < (1ll << 31), 1, "conv: M overflow");
   ConvK k;
@@ -1904,6 +2117,12 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     k.ldr = a.res.ld; k.r_bstride = a.res.bstride; k.res_f32 = a.res.dt == F32;
   }
   k.act = a.act; k.res_mode = a.res_mode; k.y_f32 = y.dt == F32;
+  k.x2 = nullptr; k.ldx2 = 0; k.x2_bstride = 0; k.k2_start = 0;
+  long long x2_bytes = 0;
+  if (dual) {
+    k.x2 = a.x2.p; k.ldx2 = a.x2.ld; k.x2_bstride = a.x2.bstride; k.k2_start = a.KH * a.KW * x.c;
+    x2_bytes = ((long long)(a.x2.n - 1) * a.x2.bstride + ((long long)a.x2.h * a.x2.w - 1) * a.x2.ld + a.x2.c) * (long long)dtype_size(x.dt);
+  }
   k.ntn = 1;
   k.reg_epi = g_reg_epilogue;
   k.pf = g_prefetch ? a.pf : nullptr;
@@ -1917,14 +2136,16 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     const long long es = (long long)dtype_size(x.dt);
     const long long x_bytes = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * es;
     const long long w_bytes = (long long)a.Npad * a.Kpad * es;
-    done = dispatch_reg(k, a, x_bytes, s);
+    done = !dual && dispatch_reg(k, a, x_bytes, s);
+    if (!done) done = dispatch_stream(k, a, x_bytes, x2_bytes, s);
     if (!done) {
       const long long yb = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * (long long)dtype_size(y.dt);
       const unsigned y_bytes = yb < (1ll << 31) ? (unsigned)yb : 0u;
-      if (x.dt == BF16) done = dispatch_glds<bf16>(k, v2_ok, x_bytes, w_bytes, y_bytes, a.ws, s);
-      else done = dispatch_glds<float>(k, v2_ok, x_bytes, w_bytes, y_bytes, a.ws, s);
+      if (x.dt == BF16) done = dispatch_glds<bf16>(k, v2_ok, x_bytes, w_bytes, y_bytes, (unsigned)x2_bytes, a.ws, s);
+      else done = dispatch_glds<float>(k, v2_ok, x_bytes, w_bytes, y_bytes, (unsigned)x2_bytes, a.ws, s);
     }
   }
+  RTD_CHECK(done || !dual, 1, "conv: no kernel took the dual-input launch");
   if (!done) {
     if (x.dt == BF16) done = dispatch_v2<bf16>(k, v2_ok, s);
     else done = dispatch_v2<float>(k, v2_ok, s);

@@ -27,6 +27,7 @@ namespace {
 thread_local std::string g_create_error;
 int g_dec_stamps = 0;  // plan-build switch: record per-phase stamps of decoder layer 2 into debug tensor "dec_stamps"
 int g_dec_split = 1;   // plan-build switch (rtd_debug_option "dec_split"): bf16 engine runs the fused decoder / AIFI linears as bf16 hi/lo splits
+int g_sc_fold = 1;     // plan-build switch (rtd_debug_option "sc_fold"): bf16 plans fold a block's projection shortcut into its last conv (ConvArgs::x2)
 int g_stem_fused = 0;  // plan-build switch (rtd_debug_option "stem_fused"): bf16 engine runs backbone.stem.0 straight from the uint8 frames.
                        // Measured neutral (same-box A/B: +0.2 % / 0 %: the kernel is latency-bound at 44 us against 56 + 20 us of
                        // preprocess + generic stem) -> off by default, kept tested
@@ -189,6 +190,49 @@ DevWeight get_weight(rtd_engine* e, const std::string& name, int dt, int N, int 
   HIP_CHECK(er);
   std::vector<float> bp(d.Npad, 0.f);
   memcpy(bp.data(), b.data, (size_t)N * 4);
+  d.bias = (float*)e->dmalloc(bp.size() * 4);
+  HIP_CHECK(hipMemcpy(d.bias, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+  e->wcache[key] = d;
+  return d;
+}
+
+// two filters over the same output channels, concatenated along K: [N][K1 | K2] -> device [Npad][Kpad], bias = b1 + b2
+// (a block's last conv with its projection shortcut folded in, ConvArgs::x2)
+DevWeight get_weight_cat(rtd_engine* e, const std::string& n1, const std::string& n2, int dt, int N, int K1, int K2) {
+  const std::string key = n1 + "+" + n2 + (dt == BF16 ? "#bf16" : "#f32");
+  auto it = e->wcache.find(key);
+  if (it != e->wcache.end()) return it->second;
+  const HostTensor& w1 = host_tensor(e, n1 + ".w");
+  const HostTensor& w2 = host_tensor(e, n2 + ".w");
+  const HostTensor& b1 = host_tensor(e, n1 + ".b");
+  const HostTensor& b2 = host_tensor(e, n2 + ".b");
+  RTD_CHECK(w1.numel() == (int64_t)N * K1 && w2.numel() == (int64_t)N * K2 && b1.numel() == N && b2.numel() == N, RTD_E_WEIGHTS,
+            "weight shape mismatch: " + n1 + " + " + n2);
+  DevWeight d;
+  d.N = N; d.K = K1 + K2; d.Kpad = conv_kpad(d.K); d.Npad = conv_npad(N); d.dt = dt;
+  std::vector<float> pad((size_t)d.Npad * d.Kpad, 0.f);
+  for (int r = 0; r < N; ++r) {
+    memcpy(&pad[(size_t)r * d.Kpad], w1.data + (size_t)r * K1, (size_t)K1 * 4);
+    memcpy(&pad[(size_t)r * d.Kpad + K1], w2.data + (size_t)r * K2, (size_t)K2 * 4);
+  }
+  float* tmp = nullptr;
+  HIP_CHECK(hipMalloc((void**)&tmp, pad.size() * 4));
+  hipError_t er = hipMemcpy(tmp, pad.data(), pad.size() * 4, hipMemcpyHostToDevice);
+  if (er == hipSuccess) {
+    if (dt == F32) {
+      d.w = tmp;
+      e->allocs.push_back(tmp);
+      tmp = nullptr;
+    } else {
+      d.w = e->dmalloc(pad.size() * 2);
+      launch_f32_to(tmp, d.w, BF16, (int64_t)pad.size(), e->stream);
+      er = hipStreamSynchronize(e->stream);
+    }
+  }
+  if (tmp) (void)hipFree(tmp);
+  HIP_CHECK(er);
+  std::vector<float> bp(d.Npad, 0.f);
+  for (int r = 0; r < N; ++r) bp[r] = b1.data[r] + b2.data[r];
   d.bias = (float*)e->dmalloc(bp.size() * 4);
   HIP_CHECK(hipMemcpy(d.bias, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
   e->wcache[key] = d;
@@ -397,23 +441,27 @@ struct Builder {
   static double tbytes(const Tensor& t) { return (double)t.pixels() * t.c * dtype_size(t.dt); }
 
   // conv / linear.  `y` may be a channel-slice view of a wider buffer.
+  // `x2` + `name2`: a second input read as an extra 1x1 tap at output resolution, its filter `name2` concatenated along K
+  // (ConvArgs::x2: the projection shortcut folded into the block's last conv)
   void conv(const std::string& name, const Tensor& x, const Tensor& y, int k, int stride, int pad, int act,
-            const Tensor* res = nullptr, int res_mode = RES_NONE, int real_cin = 0) {
-    const int K = k * k * x.c;
+            const Tensor* res = nullptr, int res_mode = RES_NONE, int real_cin = 0, const Tensor* x2 = nullptr,
+            const std::string& name2 = "") {
+    const int K = k * k * x.c + (x2 ? x2->c : 0);
     DevWeight w;
-    if (!dry) w = get_weight(e, name, x.dt, y.c, K);
+    if (!dry) w = x2 ? get_weight_cat(e, name, name2, x.dt, y.c, k * k * x.c, x2->c) : get_weight(e, name, x.dt, y.c, K);
     else { w.Kpad = conv_kpad(K); w.Npad = conv_npad(y.c); }
     ConvArgs a;
     a.x = x; a.y = y; a.w = w.w; a.bias = w.bias;
+    if (x2) a.x2 = *x2;
     a.KH = k; a.KW = k; a.stride = stride; a.pad = pad; a.Kpad = w.Kpad; a.Npad = w.Npad;
     a.act = act; a.res_mode = res ? res_mode : RES_NONE;
     if (res) a.res = *res;
     a.ws = e->conv_ws;
     const double M = (double)y.pixels();
-    const double kreal = (double)k * k * (real_cin ? real_cin : x.c);
+    const double kreal = (double)k * k * (real_cin ? real_cin : x.c) + (x2 ? x2->c : 0);
     const double flops = 2.0 * M * y.c * kreal;
     const double bytes = (double)x.pixels() * x.c * dtype_size(x.dt) + tbytes(y) + (double)y.c * K * dtype_size(x.dt) +
-                         (res ? tbytes(*res) : 0.0);
+                         (res ? tbytes(*res) : 0.0) + (x2 ? tbytes(*x2) : 0.0);
     auto ap = std::make_shared<ConvArgs>(a);
     if (!dry) {
       // chain: the previous conv launch of the plan prefetches THIS filter while it runs (ConvArgs::pf)
@@ -495,30 +543,51 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       bool has_sc;
       if (c.layer_type == RTD_LAYER_BOTTLENECK) has_sc = (cin != cout) || stride != 1;
       else has_sc = (bi == 0);
+      // The projection shortcut is a 1x1 conv over the block input whose only use is the pre-activation add of the block's last
+      // conv: y = relu(W_last * t + b_last + (W_sc * x_in + b_sc)).  In bf16 plans it is folded into that conv as extra K
+      // (ConvArgs::x2): the [B,OH,OW,cout] shortcut tensor is neither written nor read back (R50 bs 8 stage 0: 2 x 105 MB), one
+      // launch less, and the sum is rounded once instead of twice.  fp32 plans keep the reference's op sequence.
+      const int mid = cout / 4;
+      Tensor sc_in = cur;                                    // what the shortcut's 1x1 reads
+      bool fold_sc = false;
       if (has_sc) {
-        res = B.act(P, n, oh, ow, cout);
         // stride 2: AvgPool2d(2,2,ceil) then 1x1 (HF:rt_detr_resnet.py:199-213); extents are even here
         if (stride == 2) {
           Tensor pooled = B.act(P, n, oh, ow, cin);
           B.push(pfx + ".avgpool", "avgpool", 4.0 * pooled.pixels() * cin, Builder::tbytes(cur) + Builder::tbytes(pooled),
                  [cur, pooled](hipStream_t s) { launch_avgpool2(cur, pooled, s); });
-          B.conv(pfx + ".sc", pooled, res, 1, 1, 0, ACT_NONE);
-        } else {
-          B.conv(pfx + ".sc", cur, res, 1, 1, 0, ACT_NONE);
+          sc_in = pooled;
+        }
+        if (P == BF16 && g_sc_fold) {
+          // shapes only: would the kernels take the folded launch?  Asked for ONE image whatever this plan's batch: every plan
+          // of an engine must use the same filters (the host copies are dropped after the first plan) and the same arithmetic
+          // (batch invariance), and a single image has the smallest grid
+          ConvArgs probe;
+          Tensor yv; yv.dt = P; yv.n = 1; yv.h = oh; yv.w = ow; yv.c = cout; yv.ld = cout; yv.bstride = (int64_t)oh * ow * cout; yv.p = (void*)16;
+          Tensor xv = yv; xv.c = xv.ld = (c.layer_type == RTD_LAYER_BOTTLENECK ? mid : cout); xv.bstride = (int64_t)oh * ow * xv.c;
+          Tensor x2v = sc_in; x2v.p = (void*)16; x2v.n = 1;
+          probe.x = xv; probe.x2 = x2v; probe.y = yv;
+          probe.KH = probe.KW = (c.layer_type == RTD_LAYER_BOTTLENECK ? 1 : 3); probe.stride = 1; probe.pad = probe.KH / 2;
+          fold_sc = conv_dual_supported(probe);
+        }
+        if (!fold_sc) {
+          res = B.act(P, n, oh, ow, cout);
+          B.conv(pfx + ".sc", sc_in, res, 1, 1, 0, ACT_NONE);
         }
       }
       Tensor out = B.act(P, n, oh, ow, cout, oname);
       if (c.layer_type == RTD_LAYER_BOTTLENECK) {
-        const int mid = cout / 4;
         Tensor t1 = B.act(P, n, h, w, mid);
         B.conv(pfx + ".c1", cur, t1, 1, 1, 0, ACT_RELU);
         Tensor t2 = B.act(P, n, oh, ow, mid);
         B.conv(pfx + ".c2", t1, t2, 3, stride, 1, ACT_RELU);
-        B.conv(pfx + ".c3", t2, out, 1, 1, 0, ACT_RELU, &res, RES_PRE);
+        if (fold_sc) B.conv(pfx + ".c3", t2, out, 1, 1, 0, ACT_RELU, nullptr, RES_NONE, 0, &sc_in, pfx + ".sc");
+        else B.conv(pfx + ".c3", t2, out, 1, 1, 0, ACT_RELU, &res, RES_PRE);
       } else {
         Tensor t1 = B.act(P, n, oh, ow, cout);
         B.conv(pfx + ".c1", cur, t1, 3, stride, 1, ACT_RELU);
-        B.conv(pfx + ".c2", t1, out, 3, 1, 1, ACT_RELU, &res, RES_PRE);
+        if (fold_sc) B.conv(pfx + ".c2", t1, out, 3, 1, 1, ACT_RELU, nullptr, RES_NONE, 0, &sc_in, pfx + ".sc");
+        else B.conv(pfx + ".c2", t1, out, 3, 1, 1, ACT_RELU, &res, RES_PRE);
       }
       cur = out; h = oh; w = ow; cin = cout;
     }
@@ -1372,6 +1441,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "dec_fused") == 0) { g_dec_fused = value; return RTD_OK; }
   if (strcmp(name, "sel_fused") == 0) { g_sel_fused = value; return RTD_OK; }
   if (strcmp(name, "stem_fused") == 0) { g_stem_fused = value; return RTD_OK; }
+  if (strcmp(name, "sc_fold") == 0) { g_sc_fold = value; return RTD_OK; }
   if (strcmp(name, "dec_split") == 0) { g_dec_split = value; return RTD_OK; }
   if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
   if (strcmp(name, "prefetch") == 0) { conv_set_prefetch(value); return RTD_OK; }
@@ -1380,6 +1450,8 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "reg_epilogue") == 0) { conv_set_reg_epilogue(value); return RTD_OK; }
   if (strcmp(name, "glds_min_n") == 0) { conv_set_glds_min_n(value); return RTD_OK; }
   if (strcmp(name, "conv_reg") == 0) { conv_set_reg(value); return RTD_OK; }
+  if (strcmp(name, "conv_stream") == 0) { conv_set_stream(value); return RTD_OK; }
+  if (strcmp(name, "stream_min_tiles") == 0) { conv_set_stream_min_tiles(value); return RTD_OK; }
   if (strcmp(name, "ws256_min_blocks") == 0) { conv_set_ws256_min_blocks(value); return RTD_OK; }
   if (strcmp(name, "profile_twice") == 0) { g_profile_twice = value; return RTD_OK; }
   if (strcmp(name, "bench_rewarm") == 0) { g_bench_rewarm = value; return RTD_OK; }
@@ -1389,11 +1461,11 @@ int rtd_debug_option(const char* name, int value) {
   return RTD_E_INVALID;
 }
 
-int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* bias, const void* res, void* y, int B, int H,
-                int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int act, int res_mode, int out_f32) {
+static int op_conv_impl(int dtype, const void* x, const void* x2, int C2, const void* w_ohwi_f32, const float* bias, const void* res, void* y,
+                        int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int act, int res_mode, int out_f32) {
   return op_guard([&] {
     RTD_CHECK(KH == KW, RTD_E_INVALID, "square filters only");
-    const int K = KH * KW * Cin, Kpad = conv_kpad(K), Npad = conv_npad(Cout);
+    const int K = KH * KW * Cin + (x2 ? C2 : 0), Kpad = conv_kpad(K), Npad = conv_npad(Cout);
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     float* wpad = nullptr; void* wdev = nullptr; float* bpad = nullptr;
     HIP_CHECK(hipMalloc((void**)&wpad, (size_t)Npad * Kpad * 4));
@@ -1412,6 +1484,7 @@ int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* b
     a.w = wdev; a.bias = bpad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.Npad = Npad;
     a.act = act; a.res_mode = res ? res_mode : RES_NONE;
     if (res) a.res = mk(res, dtype, B, OH, OW, Cout);
+    if (x2) a.x2 = mk(x2, dtype, B, OH, OW, C2);
     ConvWorkspace ws;
     ws.slab_bytes = (size_t)640 * 128 * 128 * 4; ws.cnt_entries = 1024;
     HIP_CHECK(hipMalloc((void**)&ws.slab, ws.slab_bytes));
@@ -1426,6 +1499,17 @@ int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* b
     if (wdev != wpad) (void)hipFree(wdev);
     (void)hipFree(wpad); (void)hipFree(bpad);
   });
+}
+
+int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* bias, const void* res, void* y, int B, int H,
+                int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int act, int res_mode, int out_f32) {
+  return op_conv_impl(dtype, x, nullptr, 0, w_ohwi_f32, bias, res, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, res_mode, out_f32);
+}
+
+int rtd_op_conv_dual(int dtype, const void* x, const void* x2, const void* w_f32, const float* bias, const void* res, void* y, int B,
+                     int H, int W, int Cin, int C2, int Cout, int KH, int stride, int pad, int act, int res_mode, int out_f32) {
+  if (!x2) return RTD_E_INVALID;
+  return op_conv_impl(dtype, x, x2, C2, w_f32, bias, res, y, B, H, W, Cin, Cout, KH, KH, stride, pad, act, res_mode, out_f32);
 }
 
 int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int stride, int pad, int with_res, int reps,

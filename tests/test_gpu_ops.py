@@ -58,7 +58,61 @@ CONV_CASES = [
     (2, 64, 66, 128, 640, 1, 1, 0, "silu", 0),     # K = 128 (2 chunks), 5 channel tiles, ragged M
     (1, 8400, 1, 256, 1536, 1, 1, 0, "none", 0),   # one image of the value projection
     (3, 40, 40, 64, 520, 1, 1, 0, "relu", 0),      # K = 64 (1 chunk), partial last channel tile
+    # thin 1x1 layers (K = 64 / 128, Cout a multiple of 64): the streaming filter-in-registers kernel (mode 9 forces it on small grids)
+    (2, 50, 37, 128, 512, 1, 1, 0, "relu", 1),     # stage-1 c3 family: 8 channel groups, ragged last pixel tile
+    (1, 45, 31, 64, 64, 1, 1, 0, "silu", 2),       # one channel group, four pixel sub-tiles per block, post-activation residual
+    (3, 33, 33, 128, 128, 1, 1, 0, "none", 0),     # two channel groups
+    (2, 96, 100, 64, 256, 1, 1, 0, "none", 0),     # stage-0 shortcut family (linear)
 ]
+
+
+DUAL_CASES = [
+    # B, H, W, Cin, C2, Cout, k, act: y = act(conv_kxk(x) + conv_1x1(x2) + bias), x2 at output resolution
+    (2, 40, 36, 64, 64, 256, 1, "relu"),       # stage-0 block 0 of the bottleneck nets (64 + 64 channels: streaming kernel in bf16)
+    (2, 30, 30, 128, 256, 512, 1, "relu"),     # stage-1 block 0: K = 384
+    (1, 13, 11, 256, 512, 1024, 1, "relu"),    # stage-2 block 0, ragged pixel tile
+    (2, 24, 20, 64, 64, 128, 3, "relu"),       # basic-block nets: 3x3 main conv (K1 = 576) + 1x1 shortcut, Cout one tile
+    (1, 20, 20, 128, 64, 192, 3, "none"),      # partial last channel tile
+    (4, 128, 128, 32, 64, 128, 1, "relu"),     # 512 tiles: large enough for the fp32 kernel (fp32 K-steps are 32 wide)
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", DUAL_CASES)
+def test_conv_dual(L, dt, case):
+    """ConvArgs::x2 (the projection shortcut folded into a block's last conv) against conv(x) + conv1x1(x2) in fp64."""
+    B, H, W, Cin, C2, Cout, k, act = case
+    if dt == "bf16" and (Cin % 64 or C2 % 64):
+        pytest.skip("bf16 K-steps are 64 channels wide")
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(700 + DUAL_CASES.index(case))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x2 = torch.randn(B, C2, H, W, generator=g)
+    w1 = torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k)) ** 0.5
+    w2 = torch.randn(Cout, C2, 1, 1, generator=g) * (1.0 / C2) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    q = lambda t: t.to(tdt).double()
+    y = F.conv2d(q(x), q(w1), b.double(), padding=k // 2) + F.conv2d(q(x2), q(w2))
+    y = {"none": lambda t: t, "relu": F.relu}[act](y).float()
+    wcat = torch.cat([w1.permute(0, 2, 3, 1).reshape(Cout, -1), w2.reshape(Cout, C2)], dim=1).contiguous().cuda()
+    xd, x2d, bd = nhwc(x, tdt), nhwc(x2, tdt), b.cuda()
+    from telescope_cam_detection_amd import _capi
+    for out_f32, mode in (((1, 0),) if dt == "f32" else ((0, 0), (1, 0), (0, 3), (0, 9))):
+        if dt == "f32" and B * H * W * ((Cout + 127) // 128) < 512 * 128:
+            # fp32 launches need >= 512 tiles for the LDS-DMA kernels: the library must refuse the shape, not fall back
+            yd = torch.zeros(B, H, W, Cout, dtype=torch.float32, device="cuda")
+            rc = L.rtd_op_conv_dual(code, xd.data_ptr(), x2d.data_ptr(), wcat.data_ptr(), bd.data_ptr(), None, yd.data_ptr(),
+                                    B, H, W, Cin, C2, Cout, k, 1, k // 2, {"none": 0, "relu": 1}[act], 0, out_f32)
+            assert rc != 0
+            continue
+        _capi.debug_option("conv_mode", mode)
+        yd = torch.full((B, H, W, Cout), float("nan"), dtype=torch.float32 if out_f32 else tdt, device="cuda")
+        ck(L, L.rtd_op_conv_dual(code, xd.data_ptr(), x2d.data_ptr(), wcat.data_ptr(), bd.data_ptr(), None, yd.data_ptr(),
+                                 B, H, W, Cin, C2, Cout, k, 1, k // 2, {"none": 0, "relu": 1}[act], 0, out_f32))
+        got = yd.float().cpu().permute(0, 3, 1, 2)
+        tol = dict(atol=2e-5, rtol=2e-5) if dt == "f32" else (dict(atol=3e-3, rtol=3e-3) if out_f32 else dict(atol=3e-2, rtol=1e-2))
+        torch.testing.assert_close(got, y, **tol)
+    _capi.debug_option("conv_mode", 0)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
@@ -92,8 +146,9 @@ def test_conv(L, dt, case):
     _capi.debug_option("splitk", 2)        # exercise the in-launch split-K reduction on every small-grid shape (default: tiny grids only)
     # conv_mode 0 = auto (LDS-DMA kernel where eligible), 2 = register-staged large tile, 1 = small tiles only,
     # 3 / 4 = wave-specialised LDS-DMA kernel (4 / 2 stages), 5 = single-role LDS-DMA kernel, 6 = wave-specialised with
-    # whole-K-step fragment prefetch, 7 = wave-specialised 256-pixel tile, 8 = A-stationary kernel wherever it is eligible (1x1, K <= 256, no residual)
-    for out_f32, mode in (((1, 0), (1, 1), (1, 2), (1, 3), (1, 6), (1, 7)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (1, 6), (0, 7), (1, 7), (0, 8))):
+    # whole-K-step fragment prefetch, 7 = wave-specialised 256-pixel tile, 8 = A-stationary kernel wherever it is eligible (1x1, K <= 256, no residual),
+    # 9 = streaming 1x1 kernel wherever it is eligible (K = 64 / 128, Cout % 64 == 0), whatever the grid size
+    for out_f32, mode in (((1, 0), (1, 1), (1, 2), (1, 3), (1, 6), (1, 7)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (1, 6), (0, 7), (1, 7), (0, 8), (0, 9))):
         _capi.debug_option("conv_mode", mode)
         yd = torch.full((B, OH, OW, Cout), float("nan"), dtype=torch.float32 if out_f32 else tdt, device="cuda")
         ck(L, L.rtd_op_conv(code, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None,

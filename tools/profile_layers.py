@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--ab", default="", help="debug option to A/B")
     ap.add_argument("--vals", default="1,0", help="two values of the option: baseline,candidate")
     ap.add_argument("--out", default="")
+    ap.add_argument("--opt", action="append", default=[], help="name=value set BEFORE the engine is created (plan-build switches such as sc_fold)")
     args = ap.parse_args()
     from telescope_cam_detection_amd import _capi
     from telescope_cam_detection_amd.arch import ARCHS
@@ -43,6 +44,9 @@ def main():
     arch = ARCHS[args.arch]
     blob = pack_blob(fold_weights(arch, synth_weights(arch, 0)))
     prec = _capi.PREC_FP32 if args.precision == "fp32" else _capi.PREC_BF16
+    for o in args.opt:
+        k, v = o.split("=")
+        _capi.debug_option(k, int(v))
     eng = _capi.Engine(arch, blob, 0, prec, args.batch, (args.size, args.size), use_graph=False)
     res = {}
     VALS = [int(v) for v in args.vals.split(",")]
