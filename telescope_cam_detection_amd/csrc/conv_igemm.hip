@@ -1876,11 +1876,16 @@ static bool dispatch_reg(const ConvK& k, const ConvArgs& a, long long x_bytes, h
 //     out-of-range offset drops the store: ragged last tile).
 // Arithmetic per output is the tiled kernels' (K in order into a zero accumulator, + bias, + residual, activation).
 // ------------------------------------------------------------------------------------------------
-template <int NKK, int THREADS, bool DUAL = false>   // DUAL: the second half of K comes from ConvK::x2 (same channel count as x)
+// SLAB: residual and output cross a wave-private LDS slab (32 rows x 128 bytes + 16 of bank skew, no block barrier) so that
+// their global accesses are row-shaped - 8 lanes x 16 bytes cover one pixel's 128-byte run, 8 lines per instruction instead of
+// 32 (tools/stream_probe.hip: 44 us against 53-61 us for the stage-0 c3 byte mix)
+template <int NKK, int THREADS, bool DUAL = false, bool SLAB = true>   // DUAL: the second half of K comes from ConvK::x2 (same channel count as x)
 __global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kernel(const ConvK a, unsigned x_bytes, unsigned r_bytes, unsigned y_bytes, unsigned x2_bytes, int CG, int ntiles) {
   constexpr int NW = THREADS / 64;
   __shared__ __attribute__((aligned(16))) float sbias[512];
   __shared__ __attribute__((aligned(16))) char pf_dummy[256];
+  constexpr int SROW = 144;
+  __shared__ __attribute__((aligned(16))) char slabs[SLAB ? NW : 1][SLAB ? 32 * SROW : 16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, pl = lane & 31;
@@ -1905,6 +1910,9 @@ __global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kern
   const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? a.x2 : a.x), 0, DUAL ? x2_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
   const float* bl = sbias + cb + 32 * h;
+  char* sl = slabs[SLAB ? wv : 0];
+  char* sl_acc = sl + pl * SROW + h * 64;                      // this lane's 64 bytes in accumulator shape (pixel pl, channels 32h..)
+  char* sl_row = sl + (lane >> 3) * SROW + (lane & 7) * 16;    // ... in row shape (pixel lane/8 + 8j, 16-byte chunk lane%8)
 
   dispatch_act(a.act, [&](auto actc) {
     constexpr int ACT = decltype(actc)::value;
@@ -1926,7 +1934,22 @@ __global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kern
         for (int kk = 0; kk < NKK; ++kk) xr[kk] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xo + 32 * kk : xo, 0, 0);
       }
       u32x4_ rv[4];
-      if (a.res_mode != RES_NONE) {
+      unsigned yrow[4];                                          // SLAB: byte offsets of this lane's 4 row-shaped output chunks
+      if (SLAB) {
+        int m2 = (t * PG + ps) * 32 + (lane >> 3);
+        const int b2 = m2 / a.OHW;
+        int p2 = m2 - b2 * a.OHW;
+        long long yo2 = (long long)b2 * a.y_bstride + (long long)p2 * a.ldy + cb + (lane & 7) * 8;
+        long long ro2 = (long long)b2 * a.r_bstride + (long long)p2 * a.ldr + cb + (lane & 7) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                            // rows 8 apart: carry (image, pixel)
+          const bool ok2 = m2 < a.M;
+          yrow[j] = ok2 ? (unsigned)(yo2 * 2) : 0x80000000u;
+          if (a.res_mode != RES_NONE) rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rr, ok2 ? (unsigned)(ro2 * 2) : 0x80000000u, 0, 0);
+          m2 += 8; p2 += 8; yo2 += 8 * a.ldy; ro2 += 8 * a.ldr;
+          while (p2 >= a.OHW) { p2 -= a.OHW; yo2 += a.y_bstride - (long long)a.OHW * a.ldy; ro2 += a.r_bstride - (long long)a.OHW * a.ldr; }
+        }
+      } else if (a.res_mode != RES_NONE) {
         const unsigned ro = ok ? (unsigned)(((long long)b * a.r_bstride + (long long)p * a.ldr + cb + 32 * h) * 2) : 0x80000000u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) rv[q] = __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? ro + 16 * q : ro, 0, 0);
@@ -1941,6 +1964,14 @@ __global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kern
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][kk], __builtin_bit_cast(bf16x8, xr[kk]), acc[i], 0, 0, 0);
       const unsigned yo = ok ? (unsigned)(((long long)b * a.y_bstride + (long long)p * a.ldy + cb + 32 * h) * 2) : 0x80000000u;
+      if (SLAB && a.res_mode != RES_NONE) {                      // residual: row shape -> slab -> accumulator shape
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(u32x4_*)(sl_row + j * 8 * SROW) = rv[j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rv[q] = *(const u32x4_*)(sl_acc + 16 * q);
+        __builtin_amdgcn_wave_barrier();
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 b0 = *(const f32x4*)(bl + 8 * q), b1 = *(const f32x4*)(bl + 8 * q + 4);
@@ -1964,7 +1995,157 @@ __global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kern
           for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
         const bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o), ry, ok ? yo + 16 * q : yo, 0, 0);
+        if (SLAB) *(u32x4_*)(sl_acc + 16 * q) = __builtin_bit_cast(u32x4_, o);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o), ry, ok ? yo + 16 * q : yo, 0, 0);
+      }
+      if (SLAB) {                                                // output: accumulator shape -> slab -> row-shaped stores
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_*)(sl_row + j * 8 * SROW), ry, yrow[j], 0, 0);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  });
+}
+
+// The same streaming scheme for the REDUCING 1x1 layers (K = 256 -> 64 / 128 channels: stage-0 c1, stage-1 block-0 c1), whose
+// bytes are mostly input: here the filter (32-64 KB) lives in LDS, rows stored in the lanes' read order (row L = 64 cg + 32 i + pl
+// holds channel 64 cg + 32 h(pl) + 16 i + 4 q(pl) + e(pl), see above: consecutive lanes read consecutive skewed rows, no bank
+// conflict), a wave owns ALL channels of its 32 pixels (loop over 64-channel groups: the input is read once), and the input
+// crosses the wave-private slab too: row-shaped 16-byte loads (8 lanes = one 128-byte line), then B-operand fragments from LDS.
+template <int NKK, int NCG, int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 : 3) void conv1x1_stream2_kernel(const ConvK a, unsigned x_bytes, unsigned r_bytes, unsigned y_bytes, int ntiles) {
+  constexpr int NW = THREADS / 64, K = NKK * 16, WROW = K * 2 + 16, SROW = 144, N = NCG * 64, NCH = NKK / 4;
+  __shared__ __attribute__((aligned(16))) char wl[N * WROW];
+  __shared__ __attribute__((aligned(16))) float sbias[N];
+  __shared__ __attribute__((aligned(16))) char slabs[NW][32 * SROW];
+  __shared__ __attribute__((aligned(16))) char pf_dummy[256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, pl = lane & 31;
+  for (int i = tid; i < N; i += THREADS) sbias[i] = a.bias[i];
+  {
+    const bf16* wg = (const bf16*)a.w;
+    constexpr int CPR = K / 8;                    // 16-byte chunks per filter row
+    for (int e = tid; e < N * CPR; e += THREADS) {
+      const int L = e / CPR, ch = e - L * CPR;
+      const int l = L & 31, i = (L >> 5) & 1, cg = L >> 6;
+      const int row = cg * 64 + 32 * ((l >> 2) & 1) + 16 * i + 4 * (l >> 3) + (l & 3);
+      *(bf16x8*)(wl + L * WROW + ch * 16) = *(const bf16x8*)(wg + (size_t)row * a.Kpad + ch * 8);
+    }
+  }
+  __syncthreads();
+  prefetch_share(a, blockIdx.x, gridDim.x, tid, THREADS, pf_dummy);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.x), 0, a.res ? r_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
+  char* sl = slabs[wv];
+  char* sl_acc = sl + pl * SROW + h * 64;                      // accumulator shape: pixel pl, channels 32h.. of the group
+  char* sl_frag = sl + pl * SROW + h * 16;                     // B-operand shape: pixel pl, K bytes 32 kk + 16 h of the chunk
+  char* sl_row = sl + (lane >> 3) * SROW + (lane & 7) * 16;    // row shape: pixel lane/8 + 8j, 16-byte piece lane%8
+  const char* wrow = wl + pl * WROW + h * 16;
+
+  dispatch_act(a.act, [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+    for (int t = blockIdx.x * NW + wv; t < ntiles; t += gridDim.x * NW) {
+      unsigned xrow[4], yrow[4], rrow[4];
+      {
+        int m2 = t * 32 + (lane >> 3);
+        const int b2 = m2 / a.OHW;
+        int p2 = m2 - b2 * a.OHW;
+        long long xo2 = (long long)b2 * a.x_bstride + (long long)p2 * a.ldx + (lane & 7) * 8;
+        long long yo2 = (long long)b2 * a.y_bstride + (long long)p2 * a.ldy + (lane & 7) * 8;
+        long long ro2 = (long long)b2 * a.r_bstride + (long long)p2 * a.ldr + (lane & 7) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                            // rows 8 apart: carry (image, pixel)
+          const bool ok2 = m2 < a.M;
+          xrow[j] = ok2 ? (unsigned)(xo2 * 2) : 0x80000000u;
+          yrow[j] = ok2 ? (unsigned)(yo2 * 2) : 0x80000000u;
+          rrow[j] = ok2 ? (unsigned)(ro2 * 2) : 0x80000000u;
+          m2 += 8; p2 += 8; xo2 += 8 * a.ldx; yo2 += 8 * a.ldy; ro2 += 8 * a.ldr;
+          while (p2 >= a.OHW) {
+            p2 -= a.OHW;
+            xo2 += a.x_bstride - (long long)a.OHW * a.ldx; yo2 += a.y_bstride - (long long)a.OHW * a.ldy; ro2 += a.r_bstride - (long long)a.OHW * a.ldr;
+          }
+        }
+      }
+      u32x4_ xraw[NCH][4];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xraw[c][j] = __builtin_amdgcn_raw_buffer_load_b128(rx, xrow[j] + (xrow[j] >> 31 ? 0u : (unsigned)(c * 128)), 0, 0);
+      u32x4_ rv[4];
+      if (a.res_mode != RES_NONE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rr, rrow[j], 0, 0);
+      }
+      bf16x8 xf[NKK];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {                            // input: row shape -> slab -> fragments, one 128-byte column chunk at a time
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(u32x4_*)(sl_row + j * 8 * SROW) = xraw[c][j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xf[c * 4 + kk] = *(const bf16x8*)(sl_frag + kk * 32);
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll 1
+      for (int cg = 0; cg < NCG; ++cg) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        const char* wc = wrow + cg * 64 * WROW;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(wc + i * 32 * WROW + kk * 32), xf[kk], acc[i], 0, 0, 0);
+        u32x4_ rq[4];
+        if (a.res_mode != RES_NONE) {                            // residual: row shape -> slab -> accumulator shape
+#pragma unroll
+          for (int j = 0; j < 4; ++j) *(u32x4_*)(sl_row + j * 8 * SROW) = rv[j];
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rq[q] = *(const u32x4_*)(sl_acc + 16 * q);
+          __builtin_amdgcn_wave_barrier();
+          if (cg + 1 < NCG) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rr, rrow[j] + (rrow[j] >> 31 ? 0u : (unsigned)((cg + 1) * 128)), 0, 0);
+          }
+        }
+        const float* bl = sbias + cg * 64 + 32 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b0 = *(const f32x4*)(bl + 8 * q), b1 = *(const f32x4*)(bl + 8 * q + 4);
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = acc[q >> 1][8 * (q & 1) + e] + (e < 4 ? b0[e & 3] : b1[e & 3]);
+          float r[8];
+          if (a.res_mode != RES_NONE) {
+            const bf16x8 rb = __builtin_bit_cast(bf16x8, rq[q]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = (float)rb[e];
+          }
+          if (a.res_mode == RES_PRE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = act_c<ACT>(v[e]);
+          if (a.res_mode == RES_POST) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+          }
+          const bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+          *(u32x4_*)(sl_acc + 16 * q) = __builtin_bit_cast(u32x4_, o);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_*)(sl_row + j * 8 * SROW), ry, yrow[j] + (yrow[j] >> 31 ? 0u : (unsigned)(cg * 128)), 0, 0);
+        __builtin_amdgcn_wave_barrier();
       }
     }
   });
@@ -1972,6 +2153,10 @@ __global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kern
 
 static int g_conv_stream = 1;    // A/B hook (rtd_debug_option "conv_stream"): 0 = the thin 1x1 layers stay on the tiled kernels
 static int g_stream_min_tiles = 2048;
+static int g_stream2 = 1;        // A/B hook (rtd_debug_option "stream2"): 0 = the reducing 1x1 layers (K = 256) stay on the tiled kernels
+void conv_set_stream2(int v) { g_stream2 = v; }
+static int g_stream_slab = 1;    // A/B hook (rtd_debug_option "stream_slab"): 0 = accumulator-shaped global accesses
+void conv_set_stream_slab(int v) { g_stream_slab = v; }
 void conv_set_stream(int v) { g_conv_stream = v; }
 void conv_set_stream_min_tiles(int v) { g_stream_min_tiles = v; }
 
@@ -1984,6 +2169,25 @@ static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes
   if (x.dt != BF16 || y.dt != BF16 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0) return false;
   if (a.res_mode != RES_NONE && a.res.dt != BF16) return false;
   if (dual && !(x.c == 64 && a.x2.c == 64)) return false;
+  if (!dual && x.c == 256 && a.Kpad == 256 && (y.c == 64 || y.c == 128) && g_stream2) {
+    // reducing layers: filter in LDS, a wave owns all channels of its pixels
+    if (x.ld % 8 || y.ld % 8 || ((uintptr_t)y.p & 15)) return false;
+    if (a.res_mode != RES_NONE && (a.res.ld % 8 || ((uintptr_t)a.res.p & 15))) return false;
+    const long long y_bytes = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * 2;
+    long long r_bytes = 0;
+    if (a.res_mode != RES_NONE) r_bytes = ((long long)(a.res.n - 1) * a.res.bstride + ((long long)a.res.h * a.res.w - 1) * a.res.ld + a.res.c) * 2;
+    if (x_bytes >= (1ll << 31) || y_bytes >= (1ll << 31) || r_bytes >= (1ll << 31)) return false;
+    const long long ntiles = ((long long)k.M + 31) / 32;
+    if ((ntiles < g_stream_min_tiles && g_conv_mode != 9) || ntiles >= (1ll << 30)) return false;
+    if (y.c == 64) {        // 52 KB of LDS per 4-wave block: 3 blocks per CU
+      const unsigned gx = (unsigned)std::min<long long>((ntiles + 3) / 4, 768);
+      hipLaunchKernelGGL((conv1x1_stream2_kernel<16, 1, 256>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes, (int)ntiles);
+    } else {                // 105 KB per 8-wave block: one block per CU
+      const unsigned gx = (unsigned)std::min<long long>((ntiles + 7) / 8, 256);
+      hipLaunchKernelGGL((conv1x1_stream2_kernel<16, 2, 512>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes, (int)ntiles);
+    }
+    return true;
+  }
   const int K = x.c + (dual ? a.x2.c : 0);
   if (!(K == 64 || K == 128) || a.Kpad != K || y.c % 64 || y.c > 512 || x.ld % 8 || y.ld % 8 || ((uintptr_t)y.p & 15)) return false;
   if (a.res_mode != RES_NONE && (a.res.ld % 8 || ((uintptr_t)a.res.p & 15))) return false;
@@ -1998,10 +2202,17 @@ static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes
   const long long ntiles = ((long long)k.M + 32 * PG - 1) / (32 * PG);
   if ((ntiles * NW < g_stream_min_tiles && g_conv_mode != 9) || ntiles >= (1ll << 30)) return false;
   // persistent blocks, as many as the register budget keeps resident (K = 64: 3 waves per SIMD, K = 128: 2)
-  const unsigned gx = (unsigned)std::min<long long>(ntiles, K == 64 ? (NW == 8 ? 256 : 768) : (NW == 8 ? 256 : 512));
-#define RTD_STREAM(NKK, THREADS, DUAL)                                                                                   \
-  hipLaunchKernelGGL((conv1x1_stream_kernel<NKK, THREADS, DUAL>), dim3(gx), dim3(THREADS), 0, s, k, (unsigned)x_bytes, \
-                     (unsigned)r_bytes, (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles)
+  // (the slab variant of K = 64 needs 128 VGPRs: 4 waves per SIMD)
+  const unsigned gx = (unsigned)std::min<long long>(ntiles, K == 64 ? (NW == 8 ? 256 : (g_stream_slab ? 1024 : 768)) : (NW == 8 ? 256 : 512));
+#define RTD_STREAM(NKK, THREADS, DUAL)                                                                                                \
+  do {                                                                                                                                \
+    if (g_stream_slab)                                                                                                                \
+      hipLaunchKernelGGL((conv1x1_stream_kernel<NKK, THREADS, DUAL, true>), dim3(gx), dim3(THREADS), 0, s, k, (unsigned)x_bytes,      \
+                         (unsigned)r_bytes, (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles);                                  \
+    else                                                                                                                              \
+      hipLaunchKernelGGL((conv1x1_stream_kernel<NKK, THREADS, DUAL, false>), dim3(gx), dim3(THREADS), 0, s, k, (unsigned)x_bytes,     \
+                         (unsigned)r_bytes, (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles);                                  \
+  } while (0)
   if (K == 64) {
     if (NW == 8) RTD_STREAM(4, 512, false);
     else RTD_STREAM(4, 256, false);

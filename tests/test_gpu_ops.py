@@ -63,6 +63,10 @@ CONV_CASES = [
     (1, 45, 31, 64, 64, 1, 1, 0, "silu", 2),       # one channel group, four pixel sub-tiles per block, post-activation residual
     (3, 33, 33, 128, 128, 1, 1, 0, "none", 0),     # two channel groups
     (2, 96, 100, 64, 256, 1, 1, 0, "none", 0),     # stage-0 shortcut family (linear)
+    # reducing 1x1 layers (K = 256 -> 64 / 128): streaming kernel with the filter in LDS
+    (1, 70, 50, 256, 64, 1, 1, 0, "relu", 0),      # ragged last pixel tile
+    (2, 40, 40, 256, 128, 1, 1, 0, "silu", 1),     # two channel groups per wave, residual through the slab
+    (4, 128, 128, 256, 64, 1, 1, 0, "relu", 0),    # 2048 tiles: taken in mode 0 too
 ]
 
 
@@ -148,7 +152,9 @@ def test_conv(L, dt, case):
     # 3 / 4 = wave-specialised LDS-DMA kernel (4 / 2 stages), 5 = single-role LDS-DMA kernel, 6 = wave-specialised with
     # whole-K-step fragment prefetch, 7 = wave-specialised 256-pixel tile, 8 = A-stationary kernel wherever it is eligible (1x1, K <= 256, no residual),
     # 9 = streaming 1x1 kernel wherever it is eligible (K = 64 / 128, Cout % 64 == 0), whatever the grid size
-    for out_f32, mode in (((1, 0), (1, 1), (1, 2), (1, 3), (1, 6), (1, 7)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (1, 6), (0, 7), (1, 7), (0, 8), (0, 9))):
+    for out_f32, mode in (((1, 0), (1, 1), (1, 2), (1, 3), (1, 6), (1, 7)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (1, 6), (0, 7), (1, 7), (0, 8), (0, 9), (0, 109))):
+        _capi.debug_option("stream_slab", 0 if mode >= 100 else 1)      # 109 = mode 9 with accumulator-shaped global accesses
+        mode %= 100
         _capi.debug_option("conv_mode", mode)
         yd = torch.full((B, OH, OW, Cout), float("nan"), dtype=torch.float32 if out_f32 else tdt, device="cuda")
         ck(L, L.rtd_op_conv(code, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None,
@@ -164,6 +170,7 @@ def test_conv(L, dt, case):
             tol = dict(atol=2e-2, rtol=1e-2)       # + one bf16 rounding of the output
         torch.testing.assert_close(got, y, **tol)
     _capi.debug_option("conv_mode", 0)
+    _capi.debug_option("stream_slab", 1)
     _capi.debug_option("splitk", 0)
 
 
