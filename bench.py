@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--streams", type=int, default=3, help="engine handles (batches in flight) per GPU")
+    ap.add_argument("--latency-profile", action="store_true", help="A/B: the handles of a multi-handle run use the latency profile too")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
@@ -93,9 +94,16 @@ def main():
     blob = pack_blob(fold_weights(arch, w))
     prec = _capi.PREC_FP32 if args.precision == "fp32" else _capi.PREC_BF16
     S = max(1, args.streams)
-    engs = [_capi.Engine(arch, blob, device=local_rank, precision=prec, max_batch=B, input_size=(H, H), use_graph=not args.no_graph)
-            for _ in range(S)]
+    # several handles per GPU run the throughput profile (rtd_config.profile: 256-pixel conv tiles); the one-batch-in-flight
+    # figure, the kernel profile / roofline and the latency line come from a latency-profile handle, which is also what
+    # `--streams 1` (the rocprofv3 runs under profiles/) measures
+    prof_mode = _capi.PROFILE_THROUGHPUT if (S > 1 and not args.latency_profile) else _capi.PROFILE_LATENCY
+    engs = [_capi.Engine(arch, blob, device=local_rank, precision=prec, max_batch=B, input_size=(H, H), use_graph=not args.no_graph,
+                         profile=prof_mode) for _ in range(S)]
     eng = engs[0]
+    eng_lat = eng
+    if prof_mode != _capi.PROFILE_LATENCY:
+        eng_lat = _capi.Engine(arch, blob, device=local_rank, precision=prec, max_batch=B, input_size=(H, H), use_graph=not args.no_graph)
     # frame i of config c = default_rng(1000*c+i).integers(0,255,(H,W,3),uint8); camera k -> rank k
     frames_of = [[torch.from_numpy(noise_frame(2000 + (rank * S + si) * B + i, H, H)).cuda() for i in range(B)] for si in range(S)]
     frames = frames_of[0]
@@ -107,8 +115,13 @@ def main():
     if world > 1:
         gathered = [torch.empty(world * B * Q * 6, dtype=torch.float32, device="cuda") for _ in range(S)]
 
+    prepared_lat = eng_lat.make_async_args(frames) if eng_lat is not eng else prepared[0]
+
     def step(k, n_handles):
         si = k % n_handles
+        if n_handles == 1 and world == 1:        # one batch in flight: the latency-profile handle
+            eng_lat.infer_async_prepared(prepared_lat)
+            return
         engs[si].infer_async_prepared(prepared[si])
         if world > 1:
             ptr, n = engs[si].result_block()
@@ -119,6 +132,7 @@ def main():
     def fence():
         for e in engs:
             e.sync()
+        eng_lat.sync()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -148,7 +162,7 @@ def main():
         "config": {"workload": f"RT-DETR-{args.arch.upper()} {H}x{H} bs={B}/GPU, uint8 BGR frames resident in HBM -> "
                                f"[{B},{Q},6] detections in HBM; synthetic seeded weights",
                    "global_batch": world * B, "parallelism": f"camera-shard x{world}" + (" + RCCL all_gather of detections" if world > 1 else ""),
-                   "streams_per_gpu": S, "batches_in_flight_per_gpu": S, "hip_graph": not args.no_graph},
+                   "streams_per_gpu": S, "batches_in_flight_per_gpu": S, "kernel_profile": "throughput" if prof_mode == _capi.PROFILE_THROUGHPUT else "latency", "hip_graph": not args.no_graph},
     }
     if single is not None:
         out["single_stream"] = {"value": round(world * B * args.steps / single, 2), "unit": "frames/s",
@@ -160,7 +174,7 @@ def main():
     if rank == 0:
         # ---- per-kernel HIP-event profile on the engine's stream -> roofline of the dominant kernel ----
         print(f"[bench] {fps:.1f} frames/s; profiling kernels ...", file=sys.stderr, flush=True)
-        prof = eng.profile(B, reps=5)
+        prof = eng_lat.profile(B, reps=5)
         fam = {}
         for p in prof:
             f = fam.setdefault(p["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
@@ -204,7 +218,7 @@ def main():
             one = [frames[0]]
             for i in range(60):
                 t1 = time.perf_counter()
-                eng.infer(one, 0.25, True, on_device=True)
+                eng_lat.infer(one, 0.25, True, on_device=True)
                 if i >= 10:
                     lat.append((time.perf_counter() - t1) * 1e3)
             out["p50_ms_per_frame_bs1"] = round(float(np.percentile(lat, 50)), 4)
@@ -230,6 +244,8 @@ def main():
         print(json.dumps(out), flush=True)
     for e in engs:
         e.close()
+    if eng_lat is not eng:
+        eng_lat.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

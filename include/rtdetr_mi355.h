@@ -42,6 +42,8 @@ enum { RTD_LAYER_BASIC = 0, RTD_LAYER_BOTTLENECK = 1 };
 /* Constructor arguments of RTDETRDetector (src/rtdetr_detector.py:29-58) that matter to the device
  * side, plus the network description the reference obtains from upstream's YAML config
  * (src/rtdetr_detector.py:132).  Field order is ABI; struct_size guards it. */
+enum { RTD_PROFILE_LATENCY = 0, RTD_PROFILE_THROUGHPUT = 1 };
+
 typedef struct rtd_config {
   int32_t struct_size;      /* = sizeof(rtd_config) */
   int32_t device;           /* HIP ordinal  <- `device="cuda:N"` (:33) */
@@ -58,6 +60,11 @@ typedef struct rtd_config {
   int32_t d_model, dec_ffn, dec_heads, dec_layers;
   int32_t num_queries, num_classes, n_levels, n_points;
   float offset_scale;
+  /* RTD_PROFILE_*: which way the kernel dispatch leans.  LATENCY (0): one batch in flight owns the GPU - tiles sized so that
+   * every launch fills the CUs with the shortest critical path.  THROUGHPUT (1): several handles keep batches in flight on one
+   * GPU (batching pipeline_depth > 1, bench.py --streams > 1) - other launches fill idle CUs anyway, so the convs take the
+   * 256-pixel tile with the least LDS traffic per MFMA (+2.6 % frames/s with 3 handles, -6 % for a lone handle). */
+  int32_t profile;
 } rtd_config;
 
 /* One detection row: what the per-row loop of src/rtdetr_detector.py:267-303 emits before it

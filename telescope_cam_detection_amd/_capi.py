@@ -29,7 +29,7 @@ class RtdConfig(C.Structure):
         ("enc_dim", C.c_int32), ("enc_ffn", C.c_int32), ("enc_heads", C.c_int32), ("csp_hidden", C.c_int32),
         ("d_model", C.c_int32), ("dec_ffn", C.c_int32), ("dec_heads", C.c_int32), ("dec_layers", C.c_int32),
         ("num_queries", C.c_int32), ("num_classes", C.c_int32), ("n_levels", C.c_int32), ("n_points", C.c_int32),
-        ("offset_scale", C.c_float),
+        ("offset_scale", C.c_float), ("profile", C.c_int32),
     ]
 
 
@@ -132,7 +132,11 @@ def _raise(code: int, handle) -> None:
     raise RtdError(code, msg)
 
 
-def make_config(arch: Arch, device: int, precision: int, max_batch: int, input_size, use_graph: bool) -> RtdConfig:
+PROFILE_LATENCY, PROFILE_THROUGHPUT = 0, 1
+
+
+def make_config(arch: Arch, device: int, precision: int, max_batch: int, input_size, use_graph: bool,
+                profile: int = PROFILE_LATENCY) -> RtdConfig:
     c = RtdConfig()
     c.struct_size = C.sizeof(RtdConfig)
     c.device, c.precision, c.max_batch = device, precision, max_batch
@@ -146,6 +150,7 @@ def make_config(arch: Arch, device: int, precision: int, max_batch: int, input_s
     c.d_model, c.dec_ffn, c.dec_heads, c.dec_layers = arch.d_model, arch.dec_ffn, arch.dec_heads, arch.dec_layers
     c.num_queries, c.num_classes, c.n_levels, c.n_points = arch.num_queries, arch.num_classes, arch.n_levels, arch.n_points
     c.offset_scale = arch.offset_scale
+    c.profile = profile
     return c
 
 
@@ -153,12 +158,12 @@ class Engine:
     """Thin RAII wrapper of one rtd_handle."""
 
     def __init__(self, arch: Arch, blob: bytes, device: int = 0, precision: int = PREC_BF16, max_batch: int = 8,
-                 input_size=(640, 640), use_graph: bool = True):
+                 input_size=(640, 640), use_graph: bool = True, profile: int = PROFILE_LATENCY):
         self.arch = arch
         self.num_queries = arch.num_queries
         self.max_batch = max_batch
         self._h = C.c_void_p()
-        cfg = make_config(arch, device, precision, max_batch, input_size, use_graph)
+        cfg = make_config(arch, device, precision, max_batch, input_size, use_graph, profile)
         rc = lib().rtd_create(C.byref(cfg), C.byref(self._h))
         if rc != RTD_OK:
             self._h = C.c_void_p()

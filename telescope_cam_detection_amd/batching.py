@@ -275,6 +275,9 @@ def make_rtdetr_coordinator(config: Dict[str, Any], coordinator_cls=None, detect
     rt = detection.get("rtdetr", {})
     max_batch = int(batching.get("max_batch_size", 4))
     depth = int(batching.get("pipeline_depth", 1))      # build-specific key: batches in flight (2 = +35 % throughput on one MI355X)
+    # several detectors share the GPU: their kernels lean towards throughput (rtd_config.profile); the reference's own
+    # detector class knows no such argument and is never built with depth > 1
+    prof = {"profile": "throughput"} if depth > 1 else {}
     try:
         detector = detector_cls(
             config_path=rt.get("config_path", "RT-DETR/rtdetrv2_pytorch/configs/rtdetrv2/rtdetrv2_r18vd_120e_coco.yml"),
@@ -284,6 +287,7 @@ def make_rtdetr_coordinator(config: Dict[str, Any], coordinator_cls=None, detect
             input_size=tuple(detection.get("input_size", [640, 640])),
             wildlife_only=detection.get("wildlife_only", True),
             max_batch=max_batch,
+            **prof,
         )
         if not detector.load_model():
             logger.error("Failed to load RT-DETR detector for coordinator")
@@ -293,7 +297,7 @@ def make_rtdetr_coordinator(config: Dict[str, Any], coordinator_cls=None, detect
             for _ in range(depth - 1):
                 d2 = detector_cls(config_path=detector.config_path, model_path=detector.model_path, device=detector.device,
                                   conf_threshold=detector.conf_threshold, input_size=detector.input_size,
-                                  wildlife_only=detector.wildlife_only, max_batch=max_batch)
+                                  wildlife_only=detector.wildlife_only, max_batch=max_batch, **prof)
                 if not d2.load_model():
                     logger.error("Failed to load a pipeline detector; falling back to one batch in flight")
                     extra = []

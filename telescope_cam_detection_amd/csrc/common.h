@@ -78,6 +78,7 @@ struct ConvArgs {
   // y = act(W3 * t + Wsc * x_in + (b3 + bsc)) without writing / re-reading the shortcut tensor.  KH*KW*Cin must be a multiple of
   // one K-step (64 bf16 / 32 fp32); see conv_dual_supported().
   Tensor x2;
+  int prefer256 = 0;   // throughput profile (rtd_config.profile): take the 256-pixel tile from 100 blocks on
   Tensor y;            // output [B,OH,OW,N] (view)
   int KH = 1, KW = 1, stride = 1, pad = 0;
   int Kpad = 0, Npad = 0;

@@ -45,6 +45,7 @@ struct ConvK {
   const void* x2;        // second input (ConvArgs::x2) or nullptr; K elements k2_start.. come from it
   long long ldx2, x2_bstride;
   int k2_start;
+  int prefer256;         // ConvArgs::prefer256
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -1634,7 +1635,8 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
   }
   {
     const long long mt256 = (k.M + 255) / 256;
-    if (g_conv_mode == 7 || (g_conv_mode == 0 && g_ws256_min_blocks > 0 && mt256 * ntn >= g_ws256_min_blocks)) {
+    const int min256 = k.prefer256 ? 100 : g_ws256_min_blocks;
+    if (g_conv_mode == 7 || (g_conv_mode == 0 && min256 > 0 && mt256 * ntn >= min256)) {
       g.slab = ws.slab;
       hipLaunchKernelGGL((conv_igemm_ws256_kernel<T>), dim3((unsigned)(mt256 * ntn)), dim3(512), 0, s, g);
       return true;
@@ -2336,6 +2338,7 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
   }
   k.ntn = 1;
   k.reg_epi = g_reg_epilogue;
+  k.prefer256 = a.prefer256;
   k.pf = g_prefetch ? a.pf : nullptr;
   k.pf_bytes = (g_prefetch && a.pf && a.pf_bytes < (1ull << 31)) ? (unsigned)a.pf_bytes : 0u;
   const bool smallc = (x.c % 32) != 0;

@@ -457,6 +457,7 @@ struct Builder {
     a.act = act; a.res_mode = res ? res_mode : RES_NONE;
     if (res) a.res = *res;
     a.ws = e->conv_ws;
+    a.prefer256 = e->cfg.profile == RTD_PROFILE_THROUGHPUT;
     const double M = (double)y.pixels();
     const double kreal = (double)k * k * (real_cin ? real_cin : x.c) + (x2 ? x2->c : 0);
     const double flops = 2.0 * M * y.c * kreal;
@@ -1122,6 +1123,7 @@ int rtd_create(const rtd_config* cfg, rtd_handle* out) {
     RTD_CHECK(cfg->struct_size == (int32_t)sizeof(rtd_config), RTD_E_INVALID, "rtd_config.struct_size mismatch");
     RTD_CHECK(cfg->precision == RTD_PREC_BF16 || cfg->precision == RTD_PREC_FP32, RTD_E_INVALID, "precision");
     RTD_CHECK(cfg->max_batch >= 1 && cfg->max_batch <= 64, RTD_E_INVALID, "max_batch must be in [1,64]");
+    RTD_CHECK(cfg->profile == RTD_PROFILE_LATENCY || cfg->profile == RTD_PROFILE_THROUGHPUT, RTD_E_INVALID, "profile");
     // the FPN concatenates a 2x-upsampled map with the next level: every level must halve exactly
     RTD_CHECK(cfg->input_h >= 64 && cfg->input_w >= 64 && cfg->input_h % 32 == 0 && cfg->input_w % 32 == 0 &&
                   cfg->input_h <= 4096 && cfg->input_w <= 4096, RTD_E_INVALID, "input size must be a multiple of 32 in [64,4096]");

@@ -79,6 +79,7 @@ class RTDETRDetector:
         precision: str = "bf16",
         max_batch: int = 8,
         use_graph: bool = True,
+        profile: str = "latency",
     ):
         self.config_path = config_path
         self.model_path = model_path
@@ -90,6 +91,9 @@ class RTDETRDetector:
         self.precision = precision
         self.max_batch = max_batch
         self.use_graph = use_graph
+        # "latency": this detector usually has the GPU to itself; "throughput": several detectors keep batches in flight on one
+        # GPU (batching.BatchCoordinator with pipeline_depth > 1) - see rtd_config.profile in include/rtdetr_mi355.h
+        self.profile = profile
 
         self.model: Optional[_DeviceModel] = None
         self.postprocessor = None
@@ -114,7 +118,8 @@ class RTDETRDetector:
                 blob = pack_blob(fold_weights(arch, state))
                 prec = _capi.PREC_FP32 if str(self.precision).lower() in ("fp32", "f32", "float32") else _capi.PREC_BF16
                 engine = _capi.Engine(arch, blob, device=dev, precision=prec, max_batch=self.max_batch,
-                                      input_size=tuple(self.input_size), use_graph=self.use_graph)
+                                      input_size=tuple(self.input_size), use_graph=self.use_graph,
+                                      profile=_capi.PROFILE_THROUGHPUT if str(self.profile).lower() == "throughput" else _capi.PROFILE_LATENCY)
                 self.arch = arch
                 self.model = _DeviceModel(engine, self.device)
                 logger.info("RT-DETRv2 loaded successfully")

@@ -18,12 +18,13 @@ from tests.util import load_case, match_detections, weights_for
 pytestmark = pytest.mark.gpu
 
 
-def make_engine(arch, w, frames, input_size, precision, use_graph=False):
+def make_engine(arch, w, frames, input_size, precision, use_graph=False, profile=0):
     from telescope_cam_detection_amd import _capi
     from telescope_cam_detection_amd.weights import fold_weights, pack_blob
     blob = pack_blob(fold_weights(arch, w))
     prec = _capi.PREC_FP32 if precision == "fp32" else _capi.PREC_BF16
-    return _capi.Engine(arch, blob, device=0, precision=prec, max_batch=len(frames), input_size=input_size, use_graph=use_graph)
+    return _capi.Engine(arch, blob, device=0, precision=prec, max_batch=len(frames), input_size=input_size, use_graph=use_graph,
+                        profile=profile)
 
 
 def oracle_run(arch, w, frames, input_size):
@@ -125,6 +126,27 @@ def test_full_size_properties_bf16_bs8():
     print(f"bs8 vs bs1 (bf16): matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
     assert m >= n - 30
     eng.close()
+
+
+def test_throughput_profile_equals_latency_profile():
+    """rtd_config.profile only changes which conv tile runs a layer (256- instead of 128-pixel tiles from 100 blocks on): the
+    K order of every output is the same, so the detections must agree to the last bit of the accumulation."""
+    from telescope_cam_detection_amd import _capi
+    from telescope_cam_detection_amd.synth import noise_frame, scene_frame
+    from telescope_cam_detection_amd.arch import ARCHS
+    arch = ARCHS["r50"]
+    w = weights_for(arch, 0)
+    frames = [scene_frame(70 + i, 640, 640) if i % 2 else noise_frame(70 + i, 640, 640) for i in range(4)]
+    e1 = make_engine(arch, w, frames, (640, 640), "bf16", use_graph=True, profile=_capi.PROFILE_LATENCY)
+    e2 = make_engine(arch, w, frames, (640, 640), "bf16", use_graph=True, profile=_capi.PROFILE_THROUGHPUT)
+    a = e1.infer_raw(frames)
+    b = e2.infer_raw(frames)
+    k1 = {p["name"]: p["ms"] for p in e1.profile(4, 2)}
+    k2 = {p["name"]: p["ms"] for p in e2.profile(4, 2)}
+    assert k1.keys() == k2.keys()
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    e1.close(); e2.close()
 
 
 @pytest.mark.parametrize("name", ["t_tiny_160", "c1_r18_640_scene"])
