@@ -2025,9 +2025,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 : 3) void conv1x1_strea
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, pl = lane & 31;
-  for (int i = tid; i < N; i += THREADS) sbias[i] = a.bias[i];
+  const int cblk = blockIdx.y * N;                              // wider layers: gridDim.y blocks of N channels each (the input is re-read per block, from L2)
+  for (int i = tid; i < N; i += THREADS) sbias[i] = a.bias[cblk + i];
   {
-    const bf16* wg = (const bf16*)a.w;
+    const bf16* wg = (const bf16*)a.w + (size_t)cblk * a.Kpad;
     constexpr int CPR = K / 8;                    // 16-byte chunks per filter row
     for (int e = tid; e < N * CPR; e += THREADS) {
       const int L = e / CPR, ch = e - L * CPR;
@@ -2037,7 +2038,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 : 3) void conv1x1_strea
     }
   }
   __syncthreads();
-  prefetch_share(a, blockIdx.x, gridDim.x, tid, THREADS, pf_dummy);
+  prefetch_share(a, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, tid, THREADS, pf_dummy);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.x), 0, a.res ? r_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
@@ -2056,8 +2057,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 : 3) void conv1x1_strea
         const int b2 = m2 / a.OHW;
         int p2 = m2 - b2 * a.OHW;
         long long xo2 = (long long)b2 * a.x_bstride + (long long)p2 * a.ldx + (lane & 7) * 8;
-        long long yo2 = (long long)b2 * a.y_bstride + (long long)p2 * a.ldy + (lane & 7) * 8;
-        long long ro2 = (long long)b2 * a.r_bstride + (long long)p2 * a.ldr + (lane & 7) * 8;
+        long long yo2 = (long long)b2 * a.y_bstride + (long long)p2 * a.ldy + cblk + (lane & 7) * 8;
+        long long ro2 = (long long)b2 * a.r_bstride + (long long)p2 * a.ldr + cblk + (lane & 7) * 8;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                            // rows 8 apart: carry (image, pixel)
           const bool ok2 = m2 < a.M;
@@ -2171,7 +2172,7 @@ static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes
   if (x.dt != BF16 || y.dt != BF16 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0) return false;
   if (a.res_mode != RES_NONE && a.res.dt != BF16) return false;
   if (dual && !(x.c == 64 && a.x2.c == 64)) return false;
-  if (!dual && x.c == 256 && a.Kpad == 256 && (y.c == 64 || y.c == 128) && g_stream2) {
+  if (!dual && x.c == 256 && a.Kpad == 256 && (y.c == 64 || y.c % 128 == 0) && y.c <= 2048 && g_stream2) {
     // reducing layers: filter in LDS, a wave owns all channels of its pixels
     if (x.ld % 8 || y.ld % 8 || ((uintptr_t)y.p & 15)) return false;
     if (a.res_mode != RES_NONE && (a.res.ld % 8 || ((uintptr_t)a.res.p & 15))) return false;
@@ -2180,7 +2181,15 @@ static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes
     if (a.res_mode != RES_NONE) r_bytes = ((long long)(a.res.n - 1) * a.res.bstride + ((long long)a.res.h * a.res.w - 1) * a.res.ld + a.res.c) * 2;
     if (x_bytes >= (1ll << 31) || y_bytes >= (1ll << 31) || r_bytes >= (1ll << 31)) return false;
     const long long ntiles = ((long long)k.M + 31) / 32;
-    if ((ntiles < g_stream_min_tiles && g_conv_mode != 9) || ntiles >= (1ll << 30)) return false;
+    const int ny = y.c <= 128 ? 1 : y.c / 128;                  // expanding layers (stage-2 c3: 256 -> 1024): 128 channels per block
+    if ((ntiles * ny < g_stream_min_tiles && g_conv_mode != 9) || ntiles >= (1ll << 30)) return false;
+    if (ny > 1) {
+      // one 8-wave block per CU; whole rounds of wave tiles, so that no wave of a block has one tile more than another
+      const long long rounds = (ntiles * ny + 2047) / 2048;
+      const unsigned gx = (unsigned)std::max<long long>(1, (ntiles + 8 * rounds - 1) / (8 * rounds));
+      hipLaunchKernelGGL((conv1x1_stream2_kernel<16, 2, 512>), dim3(gx, ny), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes, (int)ntiles);
+      return true;
+    }
     if (y.c == 64) {        // 52 KB of LDS per 4-wave block: 3 blocks per CU
       const unsigned gx = (unsigned)std::min<long long>((ntiles + 3) / 4, 768);
       hipLaunchKernelGGL((conv1x1_stream2_kernel<16, 1, 256>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes, (int)ntiles);

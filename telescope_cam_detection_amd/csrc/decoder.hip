@@ -136,7 +136,7 @@ __device__ __forceinline__ void split_rows(const float* Xs, int ldx, int K, bf16
 // v_mfma_f32_16x16x32_bf16 per 32-deep chunk (lo*hi, hi*lo, hi*hi; fp32 accumulate) instead of 8 v_mfma_f32_16x16x4_f32:
 // 5x less MFMA time for the same filter bytes, products exact to ~2^-17.  A lane's fragments: A[row = lane & 15][32c + 8 (lane >> 4) .. +7],
 // W[n0 + (lane & 15)][same k].  Output: fp32 Ys and / or a hi/lo split (Yh, Yl) for a following GEMM.
-template <int ACT>
+template <int ACT, bool WLO = true>   // WLO = false: the filter's lo half is neither loaded nor multiplied (bf16 filter, split activations)
 __device__ void row_gemm_split(const bf16* Ah, const bf16* Al, int lda, const DecLin& L, float* Ys, int ldy, const float* Rs, int ldr,
                                bf16* Yh, bf16* Yl, int ldyb, int wave, int lane, int rot) {
   const int ntiles = (L.N + 15) >> 4;
@@ -163,9 +163,9 @@ __device__ void row_gemm_split(const bf16* Ah, const bf16* Al, int lda, const De
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         h0[j] = *(const bf16x8_*)(w0 + (step << 1) * 2048 + 2048 * j);
-        l0[j] = *(const bf16x8_*)(w0 + (step << 1) * 2048 + 2048 * j + 1024);
+        if (WLO) l0[j] = *(const bf16x8_*)(w0 + (step << 1) * 2048 + 2048 * j + 1024);
         h1[j] = *(const bf16x8_*)(w1 + (step << 1) * 2048 + 2048 * j);
-        l1[j] = *(const bf16x8_*)(w1 + (step << 1) * 2048 + 2048 * j + 1024);
+        if (WLO) l1[j] = *(const bf16x8_*)(w1 + (step << 1) * 2048 + 2048 * j + 1024);
       }
     };
     auto mma = [&](const bf16x8_ (&h0)[2], const bf16x8_ (&l0)[2], const bf16x8_ (&h1)[2], const bf16x8_ (&l1)[2], int step) {
@@ -175,8 +175,10 @@ __device__ void row_gemm_split(const bf16* Ah, const bf16* Al, int lda, const De
         const bf16x8_ xh = *(const bf16x8_*)(ah + k0 + 32 * j), xl = *(const bf16x8_*)(al + k0 + 32 * j);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, h0[j], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, h1[j], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, l0[j], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, l1[j], acc1, 0, 0, 0);
+        if (WLO) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, l0[j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, l1[j], acc1, 0, 0, 0);
+        }
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, h0[j], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, h1[j], acc1, 0, 0, 0);
       }
@@ -428,7 +430,7 @@ __device__ __forceinline__ void touch_weights(const DecLin& L, int part, int npa
 // SPLIT: the linear layers take hi/lo bf16 splits of their operands (row_gemm_split); every fp32 A operand of K <= 256 is split
 // into the sXh/sXl staging rows right before its GEMM, the two wide ones (FFN hidden 1024, qpos hidden 512) are written as
 // splits by the producing GEMM straight into the sF region (same bytes as the fp32 rows they replace).
-template <bool SPLIT>
+template <int SPLIT>
 __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
   // LDS (floats).  Row strides are (cols + 4): ds_read_b128 of 16 rows x 4 k-groups is conflict-free.
   constexpr int LDH = 260, LDF = 1028, LDQ = 516, LDO = 292, LDR = 68;
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (SPLIT) {                                                                                             \
       split_rows(X, LDXS, (LW).K, sXh, sXl, LDX, tid);                                                       \
       __syncthreads();                                                                                       \
-      row_gemm_split<ACT>(sXh, sXl, LDX, LW, Y, LDY, R, LDRS, nullptr, nullptr, 0, wave, lane, rot);         \
+      row_gemm_split<ACT, (SPLIT != 2)>(sXh, sXl, LDX, LW, Y, LDY, R, LDRS, nullptr, nullptr, 0, wave, lane, rot);         \
     } else {                                                                                                 \
       row_gemm<ACT>(X, LDXS, LW, Y, LDY, R, LDRS, wave, lane, rot);                                          \
     }                                                                                                        \
@@ -553,8 +555,8 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (SPLIT) {
       split_rows(sH, LDH, a.fc1.K, sXh, sXl, LDX, tid);
       __syncthreads();
-      if (a.mode == 4) row_gemm_split<ACT_GELU>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
-      else row_gemm_split<ACT_RELU>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
+      if (a.mode == 4) row_gemm_split<ACT_GELU, (SPLIT != 2)>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
+      else row_gemm_split<ACT_RELU, (SPLIT != 2)>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
     } else {
       if (a.mode == 4) row_gemm<ACT_GELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane, rot);
       else row_gemm<ACT_RELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane, rot);
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     DEC_TOUCH(a.bb0);
     __syncthreads();
     DEC_STAMP(6);   // fc1
-    if (SPLIT) row_gemm_split<ACT_NONE>(sFh, sFl, LDFB, a.fc2, sH, LDH, sH, LDH, nullptr, nullptr, 0, wave, lane, rot);
+    if (SPLIT) row_gemm_split<ACT_NONE, (SPLIT != 2)>(sFh, sFl, LDFB, a.fc2, sH, LDH, sH, LDH, nullptr, nullptr, 0, wave, lane, rot);
     else row_gemm<ACT_NONE>(sF, LDF, a.fc2, sH, LDH, sH, LDH, wave, lane, rot);
     DEC_TOUCH(a.bb1);
     __syncthreads();
@@ -638,10 +640,10 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (SPLIT) {
       split_rows(sR, LDR, a.qp0.K, sXh, sXl, LDX, tid);
       __syncthreads();
-      row_gemm_split<ACT_RELU>(sXh, sXl, LDX, a.qp0, nullptr, 0, nullptr, 0, sQh, sQl, LDQB, wave, lane, rot);
+      row_gemm_split<ACT_RELU, (SPLIT != 2)>(sXh, sXl, LDX, a.qp0, nullptr, 0, nullptr, 0, sQh, sQl, LDQB, wave, lane, rot);
       DEC_TOUCH(a.v);
       __syncthreads();
-      row_gemm_split<ACT_NONE>(sQh, sQl, LDQB, a.qp1, sP, LDH, nullptr, 0, nullptr, nullptr, 0, wave, lane, rot);
+      row_gemm_split<ACT_NONE, (SPLIT != 2)>(sQh, sQl, LDQB, a.qp1, sP, LDH, nullptr, 0, nullptr, nullptr, 0, wave, lane, rot);
     } else {
       row_gemm<ACT_RELU>(sR, LDR, a.qp0, sT, LDQ, nullptr, 0, wave, lane, rot);
       DEC_TOUCH(a.v);
@@ -810,8 +812,9 @@ void launch_dec_layer(const DecArgs& a, hipStream_t s) {
   RTD_CHECK(a.D == 256 && a.D / a.heads == 32 && a.ffn <= 1024 && a.C <= 512, 1, "fused decoder: d_model 256, head dim 32, ffn <= 1024");
   RTD_CHECK(a.n_levels == 3 && a.n_points == 4 && a.heads == NW, 1, "fused decoder: 3 levels x 4 points, 8 heads");
   const int tiles = (a.Q + DR - 1) / DR;
-  if (a.split) hipLaunchKernelGGL(dec_layer_kernel<true>, dim3(a.B * tiles), dim3(NT), 0, s, a);
-  else hipLaunchKernelGGL(dec_layer_kernel<false>, dim3(a.B * tiles), dim3(NT), 0, s, a);
+  if (a.split == 2) hipLaunchKernelGGL(dec_layer_kernel<2>, dim3(a.B * tiles), dim3(NT), 0, s, a);
+  else if (a.split) hipLaunchKernelGGL(dec_layer_kernel<1>, dim3(a.B * tiles), dim3(NT), 0, s, a);
+  else hipLaunchKernelGGL(dec_layer_kernel<0>, dim3(a.B * tiles), dim3(NT), 0, s, a);
   HIP_CHECK(hipGetLastError());
 }
 

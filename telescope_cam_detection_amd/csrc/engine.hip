@@ -631,7 +631,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       return Lw;
     };
     DecArgs a0{};
-    a0.split = g_dec_split && P == BF16;
+    a0.split = P == BF16 ? g_dec_split : 0;
     a0.B = n; a0.Q = L; a0.D = d; a0.heads = 8; a0.S = 0; a0.n_levels = 3; a0.n_points = 4; a0.ffn = c.enc_ffn; a0.C = 4;
     a0.hs_in = (const float*)t0.p; a0.qpos_in = e->pos_dev;
     a0.q_in = (const float*)qrows.p; a0.q_out = (float*)qrows.p;
@@ -807,7 +807,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       return P;
     };
     DecArgs base{};
-    base.split = g_dec_split && P == BF16;
+    base.split = P == BF16 ? g_dec_split : 0;
     base.B = n; base.Q = Q; base.D = dm; base.heads = c.dec_heads; base.S = S; base.n_levels = c.n_levels;
     base.n_points = c.n_points; base.ffn = c.dec_ffn; base.C = C; base.offset_scale = c.offset_scale;
     base.ref8 = ref8; base.ref_unact8 = ref_unact8; base.anchors = e->anchors_dev; base.tk_idx = tk;

@@ -67,6 +67,8 @@ CONV_CASES = [
     (1, 70, 50, 256, 64, 1, 1, 0, "relu", 0),      # ragged last pixel tile
     (2, 40, 40, 256, 128, 1, 1, 0, "silu", 1),     # two channel groups per wave, residual through the slab
     (4, 128, 128, 256, 64, 1, 1, 0, "relu", 0),    # 2048 tiles: taken in mode 0 too
+    (2, 40, 41, 256, 1024, 1, 1, 0, "relu", 1),    # stage-2 c3: eight 128-channel blocks in gridDim.y, residual, ragged tile
+    (1, 30, 30, 256, 384, 1, 1, 0, "none", 0),     # three channel blocks
 ]
 
 
