@@ -28,6 +28,7 @@ thread_local std::string g_create_error;
 int g_dec_stamps = 0;  // plan-build switch: record per-phase stamps of decoder layer 2 into debug tensor "dec_stamps"
 int g_dec_split = 1;   // plan-build switch (rtd_debug_option "dec_split"): bf16 engine runs the fused decoder / AIFI linears as bf16 hi/lo splits
 int g_sc_fold = 1;     // plan-build switch (rtd_debug_option "sc_fold"): bf16 plans fold a block's projection shortcut into its last conv (ConvArgs::x2)
+int g_arena_reuse = 1; // plan-build switch (rtd_debug_option "arena_reuse"): backbone stages recycle their activation buffers
 int g_stem_fused = 0;  // plan-build switch (rtd_debug_option "stem_fused"): bf16 engine runs backbone.stem.0 straight from the uint8 frames.
                        // Measured neutral (same-box A/B: +0.2 % / 0 %: the kernel is latency-bound at 44 us against 56 + 20 us of
                        // preprocess + generic stem) -> off by default, kept tested
@@ -534,6 +535,26 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   int cin = c.embedding_size;
   for (int si = 0; si < 4; ++si) {
     const int cout = c.hidden_sizes[si];
+    // Buffers are recycled inside a stage (rtd_debug_option "arena_reuse"): the blocks' outputs ping-pong between two buffers
+    // (a block's input is dead once its last conv has read it as the residual) and the c1 / c2 temporaries of every block
+    // share one buffer each.  Fewer distinct lines means more of a stage lives in L2 + the 256 MB Infinity Cache, and dead
+    // activations are overwritten in cache instead of being written back to HBM.
+    Tensor pp[2], tb1, tb2;
+    if (g_arena_reuse) {
+      const int s0 = (si > 0) ? 2 : 1;
+      const int oh0 = s0 == 2 ? down2(h) : h, ow0 = s0 == 2 ? down2(w) : w;
+      pp[0] = B.act(P, n, oh0, ow0, cout);
+      if (c.depths[si] > 1) pp[1] = B.act(P, n, oh0, ow0, cout);
+      const int mid0 = c.layer_type == RTD_LAYER_BOTTLENECK ? cout / 4 : cout;
+      tb1 = B.act(P, n, c.layer_type == RTD_LAYER_BOTTLENECK ? h : oh0, c.layer_type == RTD_LAYER_BOTTLENECK ? w : ow0, mid0);   // block 0's c1 runs before the stride
+      tb2 = B.act(P, n, oh0, ow0, mid0);
+    }
+    auto view = [&](const Tensor& buf, int hh_, int ww_, int cc_, const std::string& name) {
+      Tensor t = buf;
+      t.h = hh_; t.w = ww_; t.c = cc_; t.ld = cc_; t.bstride = (int64_t)hh_ * ww_ * cc_;
+      if (!name.empty()) B.plan->named[name] = t;
+      return t;
+    };
     for (int bi = 0; bi < c.depths[si]; ++bi) {
       const int stride = (si > 0 && bi == 0) ? 2 : 1;
       const std::string pfx = nm("backbone.s%d.b%d", si, bi);
@@ -576,16 +597,16 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
           B.conv(pfx + ".sc", sc_in, res, 1, 1, 0, ACT_NONE);
         }
       }
-      Tensor out = B.act(P, n, oh, ow, cout, oname);
+      Tensor out = g_arena_reuse ? view(pp[bi & 1], oh, ow, cout, oname) : B.act(P, n, oh, ow, cout, oname);
       if (c.layer_type == RTD_LAYER_BOTTLENECK) {
-        Tensor t1 = B.act(P, n, h, w, mid);
+        Tensor t1 = g_arena_reuse ? view(tb1, h, w, mid, "") : B.act(P, n, h, w, mid);
         B.conv(pfx + ".c1", cur, t1, 1, 1, 0, ACT_RELU);
-        Tensor t2 = B.act(P, n, oh, ow, mid);
+        Tensor t2 = g_arena_reuse ? view(tb2, oh, ow, mid, "") : B.act(P, n, oh, ow, mid);
         B.conv(pfx + ".c2", t1, t2, 3, stride, 1, ACT_RELU);
         if (fold_sc) B.conv(pfx + ".c3", t2, out, 1, 1, 0, ACT_RELU, nullptr, RES_NONE, 0, &sc_in, pfx + ".sc");
         else B.conv(pfx + ".c3", t2, out, 1, 1, 0, ACT_RELU, &res, RES_PRE);
       } else {
-        Tensor t1 = B.act(P, n, oh, ow, cout);
+        Tensor t1 = g_arena_reuse ? view(tb1, oh, ow, cout, "") : B.act(P, n, oh, ow, cout);
         B.conv(pfx + ".c1", cur, t1, 3, stride, 1, ACT_RELU);
         if (fold_sc) B.conv(pfx + ".c2", t1, out, 3, 1, 1, ACT_RELU, nullptr, RES_NONE, 0, &sc_in, pfx + ".sc");
         else B.conv(pfx + ".c2", t1, out, 3, 1, 1, ACT_RELU, &res, RES_PRE);
@@ -1444,6 +1465,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "sel_fused") == 0) { g_sel_fused = value; return RTD_OK; }
   if (strcmp(name, "stem_fused") == 0) { g_stem_fused = value; return RTD_OK; }
   if (strcmp(name, "sc_fold") == 0) { g_sc_fold = value; return RTD_OK; }
+  if (strcmp(name, "arena_reuse") == 0) { g_arena_reuse = value; return RTD_OK; }
   if (strcmp(name, "dec_split") == 0) { g_dec_split = value; return RTD_OK; }
   if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
   if (strcmp(name, "prefetch") == 0) { conv_set_prefetch(value); return RTD_OK; }
