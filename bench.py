@@ -167,7 +167,7 @@ def main():
     if single is not None:
         out["single_stream"] = {"value": round(world * B * args.steps / single, 2), "unit": "frames/s",
                                 "ms_per_step": round(1000.0 * single / args.steps, 4),
-                                "note": "same K steps on ONE handle (one batch in flight); ms_per_step here is the latency of a bs-8 step"}
+                                "note": "same K steps on ONE latency-profile handle (one batch in flight); ms_per_step here is the latency of one bs-" + str(B) + " step"}
     if args.arch in CANON_GFLOP_PER_FRAME and H == 640:
         out["mfma_frac_whole_model"] = round(CANON_GFLOP_PER_FRAME[args.arch] * fps / world / (MFMA_PEAK_TFLOPS[args.precision] * 1e3), 4)
 
@@ -205,6 +205,12 @@ def main():
                 out["roofline"]["traffic"] = round(tb / nl / 1e6, 2)
                 out["roofline"]["traffic_unit"] = "MB HBM per launch (PMC, profiles/r01_pmc_hbm_traffic.json)"
                 out["roofline"]["alg_mbytes_per_launch_unfused"] = round(d["bytes"] / d["launches"] / 1e6, 2)
+                # cross-check: the committed rocprofv3 --kernel-trace of `--streams 1` (hipGraph replay).  Its durations are
+                # kernel execution only; the HIP-event pairs above also contain the ~3-4 us between two dependent launches.
+                with open(os.path.join(ROOT, "profiles", "r01_rocprofv3_kernel_summary.json")) as fh:
+                    rp = json.load(fh)
+                out["roofline"]["avg_launch_us_rocprofv3"] = rp["conv_igemm_all"]["avg_us"]
+                out["roofline"]["achieved_rocprofv3"] = round(d["flops"] / (rp["conv_igemm_all"]["us_per_step"] * 1e-6) / 1e12, 2)
         except (OSError, KeyError, ValueError):
             pass
         out["kernel_families_ms"] = {k: round(v["ms"], 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
