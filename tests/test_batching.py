@@ -112,6 +112,27 @@ def test_make_coordinator_follows_reference_config_keys():
     assert isinstance(c, BatchCoordinator) and c.max_batch_size == 6 and abs(c.max_batch_wait_ms - 0.005) < 1e-9
     assert built["config_path"] == "x_r50vd.yml" and built["model_path"] == "w.pth" and built["max_batch"] == 6
     assert built["input_size"] == (640, 640) and built["conf_threshold"] == 0.3 and built["wildlife_only"] is False
+    assert "profile" not in built                                       # one batch in flight: the reference's own constructor arguments only
+
+    # pipeline_depth > 1: every detector of the pipeline is built with the throughput kernel profile
+    profiles = []
+
+    class PipeDet(Det):
+        def __init__(self, **kw):
+            profiles.append(kw.get("profile"))
+            self.config_path, self.model_path, self.device = kw["config_path"], kw["model_path"], kw["device"]
+            self.conf_threshold, self.input_size, self.wildlife_only = kw["conf_threshold"], kw["input_size"], kw["wildlife_only"]
+
+        def detect_batch_async(self, frames):
+            return frames
+
+        def detect_batch_collect(self, ticket):
+            return [[] for _ in ticket]
+
+    cfg["detection"]["batching"]["pipeline_depth"] = 3
+    c3 = make_rtdetr_coordinator(cfg, detector_cls=PipeDet)
+    assert isinstance(c3, BatchCoordinator) and len(c3.detectors) == 3 and profiles == ["throughput"] * 3
+    del cfg["detection"]["batching"]["pipeline_depth"]
     cfg["detection"]["batching"]["enabled"] = False
     assert make_rtdetr_coordinator(cfg, detector_cls=Det) is None
     cfg["detection"]["batching"]["enabled"] = True

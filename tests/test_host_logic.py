@@ -85,6 +85,9 @@ def test_library_loads_and_exports_every_declared_symbol():
     cfg = _capi.make_config(ARCHS["r18"], 0, _capi.PREC_BF16, 8, (640, 640), True)
     cfg.struct_size = 12
     assert lib.rtd_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.RTD_E_INVALID
+    cfg = _capi.make_config(ARCHS["r18"], 0, _capi.PREC_BF16, 8, (640, 640), True, profile=7)   # RTD_PROFILE_* is 0 or 1
+    assert lib.rtd_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.RTD_E_INVALID
+    assert _capi.make_config(ARCHS["r18"], 0, _capi.PREC_BF16, 8, (640, 640), True).profile == _capi.PROFILE_LATENCY
     assert lib.rtd_debug_option(b"no_such_option", 1) == _capi.RTD_E_INVALID
 
 
