@@ -1690,8 +1690,12 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
 //   * bias + activation in registers, bf16 rows through a wave-private LDS slab, 16-byte stores along NHWC's channels.
 // Cin = 64 filters do not fit one wave's registers for 64 output channels: gridDim.y splits the channels into 32-wide groups.
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int TN, int GROUPS>
-__global__ __launch_bounds__(256 * GROUPS, 2) void conv3x3_reg_kernel(const ConvK a, unsigned x_bytes, unsigned y_bytes, int tiles_x, int tiles_y, int ntiles) {
+// RES: a bf16 residual (basic-block nets: the block's second 3x3 conv) is added before / after the activation.  Its rows are
+// requested row-shaped (16 bytes per lane, like the stores) before the MFMAs of the row, cross the wave's store slab and are read
+// back in accumulator shape: the add happens in fp32 registers, one rounding.  Always issued (out-of-range offset = zeros), so the
+// tile loop's counted wait stays exact.
+template <int CIN, int TN, int GROUPS, bool RES = false>
+__global__ __launch_bounds__(256 * GROUPS, 2) void conv3x3_reg_kernel(const ConvK a, unsigned x_bytes, unsigned y_bytes, int tiles_x, int tiles_y, int ntiles, unsigned r_bytes = 0) {
   // GROUPS = 32 TN-channel groups handled inside the block by different wave quartets (Cin = 64: the 64 output channels need
   // two register-resident filters; both quartets read the same staged patch)
   constexpr int NW = 4 * GROUPS, NT_ = 64 * NW;
@@ -1737,6 +1741,7 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv3x3_reg_kernel(const Conv
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res : a.x), 0, RES ? r_bytes : 0u, 0x00020000);
   auto swz = [](int pi) { return CPP == 8 ? ((pi >> 1) & 7) : ((pi >> 2) & 3); };
   auto issue_patch = [&](int tile, int buf) {
     const int tx = tile % tiles_x;
@@ -1763,8 +1768,9 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv3x3_reg_kernel(const Conv
     // stay in flight (every row issues exactly 2 TN buffer stores - rows / pixels outside the image store to an out-of-range
     // offset, which the hardware drops - so the count is exact); waiting for their acknowledgement cost ~3 us per tile
     if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (TN == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (TN * (RES ? 2 : 1) == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // RES: 2 TN residual loads + 2 TN stores per row
+    else if (TN * (RES ? 2 : 1) == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __syncthreads();                                               // ... everybody's; the other buffer's readers are done
     if (tile + (int)gridDim.x < ntiles) issue_patch(tile + gridDim.x, buf ^ 1);
     const int tx = tile % tiles_x;
@@ -1775,8 +1781,20 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv3x3_reg_kernel(const Conv
     const char* pbuf = patch + buf * PBUF;
 
 #pragma unroll 1
-    for (int rr = 0; rr < 2; ++rr) {
-      const int r = wq * 2 + rr;
+    for (int rr_ = 0; rr_ < 2; ++rr_) {
+      const int r = wq * 2 + rr_;
+      u32x4_ resv[2 * TN];
+      if (RES) {
+        const int oy_ = y0 + r;
+        const long long rrow = (long long)b * a.r_bstride + ((long long)oy_ * a.W + x0) * a.ldr + nbase;
+#pragma unroll
+        for (int i2 = 0; i2 < 2 * TN; ++i2) {
+          const int idx = i2 * 64 + lane;
+          const int p = idx / (4 * TN), ch = idx - p * (4 * TN);
+          const bool ok = oy_ < a.H && x0 + p < a.W;
+          resv[i2] = __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? (unsigned)((rrow + (long long)p * a.ldr + ch * 8) * 2) : 0x80000000u, 0, 0);
+        }
+      }
       f32x16 acc[TN];
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
@@ -1807,6 +1825,15 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv3x3_reg_kernel(const Conv
       // ---- epilogue of this 32-pixel row: lane = pixel (lane & 31), channels 32 tn + 8 q + 4 h + (0..3) ----
       const int oy = y0 + r;
       char* sw_ = stage[wv];
+      if (RES) {                                                    // residual rows -> slab (row shape); read back per accumulator below
+#pragma unroll
+        for (int i2 = 0; i2 < 2 * TN; ++i2) {
+          const int idx = i2 * 64 + lane;
+          const int p = idx / (4 * TN), ch = idx - p * (4 * TN);
+          *(u32x4_*)(sw_ + p * ROWO + ch * 16) = resv[i2];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
       dispatch_act(a.act, [&](auto actc) {
         constexpr int ACT = decltype(actc)::value;
 #pragma unroll
@@ -1815,9 +1842,17 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv3x3_reg_kernel(const Conv
           for (int q = 0; q < 4; ++q) {
             const f32x4 bv = *(const f32x4*)(a.bias + nbase + 32 * tn + 8 * q + 4 * h);   // L1-resident; registers are for the filter
             bf16x4 o;
+            bf16x4 rv4;
+            if (RES) rv4 = *(const bf16x4*)(sw_ + (lane & 31) * ROWO + (32 * tn + 8 * q + 4 * h) * 2);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (bf16)act_c<ACT>(acc[tn][4 * q + e] + bv[e]);
-            *(bf16x4*)(sw_ + (lane & 31) * ROWO + (32 * tn + 8 * q + 4 * h) * 2) = o;
+            for (int e = 0; e < 4; ++e) {
+              float v = acc[tn][4 * q + e] + bv[e];
+              if (RES && a.res_mode == RES_PRE) v += (float)rv4[e];
+              v = act_c<ACT>(v);
+              if (RES && a.res_mode == RES_POST) v += (float)rv4[e];
+              o[e] = (bf16)v;
+            }
+            *(bf16x4*)(sw_ + (lane & 31) * ROWO + (32 * tn + 8 * q + 4 * h) * 2) = o;      // same 8 bytes this lane just read
           }
       });
       __builtin_amdgcn_wave_barrier();
@@ -1845,7 +1880,14 @@ static bool dispatch_reg(const ConvK& k, const ConvArgs& a, long long x_bytes, h
   if (!g_conv_reg || g_force_v1 || g_conv_mode != 0) return false;
   const Tensor& x = a.x;
   const Tensor& y = a.y;
-  if (x.dt != BF16 || y.dt != BF16 || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.res_mode != RES_NONE) return false;
+  if (x.dt != BF16 || y.dt != BF16 || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1) return false;
+  const bool with_res = a.res_mode != RES_NONE;
+  long long r_bytes = 0;
+  if (with_res) {                                               // basic-block nets: 64 -> 64 with a bf16 residual
+    if (!(x.c == 64 && y.c == 64) || a.res.dt != BF16 || a.res.ld % 8 || ((uintptr_t)a.res.p & 15)) return false;
+    r_bytes = ((long long)(a.res.n - 1) * a.res.bstride + ((long long)a.res.h * a.res.w - 1) * a.res.ld + a.res.c) * 2;
+    if (r_bytes >= (1ll << 31)) return false;
+  }
   if (!((x.c == 32 && (y.c == 32 || y.c == 64)) || (x.c == 64 && y.c == 64)) || x.ld % 8 || y.ld % 8 || ((uintptr_t)y.p & 15) || x_bytes >= (1ll << 31)) return false;
   const long long y_bytes = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * 2;
   if (y_bytes >= (1ll << 31)) return false;
@@ -1854,9 +1896,10 @@ static bool dispatch_reg(const ConvK& k, const ConvArgs& a, long long x_bytes, h
   if (ntiles < 256 || ntiles >= (1ll << 30)) return false;        // small maps: the implicit-GEMM tiles fill the chip better
   // persistent blocks, two per CU (LDS: 2 patch buffers + the store slabs)
   const unsigned gx = (unsigned)std::min<long long>(ntiles, x.c == 64 ? 256 : 512);
-  if (x.c == 32 && y.c == 32) hipLaunchKernelGGL((conv3x3_reg_kernel<32, 1, 1>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles);
-  else if (x.c == 32) hipLaunchKernelGGL((conv3x3_reg_kernel<32, 2, 1>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles);
-  else if (y.c == 64) hipLaunchKernelGGL((conv3x3_reg_kernel<64, 1, 2>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles);
+  if (x.c == 32 && y.c == 32) hipLaunchKernelGGL((conv3x3_reg_kernel<32, 1, 1>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, 0u);
+  else if (x.c == 32) hipLaunchKernelGGL((conv3x3_reg_kernel<32, 2, 1>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, 0u);
+  else if (y.c == 64 && with_res) hipLaunchKernelGGL((conv3x3_reg_kernel<64, 1, 2, true>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, (unsigned)r_bytes);
+  else if (y.c == 64) hipLaunchKernelGGL((conv3x3_reg_kernel<64, 1, 2>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, 0u);
   else return false;
   return true;
 }

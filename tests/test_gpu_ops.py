@@ -54,6 +54,8 @@ CONV_CASES = [
     (4, 60, 264, 32, 64, 3, 1, 1, "silu", 0),      # stem.2
     (4, 68, 232, 64, 64, 3, 1, 1, "relu", 0),      # stage-0 c2 (two 32-channel groups)
     (2, 160, 160, 64, 64, 3, 1, 1, "none", 0),     # exact tiles
+    (3, 100, 75, 64, 64, 3, 1, 1, "relu", 1),      # basic-block c2: pre-activation residual through the store slab, ragged tiles
+    (2, 96, 128, 64, 64, 3, 1, 1, "silu", 2),      # post-activation residual
     # short K, many channel tiles, no residual: the A-stationary kernel (auto in mode 0 from 4 channel tiles on)
     (2, 64, 66, 128, 640, 1, 1, 0, "silu", 0),     # K = 128 (2 chunks), 5 channel tiles, ragged M
     (1, 8400, 1, 256, 1536, 1, 1, 0, "none", 0),   # one image of the value projection
