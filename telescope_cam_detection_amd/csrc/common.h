@@ -116,6 +116,7 @@ void launch_layernorm(const Tensor& x, const Tensor* res, const float* g, const 
 // y = a + b (b broadcast over batch when b.n == 1)
 void launch_add(const Tensor& a, const Tensor& b, const Tensor& y, hipStream_t s);
 void launch_maxpool3x3s2(const Tensor& x, const Tensor& y, hipStream_t s);
+void maxpool_set_v1(int v);
 void launch_upsample2x(const Tensor& x, const Tensor& y, hipStream_t s);
 void launch_avgpool2(const Tensor& x, const Tensor& y, hipStream_t s);
 // qk: [B,L,2*D] (q | k), v: [B,L,D] -> o [B,L,D]; softmax(q k^T / sqrt(hd)) v per head

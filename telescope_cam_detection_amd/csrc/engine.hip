@@ -1465,6 +1465,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "sel_fused") == 0) { g_sel_fused = value; return RTD_OK; }
   if (strcmp(name, "stem_fused") == 0) { g_stem_fused = value; return RTD_OK; }
   if (strcmp(name, "sc_fold") == 0) { g_sc_fold = value; return RTD_OK; }
+  if (strcmp(name, "maxpool_v1") == 0) { maxpool_set_v1(value); return RTD_OK; }
   if (strcmp(name, "arena_reuse") == 0) { g_arena_reuse = value; return RTD_OK; }
   if (strcmp(name, "dec_split") == 0) { g_dec_split = value; return RTD_OK; }
   if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }

@@ -173,10 +173,70 @@ __global__ void k_maxpool(const T* __restrict__ x, T* __restrict__ y, int B, int
 #pragma unroll
   for (int k = 0; k < 4; ++k) o[k] = (T)m[k];
 }
+// bf16, C % 8 == 0, even output extents: a thread owns 8 channels of a 2 x 2 output patch and reads its 5 x 5 input window
+// once (25 x 16 bytes for 4 outputs instead of 36 x 8; the taps a patch shares between its outputs never leave registers,
+// and the lanes of 8 consecutive threads cover one pixel's 128-byte line)
+__global__ __launch_bounds__(256) void k_maxpool_bf16_2x2(const bf16* __restrict__ x, bf16* __restrict__ y, int B, int H, int W, int C, int64_t ldx,
+                                                          int OH, int OW, int64_t ldy) {
+  typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c8 = C / 8, PW = OW / 2, PH = OH / 2;
+  const int64_t total = (int64_t)B * PH * PW * c8;
+  if (i >= total) return;
+  const int cc = (int)(i % c8) * 8;
+  int64_t p = i / c8;
+  const int px = (int)(p % PW); p /= PW;
+  const int py = (int)(p % PH);
+  const int b = (int)(p / PH);
+  const int iy0 = 4 * py - 1, ix0 = 4 * px - 1;                  // window rows iy0 .. iy0+4, cols ix0 .. ix0+4
+  float m[4][8];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[o][k] = -INFINITY;
+#pragma unroll
+  for (int dy = 0; dy < 5; ++dy) {
+    const int iy = iy0 + dy;
+    if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) {
+      const int ix = ix0 + dx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const v8 v = *(const v8*)(x + (((int64_t)b * H + iy) * W + ix) * ldx + cc);
+#pragma unroll
+      for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox)
+          if (dy >= 2 * oy && dy <= 2 * oy + 2 && dx >= 2 * ox && dx <= 2 * ox + 2) {     // compile-time after unrolling
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m[oy * 2 + ox][k] = fmaxf(m[oy * 2 + ox][k], (float)v[k]);
+          }
+    }
+  }
+#pragma unroll
+  for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+    for (int ox = 0; ox < 2; ++ox) {
+      v8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (bf16)m[oy * 2 + ox][k];
+      *(v8*)(y + (((int64_t)b * OH + 2 * py + oy) * OW + 2 * px + ox) * ldy + cc) = o;
+    }
+}
+
+static int g_maxpool_v1 = 0;   // A/B + test hook (rtd_debug_option "maxpool_v1"): 1 = the one-output-per-thread kernel for every dtype
+void maxpool_set_v1(int v) { g_maxpool_v1 = v; }
 void launch_maxpool3x3s2(const Tensor& x, const Tensor& y, hipStream_t s) {
   RTD_CHECK(x.dt == y.dt && x.c == y.c && x.c % 4 == 0 && x.n == y.n, 1, "maxpool: dtype/channels");
   RTD_CHECK(y.h == (x.h + 2 - 3) / 2 + 1 && y.w == (x.w + 2 - 3) / 2 + 1, 1, "maxpool: shape");
   RTD_CHECK(x.bstride == (int64_t)x.h * x.w * x.ld && y.bstride == (int64_t)y.h * y.w * y.ld, 1, "maxpool: dense images");
+  if (!g_maxpool_v1 && x.dt == BF16 && x.c % 8 == 0 && x.ld % 8 == 0 && y.ld % 8 == 0 && y.h % 2 == 0 && y.w % 2 == 0 && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0) {
+    const int64_t total2 = (int64_t)y.n * (y.h / 2) * (y.w / 2) * (y.c / 8);
+    hipLaunchKernelGGL(k_maxpool_bf16_2x2, dim3(blocks_for(total2, 256)), dim3(256), 0, s, (const bf16*)x.p, (bf16*)y.p, x.n, x.h, x.w, x.c,
+                       x.ld, y.h, y.w, y.ld);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   const int64_t total = (int64_t)y.n * y.h * y.w * (y.c / 4);
   DISPATCH_T(x.dt, hipLaunchKernelGGL(k_maxpool<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const T*)x.p, (T*)y.p,
                                       x.n, x.h, x.w, x.c, x.ld, y.h, y.w, y.ld));

@@ -128,6 +128,23 @@ def test_full_size_properties_bf16_bs8():
     eng.close()
 
 
+def test_patch_maxpool_equals_per_output_maxpool():
+    """the bf16 2x2-patch max-pool kernel against the one-output-per-thread kernel: max is exact, the stem must match bitwise"""
+    from telescope_cam_detection_amd import _capi
+    arch, wseed, input_size, frames, g = load_case("c1_r18_640_scene")
+    w = weights_for(arch, wseed)
+    outs = []
+    for v1 in (1, 0):
+        _capi.debug_option("maxpool_v1", v1)
+        e = make_engine(arch, w, frames, input_size, "bf16")
+        e.infer_raw(frames)
+        outs.append(e.debug_tensor("stem").copy())
+        e.close()
+    _capi.debug_option("maxpool_v1", 0)
+    assert outs[0].shape == outs[1].shape and np.isfinite(outs[0]).all()
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
 def test_throughput_profile_equals_latency_profile():
     """rtd_config.profile only changes which conv tile runs a layer (256- instead of 128-pixel tiles from 100 blocks on): the
     K order of every output is the same, so the detections must agree to the last bit of the accumulation."""

@@ -23,6 +23,8 @@ SHAPES = [
     ("s3.c1 1x1 2048->512 @20", 20, 2048, 512, 1, 1, 0, 0),
     ("s3.c2 3x3 512->512 @20", 20, 512, 512, 3, 1, 1, 0),
     ("s3.c3 1x1 512->2048 @20 +res", 20, 512, 2048, 1, 1, 0, 1),
+    ("fpn1.c12 1x1 512->512 @80", 80, 512, 512, 1, 1, 0, 0),
+    ("proj.0 1x1 512->256 @80", 80, 512, 256, 1, 1, 0, 0),
     ("fpn1.rep 3x3 256->256 @80", 80, 256, 256, 3, 1, 1, 0),
     ("pan1.rep 3x3 256->256 @20", 20, 256, 256, 3, 1, 1, 0),
     ("lat 1x1 256->256 @20", 20, 256, 256, 1, 1, 0, 0),

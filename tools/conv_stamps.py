@@ -15,6 +15,7 @@ from telescope_cam_detection_amd import _capi
 SHAPES = {  # HW, Cin, Cout, k, stride, pad, residual
     "s0c3": (160, 64, 256, 1, 1, 0, 1), "s1c3": (80, 128, 512, 1, 1, 0, 1), "s0sc": (160, 64, 256, 1, 1, 0, 0),
     "fpn1": (80, 256, 256, 3, 1, 1, 0), "s1c1": (80, 512, 128, 1, 1, 0, 0), "s1c2": (80, 128, 128, 3, 1, 1, 0),
+    "c12": (80, 512, 512, 1, 1, 0, 0), "proj0": (80, 512, 256, 1, 1, 0, 0), "s2c2": (40, 256, 256, 3, 1, 1, 0),
     "lat": (20, 256, 256, 1, 1, 0, 0), "s3c2": (20, 512, 512, 3, 1, 1, 0), "vpall": (-8400, 256, 1536, 1, 1, 0, 0),
 }
 
