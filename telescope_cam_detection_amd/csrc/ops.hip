@@ -982,19 +982,33 @@ __global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __r
       patch[r * ROWE + el] = (bf16)(v / 255.0f);
     }
   }
-  // filter fragments: lane = output channel (lane & 31), k = 16 s + 8 (lane >> 5) + j with k = tap * 3 + c  (27 real, 5 zero)
+  for (int e = tid; e < PR * (ROWE - PC * 3); e += 256) {                               // row tails: read (times a zero filter tap) by the last pixels
+    const int r = e / (ROWE - PC * 3), i = e - r * (ROWE - PC * 3);
+    patch[r * ROWE + PC * 3 + i] = (bf16)0.f;
+  }
+  // K layout chosen for the GATHER, not for the filter: k = 10 kh + e, e = 3 kw + (BGR byte) for e < 9, e = 9 and k = 30, 31 carry
+  // zero filter taps.  A filter row of the patch is then 10 consecutive elements starting at an even offset, so the 8 k values of
+  // a lane (k = 16 s + 8 (lane >> 5) + j) are at most two runs of whole dwords: 4 ds_read_b32 per MFMA operand instead of 8
+  // ds_read_u16 (measured: no change, 44.8 us either way - the launch is bound by the per-block patch staging, not the gather).
+  // Pixel p starts at element 6 p: consecutive lanes are 3 banks apart.
   bf16x8_s wf[2];
-  int off[2][8];                      // element offset of tap k inside the patch relative to the pixel's (2 r, 2 p) corner
+  int doff[2][4];                     // dword j of the operand: element offset relative to the pixel's (2 r, 2 p) corner
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < 2; ++s) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = 16 * s + 8 * h + j;
-      const int tap = k / 3, c = k - tap * 3;
-      const int kh = tap / 3, kw = tap - kh * 3;
-      wf[s][j] = k < 27 ? wq[(size_t)(lane & 31) * Kpad + tap * 8 + c] : (bf16)0.f;    // zero filter taps: the pixel operand may be anything finite
-      off[s][j] = k < 27 ? kh * ROWE + kw * 3 + (2 - c) : 0;                            // model channel c (RGB) = frame byte 2 - c (BGR)
+      const int kh = k / 10, e = k - kh * 10;
+      const int kw = e / 3, cb = e - kw * 3;                                            // frame byte cb (BGR) = model channel 2 - cb (RGB)
+      wf[s][j] = (k < 30 && e < 9) ? wq[(size_t)(lane & 31) * Kpad + (kh * 3 + kw) * 8 + (2 - cb)] : (bf16)0.f;   // zero taps: the pixel operand may be anything finite
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 16 * s + 8 * h + 2 * j;
+      const int kh = k / 10, e = k - kh * 10;
+      doff[s][j] = k < 30 ? kh * ROWE + e : 0;                                          // e even: a whole dword of the row
+    }
+  }
   __syncthreads();
 #pragma unroll 1
   for (int rr = 0; rr < 2; ++rr) {
@@ -1005,10 +1019,12 @@ __global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __r
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8_s xf;
+      unsigned xd[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xf[j] = base[off[s][j]];
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], xf, acc, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) xd[j] = *(const unsigned*)(base + doff[s][j]);
+      typedef unsigned u4_s __attribute__((ext_vector_type(4)));
+      const u4_s xv = {xd[0], xd[1], xd[2], xd[3]};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], __builtin_bit_cast(bf16x8_s, xv), acc, 0, 0, 0);
     }
     const int oy = y0 + r;
     char* sw_ = stage[wv];
