@@ -151,10 +151,11 @@ int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* b
                 void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                 int act, int res_mode, int out_f32);
 /* conv with a second input x2 [B,OH,OW,C2] read as an extra 1x1 tap at output resolution; w_f32 = [Cout][KH*KH*Cin + C2]
- * (how the plan folds a bottleneck's projection shortcut into its last conv) */
+ * (how the plan folds a bottleneck's projection shortcut into its last conv).  x_up2 = 1 (1x1 only): x is [B,H/2,W/2,Cin] and is
+ * read through a nearest 2x upsampling, H and W being the output extents (the FPN's conv over cat([upsample(lat), proj])). */
 int rtd_op_conv_dual(int dtype, const void* x, const void* x2, const void* w_f32, const float* bias, const void* res,
                      void* y, int B, int H, int W, int Cin, int C2, int Cout, int KH, int stride, int pad,
-                     int act, int res_mode, int out_f32);
+                     int act, int res_mode, int out_f32, int x_up2);
 int rtd_op_layernorm(int dtype, const void* x, const void* res, const float* g, const float* b,
                      void* y, int rows, int dim, int out_f32);
 int rtd_op_attention(int dtype, const void* qk, const void* v, void* o, int B, int L, int heads, int hd);

@@ -98,7 +98,7 @@ def lib() -> C.CDLL:
     L.rtd_arena_bytes.restype = i64
     L.rtd_debug_option.argtypes = [C.c_char_p, i32]
     L.rtd_op_conv.argtypes = [i32, vp, vp, vp, vp, vp] + [i32] * 12
-    L.rtd_op_conv_dual.argtypes = [i32, vp, vp, vp, vp, vp, vp] + [i32] * 12
+    L.rtd_op_conv_dual.argtypes = [i32, vp, vp, vp, vp, vp, vp] + [i32] * 13
     L.rtd_op_layernorm.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32]
     L.rtd_op_attention.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32]
     L.rtd_op_msdeform.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(i32), i32, f32]

@@ -78,6 +78,9 @@ struct ConvArgs {
   // y = act(W3 * t + Wsc * x_in + (b3 + bsc)) without writing / re-reading the shortcut tensor.  KH*KW*Cin must be a multiple of
   // one K-step (64 bf16 / 32 fp32); see conv_dual_supported().
   Tensor x2;
+  // x is read through a nearest-neighbour 2x upsampling: x is [B,OH/2,OW/2,Cin], output pixel (oy,ox) reads x(oy/2, ox/2).  1x1 /
+  // stride 1 / pad 0 with a second input only (the FPN's `cat([upsample(lat), proj])` -> 1x1 conv without the upsampled tensor).
+  int x_up2 = 0;
   int prefer256 = 0;   // throughput profile (rtd_config.profile): take the 256-pixel tile from 100 blocks on
   Tensor y;            // output [B,OH,OW,N] (view)
   int KH = 1, KW = 1, stride = 1, pad = 0;

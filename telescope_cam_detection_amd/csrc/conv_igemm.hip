@@ -46,6 +46,7 @@ struct ConvK {
   long long ldx2, x2_bstride;
   int k2_start;
   int prefer256;         // ConvArgs::prefer256
+  int x_up2;             // ConvArgs::x_up2 (ws kernel loader only)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -914,6 +915,8 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
         a_iy0[i] = oy * a.stride - a.pad;
         a_ix0[i] = ox * a.stride - a.pad;
         a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)a_iy0[i] * a.W + a_ix0[i]) * a.ldx) * ES) + chunk * 16;
+        if (a.x_up2)   // 1x1 over a nearest-upsampled x: the source pixel of (oy, ox) is (oy / 2, ox / 2) of the half-size tensor
+          a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)(oy >> 1) * (a.W >> 1) + (ox >> 1)) * a.ldx) * ES) + chunk * 16;
       } else {
         a_iy0[i] = -(1 << 28);
         a_ix0[i] = -(1 << 28);
@@ -2212,7 +2215,7 @@ static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes
   const Tensor& x = a.x;
   const Tensor& y = a.y;
   const bool dual = a.x2.p != nullptr;
-  if (x.dt != BF16 || y.dt != BF16 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0) return false;
+  if (a.x_up2 || x.dt != BF16 || y.dt != BF16 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0) return false;
   if (a.res_mode != RES_NONE && a.res.dt != BF16) return false;
   if (dual && !(x.c == 64 && a.x2.c == 64)) return false;
   if (!dual && x.c == 256 && a.Kpad == 256 && (y.c == 64 || y.c % 128 == 0) && y.c <= 2048 && g_stream2) {
@@ -2333,7 +2336,9 @@ bool conv_dual_supported(const ConvArgs& a) {
   const Tensor& y = a.y;
   const Tensor& x2 = a.x2;
   if (!x2.p || x2.dt != x.dt) return false;
-  const int OH = (x.h + 2 * a.pad - a.KH) / a.stride + 1, OW = (x.w + 2 * a.pad - a.KW) / a.stride + 1;
+  const int up = a.x_up2 ? 2 : 1;
+  if (a.x_up2 && !(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0)) return false;
+  const int OH = (x.h * up + 2 * a.pad - a.KH) / a.stride + 1, OW = (x.w * up + 2 * a.pad - a.KW) / a.stride + 1;
   if (x2.n != x.n || x2.h != OH || x2.w != OW) return false;
   const int es = (int)dtype_size(x.dt), bk = 128 / es, epc = 16 / es;
   if ((a.KH * a.KW * x.c) % bk || x2.c % bk || x.c % bk || x2.ld % epc || ((uintptr_t)x2.p & 15)) return false;
@@ -2354,8 +2359,10 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
   RTD_CHECK(x.dt == BF16 || x.dt == F32, 1, "conv: input dtype");
   RTD_CHECK(y.dt == BF16 || y.dt == F32, 1, "conv: output dtype");
   const int epc = x.dt == BF16 ? 8 : 4;
-  const int OH = (x.h + 2 * a.pad - a.KH) / a.stride + 1;
-  const int OW = (x.w + 2 * a.pad - a.KW) / a.stride + 1;
+  const int up = a.x_up2 ? 2 : 1;
+  if (a.x_up2) RTD_CHECK(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.x2.p, 1, "conv: x_up2 needs a 1x1 conv with a second input");
+  const int OH = (x.h * up + 2 * a.pad - a.KH) / a.stride + 1;
+  const int OW = (x.w * up + 2 * a.pad - a.KW) / a.stride + 1;
   RTD_CHECK(OH == y.h && OW == y.w && x.n == y.n, 1, "conv: output shape mismatch");
   RTD_CHECK(x.c % epc == 0 && x.ld % epc == 0, 1, "conv: Cin / pixel stride must be a multiple of one 16-byte chunk");
   RTD_CHECK(((uintptr_t)x.p & 15) == 0 && ((uintptr_t)a.w & 15) == 0, 1, "conv: 16-byte alignment");
@@ -2369,7 +2376,8 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
   ConvK k;
   k.x = x.p; k.w = a.w; k.bias = a.bias; k.y = y.p;
   k.res = a.res_mode != RES_NONE ? a.res.p : nullptr;
-  k.M = x.n * OH * OW; k.H = x.h; k.W = x.w; k.Cin = x.c;
+  k.M = x.n * OH * OW; k.H = x.h * up; k.W = x.w * up; k.Cin = x.c;
+  k.x_up2 = a.x_up2;
   k.ldx = x.ld; k.x_bstride = x.bstride;
   k.OH = OH; k.OW = OW; k.OHW = OH * OW;
   k.N = y.c; k.Kreal = K; k.Kpad = a.Kpad;

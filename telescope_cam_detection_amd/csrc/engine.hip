@@ -28,6 +28,7 @@ thread_local std::string g_create_error;
 int g_dec_stamps = 0;  // plan-build switch: record per-phase stamps of decoder layer 2 into debug tensor "dec_stamps"
 int g_dec_split = 1;   // plan-build switch (rtd_debug_option "dec_split"): bf16 engine runs the fused decoder / AIFI linears as bf16 hi/lo splits
 int g_sc_fold = 1;     // plan-build switch (rtd_debug_option "sc_fold"): bf16 plans fold a block's projection shortcut into its last conv (ConvArgs::x2)
+int g_up_fold = 1;     // plan-build switch (rtd_debug_option "up_fold"): bf16 plans read the FPN's upsampled lateral straight from the half-size tensor
 int g_arena_reuse = 1; // plan-build switch (rtd_debug_option "arena_reuse"): backbone stages recycle their activation buffers
 int g_stem_fused = 0;  // plan-build switch (rtd_debug_option "stem_fused"): bf16 engine runs backbone.stem.0 straight from the uint8 frames.
                        // Measured neutral (same-box A/B: +0.2 % / 0 %: the kernel is latency-bound at 44 us against 56 + 20 us of
@@ -446,14 +447,16 @@ struct Builder {
   // (ConvArgs::x2: the projection shortcut folded into the block's last conv)
   void conv(const std::string& name, const Tensor& x, const Tensor& y, int k, int stride, int pad, int act,
             const Tensor* res = nullptr, int res_mode = RES_NONE, int real_cin = 0, const Tensor* x2 = nullptr,
-            const std::string& name2 = "") {
+            const std::string& name2 = "", int x_up2 = 0) {
     const int K = k * k * x.c + (x2 ? x2->c : 0);
     DevWeight w;
-    if (!dry) w = x2 ? get_weight_cat(e, name, name2, x.dt, y.c, k * k * x.c, x2->c) : get_weight(e, name, x.dt, y.c, K);
+    // name2 empty: `name` is already the filter over [x | x2] (a conv over a concatenation that is read from its two sources)
+    if (!dry) w = (x2 && !name2.empty()) ? get_weight_cat(e, name, name2, x.dt, y.c, k * k * x.c, x2->c) : get_weight(e, name, x.dt, y.c, K);
     else { w.Kpad = conv_kpad(K); w.Npad = conv_npad(y.c); }
     ConvArgs a;
     a.x = x; a.y = y; a.w = w.w; a.bias = w.bias;
     if (x2) a.x2 = *x2;
+    a.x_up2 = x_up2;
     a.KH = k; a.KW = k; a.stride = stride; a.pad = pad; a.Kpad = w.Kpad; a.Npad = w.Npad;
     a.act = act; a.res_mode = res ? res_mode : RES_NONE;
     if (res) a.res = *res;
@@ -690,9 +693,29 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   }
   t2.h = lh[2]; t2.w = lw[2];
 
-  auto csp = [&](const std::string& pfx, const Tensor& cat, const std::string& oname) {
+  // `up_src`: the half-resolution tensor whose 2x nearest upsampling is the first half of `cat`.  In bf16 plans the CSP's first
+  // 1x1 conv reads it directly (ConvArgs::x_up2 + x2 = the second half of cat): no upsample launch, no upsampled tensor.
+  auto csp = [&](const std::string& pfx, const Tensor& cat, const std::string& oname, const Tensor* up_src = nullptr) {
     Tensor h12 = B.act(P, cat.n, cat.h, cat.w, 2 * hh);
-    B.conv(pfx + ".c12", cat, h12, 1, 1, 0, ACT_SILU);
+    bool up_fold = false;
+    if (up_src && P == BF16 && g_up_fold) {
+      ConvArgs probe;                                          // shapes for ONE image, like the shortcut fold
+      probe.x = *up_src; probe.x.p = (void*)16; probe.x.n = 1;
+      probe.x2 = cat.slice_c(d, d); probe.x2.p = (void*)16; probe.x2.n = 1;
+      probe.y = h12; probe.y.p = (void*)16; probe.y.n = 1;
+      probe.x_up2 = 1;
+      up_fold = conv_dual_supported(probe);
+    }
+    if (up_fold) {
+      Tensor second = cat.slice_c(d, d);
+      B.conv(pfx + ".c12", *up_src, h12, 1, 1, 0, ACT_SILU, nullptr, RES_NONE, 0, &second, "", 1);
+    } else {
+      if (up_src) {
+        const Tensor src = *up_src, dst = cat.slice_c(0, d);
+        B.push(pfx + ".up", "upsample2x", 0.0, Builder::tbytes(src) + 4 * Builder::tbytes(src), [src, dst](hipStream_t s) { launch_upsample2x(src, dst, s); });
+      }
+      B.conv(pfx + ".c12", cat, h12, 1, 1, 0, ACT_SILU);
+    }
     Tensor r0 = B.act(P, cat.n, cat.h, cat.w, hh);
     B.conv(pfx + ".rep0", h12.slice_c(0, hh), r0, 3, 1, 1, ACT_SILU);
     Tensor r1 = B.act(P, cat.n, cat.h, cat.w, hh);
@@ -709,18 +732,13 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     B.conv(pfx + ".c3", r2, o, 1, 1, 0, ACT_SILU);
     return o;
   };
-  auto upsample = [&](const std::string& name, const Tensor& src, const Tensor& dst) {
-    B.push(name, "upsample2x", 0.0, Builder::tbytes(src) + 4 * Builder::tbytes(src), [src, dst](hipStream_t s) { launch_upsample2x(src, dst, s); });
-  };
   // FPN top-down
   Tensor lat0 = pcat1.slice_c(d, d);
   B.conv("enc.lat.0", t2, lat0, 1, 1, 0, ACT_SILU);
-  upsample("enc.up.0", lat0, cat0.slice_c(0, d));
-  Tensor F0 = csp("enc.fpn.0", cat0, "");
+  Tensor F0 = csp("enc.fpn.0", cat0, "", &lat0);
   Tensor lat1 = pcat0.slice_c(d, d);
   B.conv("enc.lat.1", F0, lat1, 1, 1, 0, ACT_SILU);
-  upsample("enc.up.1", lat1, cat1.slice_c(0, d));
-  Tensor F1 = csp("enc.fpn.1", cat1, "enc0");
+  Tensor F1 = csp("enc.fpn.1", cat1, "enc0", &lat1);
   // PAN bottom-up
   B.conv("enc.down.0", F1, pcat0.slice_c(0, d), 3, 2, 1, ACT_SILU);
   Tensor P1 = csp("enc.pan.0", pcat0, "enc1");
@@ -1467,6 +1485,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "sc_fold") == 0) { g_sc_fold = value; return RTD_OK; }
   if (strcmp(name, "maxpool_v1") == 0) { maxpool_set_v1(value); return RTD_OK; }
   if (strcmp(name, "arena_reuse") == 0) { g_arena_reuse = value; return RTD_OK; }
+  if (strcmp(name, "up_fold") == 0) { g_up_fold = value; return RTD_OK; }
   if (strcmp(name, "dec_split") == 0) { g_dec_split = value; return RTD_OK; }
   if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
   if (strcmp(name, "prefetch") == 0) { conv_set_prefetch(value); return RTD_OK; }
@@ -1489,7 +1508,7 @@ int rtd_debug_option(const char* name, int value) {
 }
 
 static int op_conv_impl(int dtype, const void* x, const void* x2, int C2, const void* w_ohwi_f32, const float* bias, const void* res, void* y,
-                        int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int act, int res_mode, int out_f32) {
+                        int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int act, int res_mode, int out_f32, int x_up2 = 0) {
   return op_guard([&] {
     RTD_CHECK(KH == KW, RTD_E_INVALID, "square filters only");
     const int K = KH * KW * Cin + (x2 ? C2 : 0), Kpad = conv_kpad(K), Npad = conv_npad(Cout);
@@ -1506,7 +1525,8 @@ static int op_conv_impl(int dtype, const void* x, const void* x2, int C2, const 
       launch_f32_to(wpad, wdev, BF16, (int64_t)Npad * Kpad, nullptr);
     } else wdev = wpad;
     ConvArgs a;
-    a.x = mk(x, dtype, B, H, W, Cin);
+    a.x = x_up2 ? mk(x, dtype, B, H / 2, W / 2, Cin) : mk(x, dtype, B, H, W, Cin);      // x_up2: H, W are the OUTPUT extents
+    a.x_up2 = x_up2;
     a.y = mk(y, out_f32 ? F32 : dtype, B, OH, OW, Cout);
     a.w = wdev; a.bias = bpad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.Npad = Npad;
     a.act = act; a.res_mode = res ? res_mode : RES_NONE;
@@ -1534,9 +1554,9 @@ int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* b
 }
 
 int rtd_op_conv_dual(int dtype, const void* x, const void* x2, const void* w_f32, const float* bias, const void* res, void* y, int B,
-                     int H, int W, int Cin, int C2, int Cout, int KH, int stride, int pad, int act, int res_mode, int out_f32) {
-  if (!x2) return RTD_E_INVALID;
-  return op_conv_impl(dtype, x, x2, C2, w_f32, bias, res, y, B, H, W, Cin, Cout, KH, KH, stride, pad, act, res_mode, out_f32);
+                     int H, int W, int Cin, int C2, int Cout, int KH, int stride, int pad, int act, int res_mode, int out_f32, int x_up2) {
+  if (!x2 || (x_up2 && ((H | W) & 1))) return RTD_E_INVALID;
+  return op_conv_impl(dtype, x, x2, C2, w_f32, bias, res, y, B, H, W, Cin, Cout, KH, KH, stride, pad, act, res_mode, out_f32, x_up2);
 }
 
 int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int stride, int pad, int with_res, int reps,

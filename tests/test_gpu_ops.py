@@ -110,17 +110,38 @@ def test_conv_dual(L, dt, case):
             # fp32 launches need >= 512 tiles for the LDS-DMA kernels: the library must refuse the shape, not fall back
             yd = torch.zeros(B, H, W, Cout, dtype=torch.float32, device="cuda")
             rc = L.rtd_op_conv_dual(code, xd.data_ptr(), x2d.data_ptr(), wcat.data_ptr(), bd.data_ptr(), None, yd.data_ptr(),
-                                    B, H, W, Cin, C2, Cout, k, 1, k // 2, {"none": 0, "relu": 1}[act], 0, out_f32)
+                                    B, H, W, Cin, C2, Cout, k, 1, k // 2, {"none": 0, "relu": 1}[act], 0, out_f32, 0)
             assert rc != 0
             continue
         _capi.debug_option("conv_mode", mode)
         yd = torch.full((B, H, W, Cout), float("nan"), dtype=torch.float32 if out_f32 else tdt, device="cuda")
         ck(L, L.rtd_op_conv_dual(code, xd.data_ptr(), x2d.data_ptr(), wcat.data_ptr(), bd.data_ptr(), None, yd.data_ptr(),
-                                 B, H, W, Cin, C2, Cout, k, 1, k // 2, {"none": 0, "relu": 1}[act], 0, out_f32))
+                                 B, H, W, Cin, C2, Cout, k, 1, k // 2, {"none": 0, "relu": 1}[act], 0, out_f32, 0))
         got = yd.float().cpu().permute(0, 3, 1, 2)
         tol = dict(atol=2e-5, rtol=2e-5) if dt == "f32" else (dict(atol=3e-3, rtol=3e-3) if out_f32 else dict(atol=3e-2, rtol=1e-2))
         torch.testing.assert_close(got, y, **tol)
     _capi.debug_option("conv_mode", 0)
+
+
+@pytest.mark.parametrize("case", [(2, 40, 36, 256, 256, 512, "silu"), (1, 26, 30, 64, 128, 256, "none"), (3, 20, 20, 128, 64, 128, "relu")])
+def test_conv_upsampled_first_input(L, case):
+    """ConvArgs::x_up2: a 1x1 conv over cat([upsample2x_nearest(lat), x2]) read from the half-size `lat` and x2 directly."""
+    B, H, W, Cin, C2, Cout, act = case
+    code, tdt = DT["bf16"]
+    g = torch.Generator().manual_seed(900 + Cin + H)
+    lat = torch.randn(B, Cin, H // 2, W // 2, generator=g)
+    x2 = torch.randn(B, C2, H, W, generator=g)
+    w = torch.randn(Cout, Cin + C2, generator=g) * (1.0 / (Cin + C2)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    q = lambda t: t.to(tdt).double()
+    cat = torch.cat([F.interpolate(q(lat), scale_factor=2.0, mode="nearest"), q(x2)], dim=1)
+    y = F.conv2d(cat, q(w)[:, :, None, None], b.double())
+    y = {"none": lambda t: t, "relu": F.relu, "silu": F.silu}[act](y).float()
+    ld, x2d, wd, bd = nhwc(lat, tdt), nhwc(x2, tdt), w.contiguous().cuda(), b.cuda()
+    yd = torch.full((B, H, W, Cout), float("nan"), dtype=tdt, device="cuda")
+    ck(L, L.rtd_op_conv_dual(code, ld.data_ptr(), x2d.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, yd.data_ptr(),
+                             B, H, W, Cin, C2, Cout, 1, 1, 0, {"none": 0, "relu": 1, "silu": 2}[act], 0, 0, 1))
+    torch.testing.assert_close(yd.float().cpu().permute(0, 3, 1, 2), y, atol=3e-2, rtol=1e-2)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
