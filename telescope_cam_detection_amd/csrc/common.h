@@ -246,6 +246,23 @@ void launch_f32_to(const float* src, void* dst, int dt, int64_t n, hipStream_t s
 void launch_to_f32(const void* src, int dt, float* dst, int64_t n, hipStream_t s);
 
 #if defined(__HIPCC__)
+// Reductions over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} (the 16-lane rows of a wave: an MFMA 16x16 accumulator's row groups)
+// on gfx950's row-swap VALU ops instead of two ds_bpermute round trips each: v_permlane16_swap exchanges odd rows of its first
+// operand with even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the second; fed the
+// same value twice, the two results are {this row pair's even row, its odd row} / {lower half, upper half} in every lane.  max and
+// fp add are commutative, so every lane gets the bits the xor-shuffle version produced.
+__device__ __forceinline__ float rows4_max(float v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float t = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows4_sum(float v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float t = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 // Wave-wide sum / max without LDS traffic: `__shfl_xor` compiles to ds_bpermute_b32 (an LDS-crossbar round trip, ~100+ cycles,
 // six in a dependent chain per reduction); here four DPP steps reduce each 16-lane row in the VALU and four v_readlane combine
 // the rows.  Every lane receives the result.  (Summation order differs from a butterfly - callers are not bit-pinned to one.)

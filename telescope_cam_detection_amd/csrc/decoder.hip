@@ -377,16 +377,14 @@ __device__ void self_attention_rows(const DecArgs& a, const float* sQ, int ldq, 
       sv[r] = (t * 16 + 4 * q + r < a.Q) ? S[r] : -INFINITY;
       mx = fmaxf(mx, sv[r]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = rows4_max(mx);
     const float mn = fmaxf(m, mx);
     const float alpha = __expf(m - mn);
     f32x4_ p;
     float rs = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { p[r] = __expf(sv[r] - mn); rs += p[r]; }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
+    rs = rows4_sum(rs);
     l = l * alpha + rs;
     m = mn;
 #pragma unroll
