@@ -217,6 +217,7 @@ struct DecArgs {
 };
 
 void launch_dec_layer(const DecArgs& a, hipStream_t s);
+void dec_set_pf(int v);
 
 // Query selection scores (HF:v2.py:1580-1586): per memory token LayerNorm(enc_output.fc) -> enc_score_head -> max over classes,
 // one launch; neither the normalised memory nor the class logits are written (the 300 selected rows are normalised again by

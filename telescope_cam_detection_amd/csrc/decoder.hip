@@ -136,7 +136,7 @@ __device__ __forceinline__ void split_rows(const float* Xs, int ldx, int K, bf16
 // v_mfma_f32_16x16x32_bf16 per 32-deep chunk (lo*hi, hi*lo, hi*hi; fp32 accumulate) instead of 8 v_mfma_f32_16x16x4_f32:
 // 5x less MFMA time for the same filter bytes, products exact to ~2^-17.  A lane's fragments: A[row = lane & 15][32c + 8 (lane >> 4) .. +7],
 // W[n0 + (lane & 15)][same k].  Output: fp32 Ys and / or a hi/lo split (Yh, Yl) for a following GEMM.
-template <int ACT, bool WLO = true>   // WLO = false: the filter's lo half is neither loaded nor multiplied (bf16 filter, split activations)
+template <int ACT, bool WLO = true, int PF = 2>   // WLO = false: the filter's lo half is neither loaded nor multiplied (bf16 filter, split activations)
 __device__ void row_gemm_split(const bf16* Ah, const bf16* Al, int lda, const DecLin& L, float* Ys, int ldy, const float* Rs, int ldr,
                                bf16* Yh, bf16* Yl, int ldyb, int wave, int lane, int rot) {
   const int ntiles = (L.N + 15) >> 4;
@@ -153,10 +153,10 @@ __device__ void row_gemm_split(const bf16* Ah, const bf16* Al, int lda, const De
     const char* w0 = (const char*)L.w + (size_t)t * kc * 2048 + lane * 16;
     const char* w1 = (const char*)L.w + (size_t)(has2 ? t + NW : t) * kc * 2048 + lane * 16;
     f32x4_ acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    // Two register sets (A, B), each one 64-deep K step of both tiles (8 x 16-byte loads per lane); a set is reloaded with the
-    // step two ahead right after its MFMAs were issued, so 8-16 loads per wave stay in flight (the loop is L2-latency bound:
-    // one step in flight per wave was 0.9 us per step).
-    bf16x8_ a0h[2], a0l[2], a1h[2], a1l[2], b0h[2], b0l[2], b1h[2], b1l[2];
+    // PF register sets, each one 64-deep K step of both tiles (8 x 16-byte loads per lane); a set is reloaded with the step PF
+    // ahead right after its MFMAs were issued, so 8 PF loads per wave stay in flight (the loop is L2-latency bound: one step in
+    // flight per wave was 0.9 us per step; rtd_debug_option "dec_pf" picks 2 or 3).
+    bf16x8_ wh0[PF][2], wl0[PF][2], wh1[PF][2], wl1[PF][2];
     int st = (rot + ps) % nsteps;
     auto nxt = [&](int v) { return v + 1 == nsteps ? 0 : v + 1; };
     auto load = [&](bf16x8_ (&h0)[2], bf16x8_ (&l0)[2], bf16x8_ (&h1)[2], bf16x8_ (&l1)[2], int step) {
@@ -183,21 +183,22 @@ __device__ void row_gemm_split(const bf16* Ah, const bf16* Al, int lda, const De
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, h1[j], acc1, 0, 0, 0);
       }
     };
-    const int s1 = nxt(st);
-    load(a0h, a0l, a1h, a1l, st);
-    if (nsteps > 1) load(b0h, b0l, b1h, b1l, s1);
-    int sa = st, sb = s1;
-    for (int it = 0; it < nsteps; it += 2) {                     // (wave-uniform guards: no load is issued past the last step)
-      __builtin_amdgcn_sched_barrier(0);
-      mma(a0h, a0l, a1h, a1l, sa);
-      __builtin_amdgcn_sched_barrier(0);
-      sa = nxt(sb);
-      if (it + 2 < nsteps) load(a0h, a0l, a1h, a1l, sa);
-      __builtin_amdgcn_sched_barrier(0);
-      if (it + 1 < nsteps) mma(b0h, b0l, b1h, b1l, sb);
-      __builtin_amdgcn_sched_barrier(0);
-      sb = nxt(sa);
-      if (it + 3 < nsteps) load(b0h, b0l, b1h, b1l, sb);
+    int cur = st, pf = st;                                       // step of the next MFMA group / of the next load
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      if (u < nsteps) { load(wh0[u], wl0[u], wh1[u], wl1[u], pf); pf = nxt(pf); }
+    }
+    for (int it = 0; it < nsteps; it += PF) {                    // (wave-uniform guards: no load is issued past the last step)
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        if (it + u < nsteps) {
+          __builtin_amdgcn_sched_barrier(0);
+          mma(wh0[u], wl0[u], wh1[u], wl1[u], cur);
+          cur = nxt(cur);
+          __builtin_amdgcn_sched_barrier(0);
+          if (it + u + PF < nsteps) { load(wh0[u], wl0[u], wh1[u], wl1[u], pf); pf = nxt(pf); }
+        }
+      }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -428,7 +429,7 @@ __device__ __forceinline__ void touch_weights(const DecLin& L, int part, int npa
 // SPLIT: the linear layers take hi/lo bf16 splits of their operands (row_gemm_split); every fp32 A operand of K <= 256 is split
 // into the sXh/sXl staging rows right before its GEMM, the two wide ones (FFN hidden 1024, qpos hidden 512) are written as
 // splits by the producing GEMM straight into the sF region (same bytes as the fp32 rows they replace).
-template <int SPLIT>
+template <int SPLIT, int DPF = 2>   // DPF: K steps of filter fragments each wave keeps in flight in the split GEMMs
 __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
   // LDS (floats).  Row strides are (cols + 4): ds_read_b128 of 16 rows x 4 k-groups is conflict-free.
   constexpr int LDH = 260, LDF = 1028, LDQ = 516, LDO = 292, LDR = 68;
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (SPLIT) {                                                                                             \
       split_rows(X, LDXS, (LW).K, sXh, sXl, LDX, tid);                                                       \
       __syncthreads();                                                                                       \
-      row_gemm_split<ACT, (SPLIT != 2)>(sXh, sXl, LDX, LW, Y, LDY, R, LDRS, nullptr, nullptr, 0, wave, lane, rot);         \
+      row_gemm_split<ACT, (SPLIT != 2), DPF>(sXh, sXl, LDX, LW, Y, LDY, R, LDRS, nullptr, nullptr, 0, wave, lane, rot);         \
     } else {                                                                                                 \
       row_gemm<ACT>(X, LDXS, LW, Y, LDY, R, LDRS, wave, lane, rot);                                          \
     }                                                                                                        \
@@ -553,8 +554,8 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (SPLIT) {
       split_rows(sH, LDH, a.fc1.K, sXh, sXl, LDX, tid);
       __syncthreads();
-      if (a.mode == 4) row_gemm_split<ACT_GELU, (SPLIT != 2)>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
-      else row_gemm_split<ACT_RELU, (SPLIT != 2)>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
+      if (a.mode == 4) row_gemm_split<ACT_GELU, (SPLIT != 2), DPF>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
+      else row_gemm_split<ACT_RELU, (SPLIT != 2), DPF>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
     } else {
       if (a.mode == 4) row_gemm<ACT_GELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane, rot);
       else row_gemm<ACT_RELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane, rot);
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     DEC_TOUCH(a.bb0);
     __syncthreads();
     DEC_STAMP(6);   // fc1
-    if (SPLIT) row_gemm_split<ACT_NONE, (SPLIT != 2)>(sFh, sFl, LDFB, a.fc2, sH, LDH, sH, LDH, nullptr, nullptr, 0, wave, lane, rot);
+    if (SPLIT) row_gemm_split<ACT_NONE, (SPLIT != 2), DPF>(sFh, sFl, LDFB, a.fc2, sH, LDH, sH, LDH, nullptr, nullptr, 0, wave, lane, rot);
     else row_gemm<ACT_NONE>(sF, LDF, a.fc2, sH, LDH, sH, LDH, wave, lane, rot);
     DEC_TOUCH(a.bb1);
     __syncthreads();
@@ -638,10 +639,10 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (SPLIT) {
       split_rows(sR, LDR, a.qp0.K, sXh, sXl, LDX, tid);
       __syncthreads();
-      row_gemm_split<ACT_RELU, (SPLIT != 2)>(sXh, sXl, LDX, a.qp0, nullptr, 0, nullptr, 0, sQh, sQl, LDQB, wave, lane, rot);
+      row_gemm_split<ACT_RELU, (SPLIT != 2), DPF>(sXh, sXl, LDX, a.qp0, nullptr, 0, nullptr, 0, sQh, sQl, LDQB, wave, lane, rot);
       DEC_TOUCH(a.v);
       __syncthreads();
-      row_gemm_split<ACT_NONE, (SPLIT != 2)>(sQh, sQl, LDQB, a.qp1, sP, LDH, nullptr, 0, nullptr, nullptr, 0, wave, lane, rot);
+      row_gemm_split<ACT_NONE, (SPLIT != 2), DPF>(sQh, sQl, LDQB, a.qp1, sP, LDH, nullptr, 0, nullptr, nullptr, 0, wave, lane, rot);
     } else {
       row_gemm<ACT_RELU>(sR, LDR, a.qp0, sT, LDQ, nullptr, 0, wave, lane, rot);
       DEC_TOUCH(a.v);
@@ -806,11 +807,14 @@ void launch_gather_ln(const float* x, int64_t ldx, int rows_per_image, const int
   HIP_CHECK(hipGetLastError());
 }
 
+static int g_dec_pf = 2;    // A/B hook (rtd_debug_option "dec_pf"): filter K steps in flight per wave in the split GEMMs (2 or 3)
+void dec_set_pf(int v) { g_dec_pf = v; }
 void launch_dec_layer(const DecArgs& a, hipStream_t s) {
   RTD_CHECK(a.D == 256 && a.D / a.heads == 32 && a.ffn <= 1024 && a.C <= 512, 1, "fused decoder: d_model 256, head dim 32, ffn <= 1024");
   RTD_CHECK(a.n_levels == 3 && a.n_points == 4 && a.heads == NW, 1, "fused decoder: 3 levels x 4 points, 8 heads");
   const int tiles = (a.Q + DR - 1) / DR;
   if (a.split == 2) hipLaunchKernelGGL(dec_layer_kernel<2>, dim3(a.B * tiles), dim3(NT), 0, s, a);
+  else if (a.split && g_dec_pf == 3) hipLaunchKernelGGL((dec_layer_kernel<1, 3>), dim3(a.B * tiles), dim3(NT), 0, s, a);
   else if (a.split) hipLaunchKernelGGL(dec_layer_kernel<1>, dim3(a.B * tiles), dim3(NT), 0, s, a);
   else hipLaunchKernelGGL(dec_layer_kernel<0>, dim3(a.B * tiles), dim3(NT), 0, s, a);
   HIP_CHECK(hipGetLastError());

@@ -1486,6 +1486,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "maxpool_v1") == 0) { maxpool_set_v1(value); return RTD_OK; }
   if (strcmp(name, "arena_reuse") == 0) { g_arena_reuse = value; return RTD_OK; }
   if (strcmp(name, "up_fold") == 0) { g_up_fold = value; return RTD_OK; }
+  if (strcmp(name, "dec_pf") == 0) { dec_set_pf(value); return RTD_OK; }
   if (strcmp(name, "dec_split") == 0) { g_dec_split = value; return RTD_OK; }
   if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
   if (strcmp(name, "prefetch") == 0) { conv_set_prefetch(value); return RTD_OK; }
