@@ -134,7 +134,17 @@ int rtd_debug_force_topk(rtd_handle h, const int32_t* idx, int32_t n);
 /* time every kernel of one forward of batch n with HIP events on the handle's stream */
 int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int32_t capacity, int32_t* count);
 int64_t rtd_arena_bytes(rtd_handle h);
-/* process-wide A/B switches for tests and profiling: "conv_v1" = 1 keeps every conv on the small-tile kernels */
+/* process-wide A/B switches for tests and profiling (defaults in brackets; unknown names return RTD_E_INVALID).
+ * Kernel dispatch, effective at the next launch / graph capture:
+ *   conv_mode [0]   0 auto | 1 small register-staged tiles | 2 + large register-staged tile | 3,4 wave-specialised LDS-DMA tile with
+ *                   4 / 2 stages | 5 single-role LDS-DMA | 6 whole-K-step fragment prefetch | 7 256-pixel tile | 8 A-stationary
+ *                   kernel wherever eligible | 9 streaming 1x1 kernels whatever the grid size
+ *   conv_reg [1], conv_stream [1], stream2 [1], stream_slab [1], stream_min_tiles [2048], wsa_min_ntn [8], ws2_min_blocks [257],
+ *   ws256_min_blocks [0], glds_min_blocks [4], glds_min_n [128], splitk [0], reg_epilogue [1], prefetch [1], maxpool_v1 [0],
+ *   dec_pf [2], glds_drop [0: timing-only probes, results wrong when set]
+ * Plan-build switches, read when an engine builds a plan (set them before rtd_load_weights):
+ *   sc_fold [1] projection shortcut folded into the block's last conv | up_fold [1] FPN upsample folded into the CSP's first conv |
+ *   arena_reuse [1] | stem_fused [0] | dec_fused [1], dec_split [1: 0 fp32 MFMA, 2 bf16 filters], sel_fused [1] | dec_stamps [0] */
 int rtd_debug_option(const char* name, int value);
 
 /* ---- Stage 2: crop + classifier pre-processing for a whole batch of detections ------------------
