@@ -81,6 +81,13 @@ struct ConvArgs {
   // x is read through a nearest-neighbour 2x upsampling: x is [B,OH/2,OW/2,Cin], output pixel (oy,ox) reads x(oy/2, ox/2).  1x1 /
   // stride 1 / pad 0 with a second input only (the FPN's `cat([upsample(lat), proj])` -> 1x1 conv without the upsampled tensor).
   int x_up2 = 0;
+  // optional FOLLOWING 1x1 conv fused into this launch (streaming kernel only, see conv_next_supported()): after a 32-pixel tile of
+  // y = act(...) is complete, the block also computes y_next = act_next(W_next * y + b_next) for those pixels from the tile it
+  // still holds in LDS - the next block's reduce conv never re-reads y from HBM (stage 0: 256 -> 64 channels, 105 MB per launch)
+  const void* next_w = nullptr;     // [Npad][Kpad] bf16, K = y.c
+  const float* next_bias = nullptr;
+  Tensor next_y;                    // [B,OH,OW,64]
+  int next_kpad = 0, next_act = ACT_NONE;
   int prefer256 = 0;   // throughput profile (rtd_config.profile): take the 256-pixel tile from 100 blocks on
   Tensor y;            // output [B,OH,OW,N] (view)
   int KH = 1, KW = 1, stride = 1, pad = 0;
@@ -94,7 +101,8 @@ struct ConvArgs {
   size_t pf_bytes = 0;
 };
 void launch_conv(const ConvArgs& a, hipStream_t s);
-bool conv_dual_supported(const ConvArgs& a);   // can this build's kernels run `a` with its second input? (the plan builder asks before fusing)
+bool conv_dual_supported(const ConvArgs& a);
+bool conv_next_supported(const ConvArgs& a);   // can `a` (shapes for ONE image) carry a fused following 1x1 conv (ConvArgs::next_*)?   // can this build's kernels run `a` with its second input? (the plan builder asks before fusing)
 int conv_kpad(int K);                 // padded filter row length the kernels expect
 int conv_npad(int N);
 void conv_set_force_v1(int v);      // A/B hook: 1 = never take the large-tile (v2) path

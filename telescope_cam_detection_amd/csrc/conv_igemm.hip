@@ -47,6 +47,11 @@ struct ConvK {
   int k2_start;
   int prefer256;         // ConvArgs::prefer256
   int x_up2;             // ConvArgs::x_up2 (ws kernel loader only)
+  const void* next_w;    // ConvArgs::next_* (streaming kernel only)
+  const float* next_bias;
+  void* next_y;
+  long long next_ldy, next_y_bstride;
+  int next_kpad, next_act;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -1927,8 +1932,12 @@ static bool dispatch_reg(const ConvK& k, const ConvArgs& a, long long x_bytes, h
 // SLAB: residual and output cross a wave-private LDS slab (32 rows x 128 bytes + 16 of bank skew, no block barrier) so that
 // their global accesses are row-shaped - 8 lanes x 16 bytes cover one pixel's 128-byte run, 8 lines per instruction instead of
 // 32 (tools/stream_probe.hip: 44 us against 53-61 us for the stage-0 c3 byte mix)
-template <int NKK, int THREADS, bool DUAL = false, bool SLAB = true>   // DUAL: the second half of K comes from ConvK::x2 (same channel count as x)
-__global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kernel(const ConvK a, unsigned x_bytes, unsigned r_bytes, unsigned y_bytes, unsigned x2_bytes, int CG, int ntiles) {
+// NEXT (N = 256, four waves = the four 64-channel groups of one 32-pixel tile): the following 256 -> 64 reduce conv runs on the tile
+// while its four slabs still hold y: wave w computes output channels 16 w .. 16 w + 15 of the 32 pixels with 16 v_mfma_f32_16x16x32_bf16
+// (its 16 x 256 filter slice stays in registers), reading every wave's slab between two block barriers; 8-byte stores.
+template <int NKK, int THREADS, bool DUAL = false, bool SLAB = true, bool NEXT = false>   // DUAL: the second half of K comes from ConvK::x2 (same channel count as x)
+__global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kernel(const ConvK a, unsigned x_bytes, unsigned r_bytes, unsigned y_bytes, unsigned x2_bytes, int CG, int ntiles, unsigned yn_bytes = 0) {
+  static_assert(!NEXT || (SLAB && THREADS == 256), "the fused reduce conv reads the four waves' slabs");
   constexpr int NW = THREADS / 64;
   __shared__ __attribute__((aligned(16))) float sbias[512];
   __shared__ __attribute__((aligned(16))) char pf_dummy[256];
@@ -1961,6 +1970,16 @@ __global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kern
   char* sl = slabs[SLAB ? wv : 0];
   char* sl_acc = sl + pl * SROW + h * 64;                      // this lane's 64 bytes in accumulator shape (pixel pl, channels 32h..)
   char* sl_row = sl + (lane >> 3) * SROW + (lane & 7) * 16;    // ... in row shape (pixel lane/8 + 8j, 16-byte chunk lane%8)
+  // NEXT: this wave's 16 x 256 slice of the following filter as v_mfma_f32_16x16x32_bf16 A operands (row lane & 15, k 32 s + 8 (lane >> 4) ..)
+  bf16x8 w1f[NEXT ? 8 : 1];
+  f32x4 b1v = {0.f, 0.f, 0.f, 0.f};
+  const __amdgpu_buffer_rsrc_t ryn = __builtin_amdgcn_make_buffer_rsrc((void*)(NEXT ? a.next_y : a.y), 0, NEXT ? yn_bytes : 0u, 0x00020000);
+  if (NEXT) {
+    const bf16* w1 = (const bf16*)a.next_w + (size_t)(16 * wv + (lane & 15)) * a.next_kpad + 8 * (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) w1f[s] = *(const bf16x8*)(w1 + 32 * s);
+    b1v = *(const f32x4*)(a.next_bias + 16 * wv + 4 * (lane >> 4));
+  }
 
   dispatch_act(a.act, [&](auto actc) {
     constexpr int ACT = decltype(actc)::value;
@@ -2051,6 +2070,36 @@ __global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kern
 #pragma unroll
         for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_*)(sl_row + j * 8 * SROW), ry, yrow[j], 0, 0);
         __builtin_amdgcn_wave_barrier();
+      }
+      if (NEXT) {
+        __syncthreads();                                         // the four slabs hold the tile's 256 output channels (bf16, activated)
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};   // pixels 0-15 / 16-31 (column lane & 15), channels 16 wv + 4 (lane >> 4) + e
+        const int r16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {                             // k = 32 s ..: slab s / 2 (64 channels each), 64-byte half s % 2
+          const char* sb = slabs[s >> 1] + (s & 1) * 64 + kq * 16 + r16 * SROW;
+          const bf16x8 p0 = *(const bf16x8*)sb, p1 = *(const bf16x8*)(sb + 16 * SROW);
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[s], p0, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[s], p1, c1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int mn = t * 32 + 16 * j + r16;
+          const int bn = mn / a.OHW;
+          const int pn = mn - bn * a.OHW;
+          const f32x4 c = j ? c1 : c0;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = c[e] + b1v[e];
+            if (a.next_act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+          }
+          const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+          const unsigned off = mn < a.M ? (unsigned)(((long long)bn * a.next_y_bstride + (long long)pn * a.next_ldy + 16 * wv + 4 * kq) * 2) : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, o), ryn, off, 0, 0);
+        }
+        __syncthreads();                                         // every wave has read the slabs: the next tile may overwrite them
       }
     }
   });
@@ -2211,7 +2260,8 @@ void conv_set_stream_min_tiles(int v) { g_stream_min_tiles = v; }
 
 // returns true when the launch was taken by the streaming kernel
 static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes, long long x2_bytes, hipStream_t s) {
-  if (!g_conv_stream || g_force_v1 || (g_conv_mode != 0 && g_conv_mode != 9)) return false;
+  const bool next = a.next_y.p != nullptr;                      // a fused following conv exists in this kernel only: no A/B switch applies
+  if (!next && (!g_conv_stream || g_force_v1 || (g_conv_mode != 0 && g_conv_mode != 9))) return false;
   const Tensor& x = a.x;
   const Tensor& y = a.y;
   const bool dual = a.x2.p != nullptr;
@@ -2246,6 +2296,8 @@ static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes
     return true;
   }
   const int K = x.c + (dual ? a.x2.c : 0);
+  if (next && !(y.c == 256 && a.next_y.c == 64 && a.next_y.dt == BF16 && a.next_kpad == 256 && a.next_y.ld % 4 == 0 && ((uintptr_t)a.next_y.p & 7) == 0 &&
+                a.next_w && a.next_bias && (a.next_act == ACT_RELU || a.next_act == ACT_NONE) && (K == 64 || dual))) return false;
   if (!(K == 64 || K == 128) || a.Kpad != K || y.c % 64 || y.c > 512 || x.ld % 8 || y.ld % 8 || ((uintptr_t)y.p & 15)) return false;
   if (a.res_mode != RES_NONE && (a.res.ld % 8 || ((uintptr_t)a.res.p & 15))) return false;
   const long long y_bytes = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * 2;
@@ -2257,7 +2309,17 @@ static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes
   const int NW = CG == 8 ? 8 : 4;
   const int PG = NW / CG;
   const long long ntiles = ((long long)k.M + 32 * PG - 1) / (32 * PG);
-  if ((ntiles * NW < g_stream_min_tiles && g_conv_mode != 9) || ntiles >= (1ll << 30)) return false;
+  if ((ntiles * NW < g_stream_min_tiles && g_conv_mode != 9 && !next) || ntiles >= (1ll << 30)) return false;
+  if (next) {
+    const long long yn_bytes = ((long long)(a.next_y.n - 1) * a.next_y.bstride + ((long long)a.next_y.h * a.next_y.w - 1) * a.next_y.ld + a.next_y.c) * 2;
+    if (yn_bytes >= (1ll << 31)) return false;
+    const unsigned gxn = (unsigned)std::min<long long>(ntiles, dual ? 512 : 768);   // 4-wave blocks: 2 (K = 128) or 3 (K = 64) waves per SIMD
+    if (dual) hipLaunchKernelGGL((conv1x1_stream_kernel<8, 256, true, true, true>), dim3(gxn), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes,
+                                 (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles, (unsigned)yn_bytes);
+    else hipLaunchKernelGGL((conv1x1_stream_kernel<4, 256, false, true, true>), dim3(gxn), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes,
+                            (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles, (unsigned)yn_bytes);
+    return true;
+  }
   // persistent blocks, as many as the register budget keeps resident (K = 64: 3 waves per SIMD, K = 128: 2)
   // (the slab variant of K = 64 needs 128 VGPRs: 4 waves per SIMD)
   const unsigned gx = (unsigned)std::min<long long>(ntiles, K == 64 ? (NW == 8 ? 256 : (g_stream_slab ? 1024 : 768)) : (NW == 8 ? 256 : 512));
@@ -2353,6 +2415,21 @@ bool conv_dual_supported(const ConvArgs& a) {
   return x_bytes < (1ll << 31) && x2_bytes < (1ll << 31) && w_bytes < (1ll << 31);
 }
 
+// The fused following conv exists in the streaming kernel for N = 256 (K = 64, or 64 + 64 with a second input) -> 64 channels; the
+// tile-count threshold of the dispatch must hold for ONE image so that every batch size takes the same path.
+bool conv_next_supported(const ConvArgs& a) {
+  const Tensor& x = a.x;
+  const Tensor& y = a.y;
+  const bool dual = a.x2.p != nullptr;
+  if (!g_conv_stream || !g_stream_slab || x.dt != BF16 || y.dt != BF16 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.x_up2) return false;
+  if (a.res_mode != RES_NONE && (a.res.dt != BF16 || a.res.ld % 8)) return false;
+  if (dual && !(x.c == 64 && a.x2.c == 64)) return false;
+  if (!dual && x.c != 64) return false;
+  if (y.c != 256 || x.ld % 8 || y.ld % 8 || a.next_y.c != 64 || a.next_y.dt != BF16 || a.next_y.ld % 4) return false;
+  const long long ntiles = ((long long)y.n * y.h * y.w + 31) / 32;
+  return ntiles * 4 >= g_stream_min_tiles;
+}
+
 void launch_conv(const ConvArgs& a, hipStream_t s) {
   const Tensor& x = a.x;
   const Tensor& y = a.y;
@@ -2378,6 +2455,9 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
   k.res = a.res_mode != RES_NONE ? a.res.p : nullptr;
   k.M = x.n * OH * OW; k.H = x.h * up; k.W = x.w * up; k.Cin = x.c;
   k.x_up2 = a.x_up2;
+  k.next_w = a.next_w; k.next_bias = a.next_bias; k.next_y = a.next_y.p; k.next_ldy = a.next_y.ld; k.next_y_bstride = a.next_y.bstride;
+  k.next_kpad = a.next_kpad; k.next_act = a.next_act;
+  if (a.next_y.p) RTD_CHECK(a.next_y.n == y.n && a.next_y.h == y.h && a.next_y.w == y.w, 1, "conv: fused next conv output shape");
   k.ldx = x.ld; k.x_bstride = x.bstride;
   k.OH = OH; k.OW = OW; k.OHW = OH * OW;
   k.N = y.c; k.Kreal = K; k.Kpad = a.Kpad;
@@ -2410,8 +2490,9 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     const long long es = (long long)dtype_size(x.dt);
     const long long x_bytes = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * es;
     const long long w_bytes = (long long)a.Npad * a.Kpad * es;
-    done = !dual && dispatch_reg(k, a, x_bytes, s);
+    done = !dual && !a.next_y.p && dispatch_reg(k, a, x_bytes, s);
     if (!done) done = dispatch_stream(k, a, x_bytes, x2_bytes, s);
+    RTD_CHECK(done || !a.next_y.p, 1, "conv: the fused following conv needs the streaming kernel (see conv_next_supported)");
     if (!done) {
       const long long yb = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * (long long)dtype_size(y.dt);
       const unsigned y_bytes = yb < (1ll << 31) ? (unsigned)yb : 0u;
@@ -2420,6 +2501,7 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     }
   }
   RTD_CHECK(done || !dual, 1, "conv: no kernel took the dual-input launch");
+  RTD_CHECK(done || !a.next_y.p, 1, "conv: no kernel took the launch with a fused following conv (see conv_next_supported)");
   if (!done) {
     if (x.dt == BF16) done = dispatch_v2<bf16>(k, v2_ok, s);
     else done = dispatch_v2<float>(k, v2_ok, s);

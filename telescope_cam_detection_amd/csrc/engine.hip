@@ -28,6 +28,7 @@ thread_local std::string g_create_error;
 int g_dec_stamps = 0;  // plan-build switch: record per-phase stamps of decoder layer 2 into debug tensor "dec_stamps"
 int g_dec_split = 1;   // plan-build switch (rtd_debug_option "dec_split"): bf16 engine runs the fused decoder / AIFI linears as bf16 hi/lo splits
 int g_sc_fold = 1;     // plan-build switch (rtd_debug_option "sc_fold"): bf16 plans fold a block's projection shortcut into its last conv (ConvArgs::x2)
+int g_c1_fuse = 1;     // plan-build switch (rtd_debug_option "c1_fuse"): bf16 plans run a stage-0 block's reduce conv inside the previous block's last conv
 int g_up_fold = 1;     // plan-build switch (rtd_debug_option "up_fold"): bf16 plans read the FPN's upsampled lateral straight from the half-size tensor
 int g_arena_reuse = 1; // plan-build switch (rtd_debug_option "arena_reuse"): backbone stages recycle their activation buffers
 int g_stem_fused = 0;  // plan-build switch (rtd_debug_option "stem_fused"): bf16 engine runs backbone.stem.0 straight from the uint8 frames.
@@ -447,7 +448,7 @@ struct Builder {
   // (ConvArgs::x2: the projection shortcut folded into the block's last conv)
   void conv(const std::string& name, const Tensor& x, const Tensor& y, int k, int stride, int pad, int act,
             const Tensor* res = nullptr, int res_mode = RES_NONE, int real_cin = 0, const Tensor* x2 = nullptr,
-            const std::string& name2 = "", int x_up2 = 0) {
+            const std::string& name2 = "", int x_up2 = 0, const Tensor* next_y = nullptr, const std::string& next_name = "", int next_act = ACT_NONE) {
     const int K = k * k * x.c + (x2 ? x2->c : 0);
     DevWeight w;
     // name2 empty: `name` is already the filter over [x | x2] (a conv over a concatenation that is read from its two sources)
@@ -460,13 +461,19 @@ struct Builder {
     a.KH = k; a.KW = k; a.stride = stride; a.pad = pad; a.Kpad = w.Kpad; a.Npad = w.Npad;
     a.act = act; a.res_mode = res ? res_mode : RES_NONE;
     if (res) a.res = *res;
+    if (next_y) {                                              // the following 1x1 conv rides on this launch (ConvArgs::next_*)
+      DevWeight wn;
+      if (!dry) wn = get_weight(e, next_name, x.dt, next_y->c, y.c);
+      else { wn.Kpad = conv_kpad(y.c); wn.Npad = conv_npad(next_y->c); }
+      a.next_w = wn.w; a.next_bias = wn.bias; a.next_y = *next_y; a.next_kpad = wn.Kpad; a.next_act = next_act;
+    }
     a.ws = e->conv_ws;
     a.prefer256 = e->cfg.profile == RTD_PROFILE_THROUGHPUT;
     const double M = (double)y.pixels();
     const double kreal = (double)k * k * (real_cin ? real_cin : x.c) + (x2 ? x2->c : 0);
-    const double flops = 2.0 * M * y.c * kreal;
+    const double flops = 2.0 * M * y.c * kreal + (next_y ? 2.0 * M * y.c * next_y->c : 0.0);
     const double bytes = (double)x.pixels() * x.c * dtype_size(x.dt) + tbytes(y) + (double)y.c * K * dtype_size(x.dt) +
-                         (res ? tbytes(*res) : 0.0) + (x2 ? tbytes(*x2) : 0.0);
+                         (res ? tbytes(*res) : 0.0) + (x2 ? tbytes(*x2) : 0.0) + (next_y ? tbytes(*next_y) : 0.0);
     auto ap = std::make_shared<ConvArgs>(a);
     if (!dry) {
       // chain: the previous conv launch of the plan prefetches THIS filter while it runs (ConvArgs::pf)
@@ -558,6 +565,8 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       if (!name.empty()) B.plan->named[name] = t;
       return t;
     };
+    bool c1_done = false;                                       // this block's c1 already ran inside the previous block's last conv
+    Tensor t1_next;
     for (int bi = 0; bi < c.depths[si]; ++bi) {
       const int stride = (si > 0 && bi == 0) ? 2 : 1;
       const std::string pfx = nm("backbone.s%d.b%d", si, bi);
@@ -602,12 +611,31 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       }
       Tensor out = g_arena_reuse ? view(pp[bi & 1], oh, ow, cout, oname) : B.act(P, n, oh, ow, cout, oname);
       if (c.layer_type == RTD_LAYER_BOTTLENECK) {
-        Tensor t1 = g_arena_reuse ? view(tb1, h, w, mid, "") : B.act(P, n, h, w, mid);
-        B.conv(pfx + ".c1", cur, t1, 1, 1, 0, ACT_RELU);
+        // the c1 output of this block: with recycled buffers it is the stage's shared temporary, which the PREVIOUS block's last conv
+        // may already have filled (ConvArgs::next_*: the reduce conv fused into the expand conv that produced its input)
+        Tensor t1 = g_arena_reuse ? view(tb1, h, w, mid, "") : (c1_done ? t1_next : B.act(P, n, h, w, mid));
+        if (!c1_done) B.conv(pfx + ".c1", cur, t1, 1, 1, 0, ACT_RELU);
+        c1_done = false;
         Tensor t2 = g_arena_reuse ? view(tb2, oh, ow, mid, "") : B.act(P, n, oh, ow, mid);
         B.conv(pfx + ".c2", t1, t2, 3, stride, 1, ACT_RELU);
-        if (fold_sc) B.conv(pfx + ".c3", t2, out, 1, 1, 0, ACT_RELU, nullptr, RES_NONE, 0, &sc_in, pfx + ".sc");
-        else B.conv(pfx + ".c3", t2, out, 1, 1, 0, ACT_RELU, &res, RES_PRE);
+        // fuse the NEXT block's c1 (same stage: stride 1, same extents, reads `out`) when the streaming kernel takes this conv
+        const Tensor* nx = nullptr;
+        std::string nx_name;
+        if (P == BF16 && g_c1_fuse && bi + 1 < c.depths[si]) {
+          Tensor t1_shape = out; t1_shape.c = t1_shape.ld = mid; t1_shape.bstride = (int64_t)oh * ow * mid;
+          ConvArgs probe;                                        // shapes for ONE image
+          probe.x = t2; probe.x.p = (void*)16; probe.x.n = 1;
+          probe.y = out; probe.y.p = (void*)16; probe.y.n = 1;
+          if (fold_sc) { probe.x2 = sc_in; probe.x2.p = (void*)16; probe.x2.n = 1; }
+          else { probe.res = res; probe.res.p = (void*)16; probe.res.n = 1; probe.res_mode = RES_PRE; }
+          probe.next_y = t1_shape; probe.next_y.p = (void*)16; probe.next_y.n = 1;
+          if (conv_next_supported(probe)) {
+            t1_next = g_arena_reuse ? view(tb1, oh, ow, mid, "") : B.act(P, n, oh, ow, mid);
+            nx = &t1_next; nx_name = nm("backbone.s%d.b%d", si, bi + 1) + ".c1"; c1_done = true;
+          }
+        }
+        if (fold_sc) B.conv(pfx + ".c3", t2, out, 1, 1, 0, ACT_RELU, nullptr, RES_NONE, 0, &sc_in, pfx + ".sc", 0, nx, nx_name, ACT_RELU);
+        else B.conv(pfx + ".c3", t2, out, 1, 1, 0, ACT_RELU, &res, RES_PRE, 0, nullptr, "", 0, nx, nx_name, ACT_RELU);
       } else {
         Tensor t1 = g_arena_reuse ? view(tb1, oh, ow, cout, "") : B.act(P, n, oh, ow, cout);
         B.conv(pfx + ".c1", cur, t1, 3, stride, 1, ACT_RELU);
@@ -1486,6 +1514,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "maxpool_v1") == 0) { maxpool_set_v1(value); return RTD_OK; }
   if (strcmp(name, "arena_reuse") == 0) { g_arena_reuse = value; return RTD_OK; }
   if (strcmp(name, "up_fold") == 0) { g_up_fold = value; return RTD_OK; }
+  if (strcmp(name, "c1_fuse") == 0) { g_c1_fuse = value; return RTD_OK; }
   if (strcmp(name, "dec_pf") == 0) { dec_set_pf(value); return RTD_OK; }
   if (strcmp(name, "dec_split") == 0) { g_dec_split = value; return RTD_OK; }
   if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
