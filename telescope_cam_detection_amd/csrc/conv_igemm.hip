@@ -1932,12 +1932,13 @@ static bool dispatch_reg(const ConvK& k, const ConvArgs& a, long long x_bytes, h
 // SLAB: residual and output cross a wave-private LDS slab (32 rows x 128 bytes + 16 of bank skew, no block barrier) so that
 // their global accesses are row-shaped - 8 lanes x 16 bytes cover one pixel's 128-byte run, 8 lines per instruction instead of
 // 32 (tools/stream_probe.hip: 44 us against 53-61 us for the stage-0 c3 byte mix)
-// NEXT (N = 256, four waves = the four 64-channel groups of one 32-pixel tile): the following 256 -> 64 reduce conv runs on the tile
-// while its four slabs still hold y: wave w computes output channels 16 w .. 16 w + 15 of the 32 pixels with 16 v_mfma_f32_16x16x32_bf16
-// (its 16 x 256 filter slice stays in registers), reading every wave's slab between two block barriers; 8-byte stores.
+// NEXT (the block's NW waves = the N / 64 channel groups of ONE 32-pixel tile; N = 256 or 512): the following N -> N / 4 reduce conv
+// runs on the tile while the slabs still hold y: wave w computes output channels 16 w .. 16 w + 15 of the 32 pixels with N / 16
+// v_mfma_f32_16x16x32_bf16 (its 16 x N filter slice stays in registers), reading every wave's slab between two block barriers.
 template <int NKK, int THREADS, bool DUAL = false, bool SLAB = true, bool NEXT = false>   // DUAL: the second half of K comes from ConvK::x2 (same channel count as x)
 __global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kernel(const ConvK a, unsigned x_bytes, unsigned r_bytes, unsigned y_bytes, unsigned x2_bytes, int CG, int ntiles, unsigned yn_bytes = 0) {
-  static_assert(!NEXT || (SLAB && THREADS == 256), "the fused reduce conv reads the four waves' slabs");
+  static_assert(!NEXT || SLAB, "the fused reduce conv reads the waves' slabs");
+  constexpr int NS = NEXT ? THREADS / 32 : 1;                   // 32-deep k steps of the fused conv: N / 32 with N = 64 NW
   constexpr int NW = THREADS / 64;
   __shared__ __attribute__((aligned(16))) float sbias[512];
   __shared__ __attribute__((aligned(16))) char pf_dummy[256];
@@ -1971,13 +1972,13 @@ __global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kern
   char* sl_acc = sl + pl * SROW + h * 64;                      // this lane's 64 bytes in accumulator shape (pixel pl, channels 32h..)
   char* sl_row = sl + (lane >> 3) * SROW + (lane & 7) * 16;    // ... in row shape (pixel lane/8 + 8j, 16-byte chunk lane%8)
   // NEXT: this wave's 16 x 256 slice of the following filter as v_mfma_f32_16x16x32_bf16 A operands (row lane & 15, k 32 s + 8 (lane >> 4) ..)
-  bf16x8 w1f[NEXT ? 8 : 1];
+  bf16x8 w1f[NS];
   f32x4 b1v = {0.f, 0.f, 0.f, 0.f};
   const __amdgpu_buffer_rsrc_t ryn = __builtin_amdgcn_make_buffer_rsrc((void*)(NEXT ? a.next_y : a.y), 0, NEXT ? yn_bytes : 0u, 0x00020000);
   if (NEXT) {
     const bf16* w1 = (const bf16*)a.next_w + (size_t)(16 * wv + (lane & 15)) * a.next_kpad + 8 * (lane >> 4);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) w1f[s] = *(const bf16x8*)(w1 + 32 * s);
+    for (int s = 0; s < NS; ++s) w1f[s] = *(const bf16x8*)(w1 + 32 * s);
     b1v = *(const f32x4*)(a.next_bias + 16 * wv + 4 * (lane >> 4));
   }
 
@@ -2076,7 +2077,7 @@ __global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kern
         f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};   // pixels 0-15 / 16-31 (column lane & 15), channels 16 wv + 4 (lane >> 4) + e
         const int r16 = lane & 15, kq = lane >> 4;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {                             // k = 32 s ..: slab s / 2 (64 channels each), 64-byte half s % 2
+        for (int s = 0; s < NS; ++s) {                            // k = 32 s ..: slab s / 2 (64 channels each), 64-byte half s % 2
           const char* sb = slabs[s >> 1] + (s & 1) * 64 + kq * 16 + r16 * SROW;
           const bf16x8 p0 = *(const bf16x8*)sb, p1 = *(const bf16x8*)(sb + 16 * SROW);
           c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[s], p0, c0, 0, 0, 0);
@@ -2296,8 +2297,9 @@ static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes
     return true;
   }
   const int K = x.c + (dual ? a.x2.c : 0);
-  if (next && !(y.c == 256 && a.next_y.c == 64 && a.next_y.dt == BF16 && a.next_kpad == 256 && a.next_y.ld % 4 == 0 && ((uintptr_t)a.next_y.p & 7) == 0 &&
-                a.next_w && a.next_bias && (a.next_act == ACT_RELU || a.next_act == ACT_NONE) && (K == 64 || dual))) return false;
+  if (next && !((y.c == 256 || y.c == 512) && a.next_y.c == y.c / 4 && a.next_y.dt == BF16 && a.next_kpad == y.c && a.next_y.ld % 4 == 0 &&
+                ((uintptr_t)a.next_y.p & 7) == 0 && a.next_w && a.next_bias && (a.next_act == ACT_RELU || a.next_act == ACT_NONE) &&
+                ((y.c == 256 && (K == 64 || dual)) || (y.c == 512 && K == 128 && !dual)))) return false;
   if (!(K == 64 || K == 128) || a.Kpad != K || y.c % 64 || y.c > 512 || x.ld % 8 || y.ld % 8 || ((uintptr_t)y.p & 15)) return false;
   if (a.res_mode != RES_NONE && (a.res.ld % 8 || ((uintptr_t)a.res.p & 15))) return false;
   const long long y_bytes = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * 2;
@@ -2313,8 +2315,10 @@ static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes
   if (next) {
     const long long yn_bytes = ((long long)(a.next_y.n - 1) * a.next_y.bstride + ((long long)a.next_y.h * a.next_y.w - 1) * a.next_y.ld + a.next_y.c) * 2;
     if (yn_bytes >= (1ll << 31)) return false;
-    const unsigned gxn = (unsigned)std::min<long long>(ntiles, dual ? 512 : 768);   // 4-wave blocks: 2 (K = 128) or 3 (K = 64) waves per SIMD
-    if (dual) hipLaunchKernelGGL((conv1x1_stream_kernel<8, 256, true, true, true>), dim3(gxn), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes,
+    const unsigned gxn = (unsigned)std::min<long long>(ntiles, NW == 8 ? 256 : (dual ? 512 : 768));   // 4-wave blocks: 2 (K = 128) or 3 (K = 64) waves per SIMD
+    if (NW == 8) hipLaunchKernelGGL((conv1x1_stream_kernel<8, 512, false, true, true>), dim3(gxn), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes,
+                                    (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles, (unsigned)yn_bytes);
+    else if (dual) hipLaunchKernelGGL((conv1x1_stream_kernel<8, 256, true, true, true>), dim3(gxn), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes,
                                  (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles, (unsigned)yn_bytes);
     else hipLaunchKernelGGL((conv1x1_stream_kernel<4, 256, false, true, true>), dim3(gxn), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes,
                             (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles, (unsigned)yn_bytes);
@@ -2415,19 +2419,20 @@ bool conv_dual_supported(const ConvArgs& a) {
   return x_bytes < (1ll << 31) && x2_bytes < (1ll << 31) && w_bytes < (1ll << 31);
 }
 
-// The fused following conv exists in the streaming kernel for N = 256 (K = 64, or 64 + 64 with a second input) -> 64 channels; the
-// tile-count threshold of the dispatch must hold for ONE image so that every batch size takes the same path.
+// The fused following conv exists in the streaming kernel for N = 256 (K = 64, or 64 + 64 with a second input) -> 64 channels and
+// N = 512 (K = 128) -> 128 channels.  Asked per plan (batch size): the fused and the separate form use the same filter tensors and
+// give bit-identical outputs, so plans of different batch sizes may differ.
 bool conv_next_supported(const ConvArgs& a) {
   const Tensor& x = a.x;
   const Tensor& y = a.y;
   const bool dual = a.x2.p != nullptr;
   if (!g_conv_stream || !g_stream_slab || x.dt != BF16 || y.dt != BF16 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.x_up2) return false;
   if (a.res_mode != RES_NONE && (a.res.dt != BF16 || a.res.ld % 8)) return false;
-  if (dual && !(x.c == 64 && a.x2.c == 64)) return false;
-  if (!dual && x.c != 64) return false;
-  if (y.c != 256 || x.ld % 8 || y.ld % 8 || a.next_y.c != 64 || a.next_y.dt != BF16 || a.next_y.ld % 4) return false;
+  if (dual && !(x.c == 64 && a.x2.c == 64 && y.c == 256)) return false;
+  if (!dual && !((x.c == 64 && y.c == 256) || (x.c == 128 && y.c == 512))) return false;
+  if (x.ld % 8 || y.ld % 8 || a.next_y.c != y.c / 4 || a.next_y.dt != BF16 || a.next_y.ld % 4) return false;
   const long long ntiles = ((long long)y.n * y.h * y.w + 31) / 32;
-  return ntiles * 4 >= g_stream_min_tiles;
+  return ntiles * (y.c / 64) >= g_stream_min_tiles;
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t s) {

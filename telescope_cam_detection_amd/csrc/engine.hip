@@ -623,12 +623,12 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
         std::string nx_name;
         if (P == BF16 && g_c1_fuse && bi + 1 < c.depths[si]) {
           Tensor t1_shape = out; t1_shape.c = t1_shape.ld = mid; t1_shape.bstride = (int64_t)oh * ow * mid;
-          ConvArgs probe;                                        // shapes for ONE image
-          probe.x = t2; probe.x.p = (void*)16; probe.x.n = 1;
-          probe.y = out; probe.y.p = (void*)16; probe.y.n = 1;
-          if (fold_sc) { probe.x2 = sc_in; probe.x2.p = (void*)16; probe.x2.n = 1; }
-          else { probe.res = res; probe.res.p = (void*)16; probe.res.n = 1; probe.res_mode = RES_PRE; }
-          probe.next_y = t1_shape; probe.next_y.p = (void*)16; probe.next_y.n = 1;
+          ConvArgs probe;                                        // this plan's shapes (fused and separate launches are bit-identical)
+          probe.x = t2; probe.x.p = (void*)16;
+          probe.y = out; probe.y.p = (void*)16;
+          if (fold_sc) { probe.x2 = sc_in; probe.x2.p = (void*)16; }
+          else { probe.res = res; probe.res.p = (void*)16; probe.res_mode = RES_PRE; }
+          probe.next_y = t1_shape; probe.next_y.p = (void*)16;
           if (conv_next_supported(probe)) {
             t1_next = g_arena_reuse ? view(tb1, oh, ow, mid, "") : B.act(P, n, oh, ow, mid);
             nx = &t1_next; nx_name = nm("backbone.s%d.b%d", si, bi + 1) + ".c1"; c1_done = true;
