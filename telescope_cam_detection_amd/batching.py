@@ -274,7 +274,7 @@ def make_rtdetr_coordinator(config: Dict[str, Any], coordinator_cls=None, detect
             coordinator_cls = BatchCoordinator
     rt = detection.get("rtdetr", {})
     max_batch = int(batching.get("max_batch_size", 4))
-    depth = int(batching.get("pipeline_depth", 1))      # build-specific key: batches in flight (2 = +35 % throughput on one MI355X)
+    depth = int(batching.get("pipeline_depth", 1))      # build-specific key: batches in flight (2 = +33 %, 3 = +46 % throughput on one MI355X)
     # several detectors share the GPU: their kernels lean towards throughput (rtd_config.profile); the reference's own
     # detector class knows no such argument and is never built with depth > 1
     prof = {"profile": "throughput"} if depth > 1 else {}

@@ -217,7 +217,7 @@ class RTDETRDetector:
     def detect_batch_async(self, frames: List[Union[np.ndarray, "torch.Tensor"]]):
         """Enqueue one batch (<= max_batch frames) on this detector's stream and return a ticket at once; `detect_batch_collect`
         blocks for that batch only.  With two detectors a coordinator keeps two batches in flight: one batch's kernels fill the
-        CUs the other's small grids leave idle (bench.py --streams 2: +35 % frames/s on one MI355X)."""
+        CUs the other's small grids leave idle (bench.py --streams 2 / 3: +33 % / +46 % frames/s on one MI355X)."""
         import torch
 
         if self.model is None:
