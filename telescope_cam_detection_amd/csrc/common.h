@@ -115,6 +115,7 @@ void conv_set_stream(int v);        // A/B hook: 0 = no streaming 1x1 kernel for
 void conv_set_stream_min_tiles(int v);
 void conv_set_stream_slab(int v);
 void conv_set_stream2(int v);
+void conv_set_stream2_max_n(int v);
 void conv_set_glds_min_n(int v);    // A/B hook: smallest Cout the LDS-DMA kernels take (bf16)
 void conv_set_reg_epilogue(int v);   // A/B hook: 0 = every ws tile goes through the fp32 staging epilogue
 void conv_set_ws2_min_blocks(int v);

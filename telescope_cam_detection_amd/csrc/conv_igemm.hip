@@ -2252,6 +2252,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 : 3) void conv1x1_strea
 
 static int g_conv_stream = 1;    // A/B hook (rtd_debug_option "conv_stream"): 0 = the thin 1x1 layers stay on the tiled kernels
 static int g_stream_min_tiles = 2048;
+static int g_stream2_max_n = 2048;   // A/B hook (rtd_debug_option "stream2_max_n"): widest layer the LDS-filter streaming kernel takes
+void conv_set_stream2_max_n(int v) { g_stream2_max_n = v; }
 static int g_stream2 = 1;        // A/B hook (rtd_debug_option "stream2"): 0 = the reducing 1x1 layers (K = 256) stay on the tiled kernels
 void conv_set_stream2(int v) { g_stream2 = v; }
 static int g_stream_slab = 1;    // A/B hook (rtd_debug_option "stream_slab"): 0 = accumulator-shaped global accesses
@@ -2269,7 +2271,7 @@ static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes
   if (a.x_up2 || x.dt != BF16 || y.dt != BF16 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0) return false;
   if (a.res_mode != RES_NONE && a.res.dt != BF16) return false;
   if (dual && !(x.c == 64 && a.x2.c == 64)) return false;
-  if (!dual && x.c == 256 && a.Kpad == 256 && (y.c == 64 || y.c % 128 == 0) && y.c <= 2048 && g_stream2) {
+  if (!dual && x.c == 256 && a.Kpad == 256 && (y.c == 64 || y.c % 128 == 0) && y.c <= g_stream2_max_n && g_stream2) {
     // reducing layers: filter in LDS, a wave owns all channels of its pixels
     if (x.ld % 8 || y.ld % 8 || ((uintptr_t)y.p & 15)) return false;
     if (a.res_mode != RES_NONE && (a.res.ld % 8 || ((uintptr_t)a.res.p & 15))) return false;
