@@ -211,6 +211,11 @@ def main():
                     rp = json.load(fh)
                 out["roofline"]["avg_launch_us_rocprofv3"] = rp["conv_igemm_all"]["avg_us"]
                 out["roofline"]["achieved_rocprofv3"] = round(d["flops"] / (rp["conv_igemm_all"]["us_per_step"] * 1e-6) / 1e12, 2)
+                # MFMA-pipe occupancy as the counters report it (SQ_VALU_MFMA_BUSY_CYCLES over GRBM_GUI_ACTIVE x SIMDs): independent of the
+                # clock the chip holds under load, low-biased on short dispatches (tools/summarize_profiles.py mfma)
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_util.json")) as fh:
+                    mu = json.load(fh)
+                out["roofline"]["mfma_busy_frac_pmc"] = mu["conv_igemm_all"]["mfma_util"]
         except (OSError, KeyError, ValueError):
             pass
         out["kernel_families_ms"] = {k: round(v["ms"], 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}

@@ -13,6 +13,7 @@ timeout -k 10 600 python bench.py > $O/bench_r50.json 2> $O/bench_r50.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o runc -- python3 bench.py --steps 20 --warmup 3 --streams 1 --no-cpu-baseline --no-latency > $O/trace.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o runc -- python3 bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-latency > $O/pmc_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o runc -- python3 bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-latency > $O/pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o runc -- python3 bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-latency > $O/pmc_mfma.log 2>&1
 # 3. the other configurations: R18 (the reference's default model), the exact fp32 engine, BASELINE config 3 (R101 1280^2 bs 4)
 timeout -k 10 300 python bench.py --arch r18 --no-cpu-baseline > $O/bench_r18.json 2>/dev/null
 timeout -k 10 300 python bench.py --precision fp32 --no-cpu-baseline --steps 30 --warmup 5 > $O/bench_fp32.json 2>/dev/null

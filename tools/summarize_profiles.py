@@ -4,6 +4,7 @@ committed under profiles/.
 
     python tools/summarize_profiles.py trace  gpurun_out/rp/runc/<pid>_kernel_trace.csv        profiles/rNN_rocprofv3_kernel_summary.json
     python tools/summarize_profiles.py pmc    <fetch counter_collection.csv> <write counter_collection.csv> profiles/rNN_pmc_hbm_traffic.json
+    python tools/summarize_profiles.py mfma   <counter_collection.csv of --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE> profiles/rNN_pmc_mfma_util.json
 """
 import collections
 import csv
@@ -84,8 +85,46 @@ def do_pmc(fetch, write, out):
             print(k, v["launches"], round(v["hbm_bytes_per_launch"] / 1e6, 2), "MB/launch")
 
 
+def do_mfma(path, out):
+    """MFMA-pipe utilisation as the counters report it: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over every SIMD of the chip; 32 per
+    v_mfma_f32_32x32x16_bf16) over GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs; = shader cycles of the dispatch) x 256 CUs x 4
+    SIMDs.  Clock-independent: a kernel whose CUs hold a low clock under MFMA load still shows its pipe occupancy."""
+    rows = list(csv.DictReader(open(path)))
+    by = collections.defaultdict(list)
+    for r in rows:
+        by[r["Counter_Name"]].append(r)
+    busy_rows = by["SQ_VALU_MFMA_BUSY_CYCLES"]
+    act_rows = by["GRBM_GUI_ACTIVE"]
+    steps_b, _ = steady_steps(busy_rows)
+    steps_a, _ = steady_steps(act_rows)
+    fam = collections.defaultdict(lambda: [0.0, 0.0, 0, 0.0])
+    for rb, ra in zip(steps_b[-1], steps_a[-1]):
+        assert rb["Dispatch_Id"] == ra["Dispatch_Id"]
+        f = fam[family(rb["Kernel_Name"])]
+        f[0] += float(rb["Counter_Value"])
+        f[1] += float(ra["Counter_Value"]) / 8.0
+        f[2] += 1
+        f[3] += (int(rb["End_Timestamp"]) - int(rb["Start_Timestamp"])) / 1e3
+    res = {"note": "one steady graph step of `bench.py --streams 1` under rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; "
+                   "util = busy / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs); clock = GRBM_GUI_ACTIVE / 8 / duration (reads high on short dispatches)"}
+    tb = ta = 0.0
+    for k, (b, a, c, us) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+        res[k] = dict(launches=c, mfma_busy_cycles=b, shader_cycles=a, us=round(us, 1), mfma_util=round(b / (a * 1024.0), 4) if a else 0.0,
+                      mean_clock_ghz=round(a / us / 1e3, 3) if us else 0.0)
+        tb += b; ta += a
+    res["whole_step"] = dict(mfma_util=round(tb / (ta * 1024.0), 4))
+    conv = [v for k, v in res.items() if isinstance(v, dict) and k.startswith("conv")]
+    res["conv_igemm_all"] = dict(mfma_util=round(sum(v["mfma_busy_cycles"] for v in conv) / (sum(v["shader_cycles"] for v in conv) * 1024.0), 4))
+    json.dump(res, open(out, "w"), indent=1)
+    for k, v in res.items():
+        if isinstance(v, dict):
+            print(k, v)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "trace":
         do_trace(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "mfma":
+        do_mfma(sys.argv[2], sys.argv[3])
     else:
         do_pmc(sys.argv[2], sys.argv[3], sys.argv[4])
