@@ -123,6 +123,80 @@ def test_conv_dual(L, dt, case):
     _capi.debug_option("conv_mode", 0)
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_dual_input_conv_random_shapes(L, seed):
+    """ConvArgs::x2 / x_up2 on random small maps (ragged tiles, tiles across images), 1x1 and 3x3 main convs."""
+    rng = np.random.default_rng(7700 + seed)
+    Cin, C2 = int(rng.choice([64, 128, 256])), int(rng.choice([64, 128, 256]))
+    Cout = int(rng.choice([128, 256, 320]))
+    k = int(rng.choice([1, 3]))
+    up2 = int(k == 1 and rng.integers(0, 2))
+    B = int(rng.integers(1, 4))
+    H, W = int(rng.integers(1, 20)) * 2, int(rng.integers(1, 20)) * 2
+    act = str(rng.choice(["none", "relu", "silu"]))
+    code, tdt = DT["bf16"]
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    x = torch.randn(B, Cin, H // 2 if up2 else H, W // 2 if up2 else W, generator=g)
+    x2 = torch.randn(B, C2, H, W, generator=g)
+    w1 = torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k)) ** 0.5
+    w2 = torch.randn(Cout, C2, 1, 1, generator=g) * (1.0 / C2) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    q = lambda t: t.to(tdt).double()
+    xin = F.interpolate(q(x), scale_factor=2.0, mode="nearest") if up2 else q(x)
+    y = F.conv2d(xin, q(w1), b.double(), padding=k // 2) + F.conv2d(q(x2), q(w2))
+    y = {"none": lambda t: t, "relu": F.relu, "silu": F.silu}[act](y).float()
+    wcat = torch.cat([w1.permute(0, 2, 3, 1).reshape(Cout, -1), w2.reshape(Cout, C2)], dim=1).contiguous().cuda()
+    xd, x2d, bd = nhwc(x, tdt), nhwc(x2, tdt), b.cuda()
+    yd = torch.full((B, H, W, Cout), float("nan"), dtype=tdt, device="cuda")
+    rc = L.rtd_op_conv_dual(code, xd.data_ptr(), x2d.data_ptr(), wcat.data_ptr(), bd.data_ptr(), None, yd.data_ptr(),
+                            B, H, W, Cin, C2, Cout, k, 1, k // 2, {"none": 0, "relu": 1, "silu": 2}[act], 0, 0, up2)
+    tiles = ((B * H * W + 127) // 128) * ((Cout + 127) // 128)
+    if tiles < 4:                       # fewer tiles than the LDS-DMA kernels take: refused, never a silent fallback
+        assert rc != 0
+        return
+    ck(L, rc)
+    torch.testing.assert_close(yd.float().cpu().permute(0, 3, 1, 2), y, atol=3e-2, rtol=1e-2,
+                               msg=lambda m: f"{m} shape {(B, H, W, Cin, C2, Cout, k, up2, act)}")
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_streaming_1x1_kernels_random_shapes(L, seed):
+    """conv_mode 9 (streaming kernels on any grid): random small maps - images smaller than a 32-pixel tile, tiles that straddle
+    several images, ragged last tiles - for every channel configuration the three streaming kernels take."""
+    rng = np.random.default_rng(4200 + seed)
+    Cin = int(rng.choice([64, 128, 256]))
+    Cout = int(rng.choice([64, 128, 256, 512]) if Cin != 256 else rng.choice([64, 128, 256, 384, 640]))
+    B, H, W = int(rng.integers(1, 5)), int(rng.integers(1, 40)), int(rng.integers(1, 40))
+    act = str(rng.choice(["none", "relu", "silu"]))
+    res_mode = int(rng.integers(0, 3))
+    code, tdt = DT["bf16"]
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * (1.0 / Cin) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(B, Cout, H, W, generator=g) if res_mode else None
+    q = lambda t: t.to(tdt).double()
+    y = F.conv2d(q(x), q(w), b.double())
+    if res_mode == 1:
+        y = y + q(res)
+    y = {"none": lambda t: t, "relu": F.relu, "silu": F.silu}[act](y)
+    if res_mode == 2:
+        y = y + q(res)
+    from telescope_cam_detection_amd import _capi
+    _capi.debug_option("conv_mode", 9)
+    try:
+        xd, wd, bd = nhwc(x, tdt), w.permute(0, 2, 3, 1).contiguous().cuda(), b.cuda()
+        rd = nhwc(res, tdt) if res is not None else None
+        yd = torch.full((B, H, W, Cout), float("nan"), dtype=tdt, device="cuda")
+        ck(L, L.rtd_op_conv(code, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None, yd.data_ptr(),
+                            B, H, W, Cin, Cout, 1, 1, 1, 0, {"none": 0, "relu": 1, "silu": 2}[act], res_mode, 0))
+    finally:
+        _capi.debug_option("conv_mode", 0)
+    got = yd.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all(), (B, H, W, Cin, Cout, act, res_mode)
+    torch.testing.assert_close(got, y.float(), atol=3e-2, rtol=1e-2, msg=lambda m: f"{m} shape {(B, H, W, Cin, Cout, act, res_mode)}")
+
+
 @pytest.mark.parametrize("case", [(2, 40, 36, 256, 256, 512, "silu"), (1, 26, 30, 64, 128, 256, "none"), (3, 20, 20, 128, 64, 128, "relu")])
 def test_conv_upsampled_first_input(L, case):
     """ConvArgs::x_up2: a 1x1 conv over cat([upsample2x_nearest(lat), x2]) read from the half-size `lat` and x2 directly."""
