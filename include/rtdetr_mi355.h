@@ -138,8 +138,8 @@ int64_t rtd_arena_bytes(rtd_handle h);
  * Kernel dispatch, effective at the next launch / graph capture:
  *   conv_mode [0]   0 auto | 1 small register-staged tiles | 2 + large register-staged tile | 3,4 wave-specialised LDS-DMA tile with
  *                   4 / 2 stages | 5 single-role LDS-DMA | 6 whole-K-step fragment prefetch | 7 256-pixel tile | 8 A-stationary
- *                   kernel wherever eligible | 9 streaming 1x1 kernels whatever the grid size
- *   conv_reg [1], conv_stream [1], stream2 [1], stream2_max_n [2048], stream_slab [1], stream_min_tiles [2048], wsa_min_ntn [8], ws2_min_blocks [257],
+ *                   kernel wherever eligible | 9 streaming 1x1 kernels whatever the grid size | 10 128 x 64 tile everywhere
+ *   conv_reg [1], conv_stream [1], stream2 [1], stream2_max_n [2048], stream_slab [1], stream_min_tiles [2048], wsa_min_ntn [8], ws2_min_blocks [257], ws64_max_blocks [160],
  *   ws256_min_blocks [0], glds_min_blocks [4], glds_min_n [128], splitk [0], reg_epilogue [1], prefetch [1], maxpool_v1 [0],
  *   dec_pf [2], glds_drop [0: timing-only probes, results wrong when set]
  * Plan-build switches, read when an engine builds a plan (set them before rtd_load_weights):

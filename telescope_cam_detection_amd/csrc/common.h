@@ -119,6 +119,7 @@ void conv_set_stream2_max_n(int v);
 void conv_set_glds_min_n(int v);    // A/B hook: smallest Cout the LDS-DMA kernels take (bf16)
 void conv_set_reg_epilogue(int v);   // A/B hook: 0 = every ws tile goes through the fp32 staging epilogue
 void conv_set_ws2_min_blocks(int v);
+void conv_set_ws64_max_blocks(int v);
 void conv_set_wsa_min_ntn(int v);
 void conv_set_prefetch(int v);      // A/B hook: 0 = launches ignore ConvArgs::pf
 void conv_set_mode(int v);          // A/B hook: 0 auto, 1 = v1 only, 2 = v1 + v2 (no LDS-DMA kernel)

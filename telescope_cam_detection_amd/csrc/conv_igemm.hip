@@ -55,6 +55,7 @@ struct ConvK {
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
 // Touch `pf_bytes` at `pf` (one dword per 128-byte line, this block's share) with LDS-DMA into a 256-byte dummy: no VGPR is
 // written, nothing waits for the data; the lines land in this XCD's L2 and in the Infinity Cache.
@@ -737,20 +738,21 @@ __device__ __forceinline__ bool g_reg_epilogue_ok(const ConvK& a) { return a.res
 
 // Copy-out of a tile that is already final (bias + activation applied in the MFMA waves' registers, bf16 rows in LDS): pure
 // 16-byte LDS -> global moves, 32 rows apart per iteration.
-template <int ITERS>
+template <int ITERS, int BN = 128>   // 512 threads: BN / 8 chunks per row, 4096 / BN rows per pass
 __device__ __forceinline__ void ws_copy_out_bf16(const ConvK& a, const bf16* sb, int SLB, int tid, int m0, int n0) {
-  const int c8 = tid & 15;
+  constexpr int CH8 = BN / 8, RSTEP = 512 / CH8;
+  const int c8 = tid % CH8;
   const int c = n0 + c8 * 8;
   if (c >= a.N) return;
-  int m = m0 + (tid >> 4);
+  int m = m0 + tid / CH8;
   const int b = m / a.OHW;
   int p = m - b * a.OHW;
   long long yoff = (long long)b * a.y_bstride + (long long)p * a.ldy + c;
-  const bf16* srow = sb + (tid >> 4) * SLB + c8 * 8;
+  const bf16* srow = sb + (tid / CH8) * SLB + c8 * 8;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     if (m < a.M) *(bf16x8*)((bf16*)a.y + yoff) = *(const bf16x8*)srow;
-    m += 32; p += 32; yoff += 32 * a.ldy; srow += 32 * SLB;
+    m += RSTEP; p += RSTEP; yoff += RSTEP * a.ldy; srow += RSTEP * SLB;
     while (p >= a.OHW) { p -= a.OHW; yoff += a.y_bstride - (long long)a.OHW * a.ldy; }
   }
 }
@@ -758,18 +760,19 @@ __device__ __forceinline__ void ws_copy_out_bf16(const ConvK& a, const bf16* sb,
 // Copy-out of the wave-specialised kernels: staging tile (fp32, [rows][SLD]) -> bias (+ residual) -> activation -> y, 8 channels
 // (16 bytes of bf16) per thread and iteration, 32 rows apart.  The loop is instruction-bound (2 waves per SIMD walk it), so the
 // pixel -> (image, offset) division is done once and carried, and the activation is a template parameter.
-template <int ITERS, int ACT>
+template <int ITERS, int ACT, int BN = 128>
 __device__ __forceinline__ void ws_copy_out(const ConvK& a, const float* st, int SLD, int tid, int m0, int n0, const bf16x8* rpre) {
-  const int c8 = tid & 15;
+  constexpr int CH8 = BN / 8, RSTEP = 512 / CH8;
+  const int c8 = tid % CH8;
   const int c = n0 + c8 * 8;
   if (c >= a.N) return;
   const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
-  int m = m0 + (tid >> 4);
+  int m = m0 + tid / CH8;
   int b = m / a.OHW;
   int p = m - b * a.OHW;
   long long yoff = (long long)b * a.y_bstride + (long long)p * a.ldy + c;
   long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
-  const float* srow = st + (tid >> 4) * SLD + c8 * 8;
+  const float* srow = st + (tid / CH8) * SLD + c8 * 8;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     if (m < a.M) {
@@ -806,11 +809,11 @@ __device__ __forceinline__ void ws_copy_out(const ConvK& a, const float* st, int
         *(bf16x8*)((bf16*)a.y + yoff) = o;
       }
     }
-    m += 32;
-    p += 32;
-    yoff += 32 * a.ldy;
-    roff += 32 * a.ldr;
-    srow += 32 * SLD;
+    m += RSTEP;
+    p += RSTEP;
+    yoff += RSTEP * a.ldy;
+    roff += RSTEP * a.ldr;
+    srow += RSTEP * SLD;
     while (p >= a.OHW) {                                        // next image (maps smaller than 32 pixels wrap more than once)
       p -= a.OHW;
       yoff += a.y_bstride - (long long)a.OHW * a.ldy;
@@ -834,10 +837,18 @@ __device__ __forceinline__ void ws_copy_out(const ConvK& a, const float* st, int
 // while the MFMAs of tile ks run, so no ds_read latency is exposed behind the barrier (tools/ingest_probe.hip: the L2 ->
 // LDS path sustains 115-150 GB/s per CU, 2.5x what the non-DEEP K-step takes in; its K-step is bound by the serial
 // ds_read -> MFMA chain after each barrier, not by the DMA).  Tiles land one barrier earlier: 2 tiles stay in flight.
-template <typename T, int STAGES, bool DEEP = false>
+// BN = 64: a 128 pixel x 64 channel tile for grids that leave most CUs idle with 128 x 128 tiles (stage 3 / PAN at batch 8, nearly
+// everything at batch 1): twice the blocks, each MFMA wave owns 32 pixels x 64 channels (one pixel tile, two channel tiles), the
+// loaders stage 24 KiB per K-step.  Same K order per output, so a layer's results do not depend on which tile width ran it.
+template <typename T, int STAGES, bool DEEP = false, int BN = 128>
 __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kernel(const ConvG g) {
   const ConvK& a = g.k;
-  constexpr int BM = 128, BN = 128;
+  constexpr int BM = 128;
+  static_assert(BN == 128 || (BN == 64 && !DEEP), "tile widths");
+  constexpr int TJ = BN == 128 ? 2 : 1;          // pixel tiles (32 rows) per MFMA wave; channel tiles per wave: always 2
+  constexpr int NBI = BN / 32;                    // 32-row filter pieces per loader wave and K-step
+  constexpr int PPT = 4 + NBI;                    // LDS-DMA pieces per loader wave and K-step (counted waits)
+  constexpr int CH8 = BN / 8, RSTEP = 512 / CH8, CITERS = BM / RSTEP;   // copy-out: 16-byte chunks per row, rows per pass, passes
   constexpr int ES = (int)sizeof(T);
   constexpr int BK = 128 / ES;
   constexpr int STAGE = (BM + BN) * 128;
@@ -854,7 +865,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform -> scalar role branches
   const bool loader = wv >= 4;
   const int w4 = wv & 3;
-  const int wm = w4 & 1, wn = w4 >> 1;
+  const int wm = BN == 128 ? (w4 & 1) : w4, wn = BN == 128 ? (w4 >> 1) : 0;
   int wg;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -876,29 +887,29 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
   const long long t_base = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
   if (stamps && wv == 0) stamps[6] = (long long)__builtin_amdgcn_s_memrealtime();
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][TJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // bf16 residual rows of this thread's 4 epilogue iterations: every load is issued at kernel start, beside the first tile's DMA (and
   // before any store to y, which the compiler must assume aliases res): the residual latency overlaps the K loop instead of
   // being paid four times in series in the epilogue
-  const int c8 = tid & 15;
+  const int c8 = tid % CH8;
   const int c = n0 + c8 * 8;
   bf16x8 rpre[4];
   if (a.res_mode != RES_NONE && !a.res_f32 && c < a.N) {
-    int m = m0 + (tid >> 4);
+    int m = m0 + tid / CH8;
     const int b = m / a.OHW;
     int p = m - b * a.OHW;
     long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {                                // rows 32 apart: carry (image, pixel) instead of dividing again
+    for (int it = 0; it < CITERS; ++it) {                           // rows RSTEP apart: carry (image, pixel) instead of dividing again
       if (m < a.M) rpre[it] = *(const bf16x8*)((const bf16*)a.res + roff);
-      m += 32; p += 32; roff += 32 * a.ldr;
+      m += RSTEP; p += RSTEP; roff += RSTEP * a.ldr;
       while (p >= a.OHW) { p -= a.OHW; roff += a.r_bstride - (long long)a.OHW * a.ldr; }
     }
   }
@@ -971,7 +982,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NBI; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sa + BM * 128 + i * 4096), 16, (unsigned)(b_off[i] + k0 * ES), 0, 0, 0);
       k0 += BK;
       c0 += BK;
@@ -980,7 +991,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
         if (++kw == a.KW) { kw = 0; ++kh; }
       }
     };
-    if (DEEP) {
+    if constexpr (DEEP) {
       // tile t lives in buffer t % 4.  Before barrier ks tile ks+1 must have landed (the MFMA waves read it during step
       // ks); after barrier ks the buffer of tile ks (read during step ks-1, reads drained before the barrier) is refilled.
       for (int t = 0; t < 4 && t < nk; ++t) issue(t);
@@ -1001,15 +1012,15 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
     for (int t = 0; t < AHEAD && t < nk; ++t) issue(t);
     for (int ks = 0; ks < nk; ++ks) {
       const int younger = nk - 1 - ks;
-      if (STAGES == 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (STAGES >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (STAGES == 4 && younger >= 2) wait_vmcnt<2 * PPT>();
+      else if (STAGES >= 3 && younger >= 1) wait_vmcnt<PPT>();
+      else wait_vmcnt<0>();
       if (stamps && wv == 4 && ks == 0) stamps[0] = (long long)__builtin_amdgcn_s_memtime() - t_base;
       __builtin_amdgcn_s_barrier();
       if (ks + AHEAD < nk) issue((ks + AHEAD) % STAGES);
     }
     }
-  } else if (DEEP) {
+  } else if constexpr (DEEP) {
     // ---- MFMA role, whole-K-step fragment double buffering ------------------------------------------
     int foff[4];
 #pragma unroll
@@ -1057,25 +1068,25 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
     for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 128 + (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
     for (int ks = 0; ks < nk; ++ks) {
       __builtin_amdgcn_s_barrier();
-      const char* sa = smem + (ks % STAGES) * STAGE + wm * 64 * 128;
+      const char* sa = smem + (ks % STAGES) * STAGE + wm * (32 * TJ) * 128;
       const char* sb = smem + (ks % STAGES) * STAGE + (BM + wn * 64) * 128;
-      Frag xf[2][2], wf[2][2];                     // [register buffer][tile]: fragments of step kk+1 load under the MFMAs of kk
+      Frag xf[2][TJ], wf[2][2];                    // [register buffer][tile]: fragments of step kk+1 load under the MFMAs of kk
 #pragma unroll
-      for (int j = 0; j < 2; ++j) xf[0][j] = *(const Frag*)(sa + j * 4096 + foff[0]);
+      for (int j = 0; j < TJ; ++j) xf[0][j] = *(const Frag*)(sa + j * 4096 + foff[0]);
 #pragma unroll
       for (int i = 0; i < 2; ++i) wf[0][i] = *(const Frag*)(sb + i * 4096 + foff[0]);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         if (kk < 3) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) xf[(kk + 1) & 1][j] = *(const Frag*)(sa + j * 4096 + foff[kk + 1]);
+          for (int j = 0; j < TJ; ++j) xf[(kk + 1) & 1][j] = *(const Frag*)(sa + j * 4096 + foff[kk + 1]);
 #pragma unroll
           for (int i = 0; i < 2; ++i) wf[(kk + 1) & 1][i] = *(const Frag*)(sb + i * 4096 + foff[kk + 1]);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) Mma<T>::run(wf[kk & 1][i], xf[kk & 1][j], acc[i][j]);
+          for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[kk & 1][i], xf[kk & 1][j], acc[i][j]);
       }
     }
   }
@@ -1092,11 +1103,11 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-            *(f32x4*)(my + ((((i * 2 + j) * 4 + q) * 256) + w4 * 64 + lane) * 4) = v;
+            *(f32x4*)(my + ((((i * TJ + j) * 4 + q) * 256) + w4 * 64 + lane) * 4) = v;
           }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1123,10 +1134,10 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const f32x4 v = *(const f32x4*)(other + ((((i * 2 + j) * 4 + q) * 256) + w4 * 64 + lane) * 4);
+              const f32x4 v = *(const f32x4*)(other + ((((i * TJ + j) * 4 + q) * 256) + w4 * 64 + lane) * 4);
 #pragma unroll
               for (int u = 0; u < 4; ++u) acc[i][j][4 * q + u] += v[u];
             }
@@ -1150,8 +1161,8 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
           for (int q = 0; q < 4; ++q) {
             const f32x4 bv = *(const f32x4*)(a.bias + n0 + wn * 64 + i * 32 + 8 * q + 4 * h);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const int pl = wm * 64 + j * 32 + (lane & 31);
+            for (int j = 0; j < TJ; ++j) {
+              const int pl = wm * (32 * TJ) + j * 32 + (lane & 31);
               bf16x4 o;
 #pragma unroll
               for (int e = 0; e < 4; ++e) o[e] = (bf16)act_c<ACT>(acc[i][j][4 * q + e] + bv[e]);
@@ -1161,15 +1172,15 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
       });
     }
     __syncthreads();
-    ws_copy_out_bf16<4>(a, sb, SLB, tid, m0, n0);
+    ws_copy_out_bf16<CITERS, BN>(a, sb, SLB, tid, m0, n0);
     return;
   }
   float* st = (float*)smem;
   if (!loader) {
     const int h = lane >> 5;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int pl = wm * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < TJ; ++j) {
+      const int pl = wm * (32 * TJ) + j * 32 + (lane & 31);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1181,7 +1192,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
   }
   __syncthreads();
   if (stamps && wv == 0) stamps[2] = (long long)__builtin_amdgcn_s_memtime() - t_base;
-  dispatch_act(a.act, [&](auto actc) { ws_copy_out<4, decltype(actc)::value>(a, st, SLD, tid, m0, n0, rpre); });
+  dispatch_act(a.act, [&](auto actc) { ws_copy_out<CITERS, decltype(actc)::value, BN>(a, st, SLD, tid, m0, n0, rpre); });
   if (stamps && wv == 0) {
     stamps[3] = (long long)__builtin_amdgcn_s_memtime() - t_base;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1376,7 +1387,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws256_kernel(const ConvG g)
   }
 }
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // ------------------------------------------------------------------------------------------------
 // v4c: A-STATIONARY wave-specialised kernel for 1x1 convs / token GEMMs with a short K (<= 256) and many channel tiles
@@ -1596,11 +1606,14 @@ static int g_ws2_min_blocks = 257;   // grids that do not fit one block per CU r
 void conv_set_ws2_min_blocks(int v) { g_ws2_min_blocks = v; }
 static int g_reg_epilogue = 1;
 void conv_set_reg_epilogue(int v) { g_reg_epilogue = v; }
+static int g_ws64_max_blocks = 160;   // A/B hook: 128 x 128-tile grids below this take the 128 x 64 tile (0 = never)
+void conv_set_ws64_max_blocks(int v) { g_ws64_max_blocks = v; }
 static int g_prefetch = 1;    // A/B hook (rtd_debug_option "prefetch"): 0 = no next-layer filter prefetch
 void conv_set_prefetch(int v) { g_prefetch = v; }
 template <typename T>
 static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long w_bytes, unsigned y_bytes, unsigned x2_bytes, const ConvWorkspace& ws, hipStream_t s) {
-  if (!ok || ((g_conv_mode == 1 || g_conv_mode == 2) && !k.x2)) return false;     // 5 = single-role LDS-DMA kernels (v3) for A/B
+  if (!ok || ((g_conv_mode == 1 || g_conv_mode == 2) && !k.x2)) return false;
+  static_assert(sizeof(T) == 2 || sizeof(T) == 4, "bf16 / fp32");     // 5 = single-role LDS-DMA kernels (v3) for A/B
   const long long mt = (k.M + 127) / 128, ntn = (k.N + 127) / 128;
   // fp32 GEMMs (query-selection heads) may use a partly empty N tile: N >= 64 still beats the small-tile kernel
   // N >= 64 may use a partly empty N tile (the filter is padded to 128 rows): the N = 64 reduce convs of stage 0 are HBM-bound,
@@ -1615,6 +1628,17 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
   g.x_bytes = (g_glds_drop & 1) ? 0u : (unsigned)x_bytes;
   g.w_bytes = (g_glds_drop & 2) ? 0u : (unsigned)w_bytes;
   g.x2_bytes = x2_bytes;
+  // small grids: 128 x 64 tiles double the blocks (rtd_debug_option "ws64_max_blocks": grids below this many 128 x 128 tiles; conv_mode 10
+  // forces it everywhere for the tests)
+  // (latency profile only: with other batches in flight the idle CUs are taken anyway and the narrower tile stages 1.5x the bytes per
+  // MFMA - measured +1.4 % for one handle, -1 % for three)
+  if ((g_conv_mode == 0 && !k.prefer256 && mt * ntn < g_ws64_max_blocks && k.N > 64) || g_conv_mode == 10) {
+    const long long ntn64 = (k.N + 63) / 64;
+    g.k.ntn = (int)ntn64;
+    g.slab = ws.slab;
+    hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, false, 64>), dim3((unsigned)(mt * ntn64)), dim3(512), 0, s, g);
+    return true;
+  }
   if (k.x2) {
     // dual-input launches exist in the wave-specialised kernel only (every conv_mode): 4 stages on small grids, 2 above
     g.slab = ws.slab;

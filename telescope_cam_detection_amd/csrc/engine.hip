@@ -1528,6 +1528,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "stream_min_tiles") == 0) { conv_set_stream_min_tiles(value); return RTD_OK; }
   if (strcmp(name, "stream_slab") == 0) { conv_set_stream_slab(value); return RTD_OK; }
   if (strcmp(name, "stream2") == 0) { conv_set_stream2(value); return RTD_OK; }
+  if (strcmp(name, "ws64_max_blocks") == 0) { conv_set_ws64_max_blocks(value); return RTD_OK; }
   if (strcmp(name, "stream2_max_n") == 0) { conv_set_stream2_max_n(value); return RTD_OK; }
   if (strcmp(name, "ws256_min_blocks") == 0) { conv_set_ws256_min_blocks(value); return RTD_OK; }
   if (strcmp(name, "profile_twice") == 0) { g_profile_twice = value; return RTD_OK; }

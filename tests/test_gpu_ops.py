@@ -105,7 +105,7 @@ def test_conv_dual(L, dt, case):
     wcat = torch.cat([w1.permute(0, 2, 3, 1).reshape(Cout, -1), w2.reshape(Cout, C2)], dim=1).contiguous().cuda()
     xd, x2d, bd = nhwc(x, tdt), nhwc(x2, tdt), b.cuda()
     from telescope_cam_detection_amd import _capi
-    for out_f32, mode in (((1, 0),) if dt == "f32" else ((0, 0), (1, 0), (0, 3), (0, 9))):
+    for out_f32, mode in (((1, 0), (1, 10)) if dt == "f32" else ((0, 0), (1, 0), (0, 3), (0, 9), (0, 10))):
         if dt == "f32" and B * H * W * ((Cout + 127) // 128) < 512 * 128:
             # fp32 launches need >= 512 tiles for the LDS-DMA kernels: the library must refuse the shape, not fall back
             yd = torch.zeros(B, H, W, Cout, dtype=torch.float32, device="cuda")
@@ -251,7 +251,8 @@ def test_conv(L, dt, case):
     # 3 / 4 = wave-specialised LDS-DMA kernel (4 / 2 stages), 5 = single-role LDS-DMA kernel, 6 = wave-specialised with
     # whole-K-step fragment prefetch, 7 = wave-specialised 256-pixel tile, 8 = A-stationary kernel wherever it is eligible (1x1, K <= 256, no residual),
     # 9 = streaming 1x1 kernel wherever it is eligible (K = 64 / 128, Cout % 64 == 0), whatever the grid size
-    for out_f32, mode in (((1, 0), (1, 1), (1, 2), (1, 3), (1, 6), (1, 7)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (1, 6), (0, 7), (1, 7), (0, 8), (0, 9), (0, 109))):
+    # 10 = the 128 x 64 tile of the wave-specialised kernel (auto below 160 tiles) on every shape the LDS-DMA kernels take
+    for out_f32, mode in (((1, 0), (1, 1), (1, 2), (1, 3), (1, 6), (1, 7), (1, 10)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (1, 6), (0, 7), (1, 7), (0, 8), (0, 9), (0, 109), (0, 10), (1, 10))):
         _capi.debug_option("stream_slab", 0 if mode >= 100 else 1)      # 109 = mode 9 with accumulator-shaped global accesses
         mode %= 100
         _capi.debug_option("conv_mode", mode)
