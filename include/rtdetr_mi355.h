@@ -144,7 +144,8 @@ int64_t rtd_arena_bytes(rtd_handle h);
  *   dec_pf [2], glds_drop [0: timing-only probes, results wrong when set]
  * Plan-build switches, read when an engine builds a plan (set them before rtd_load_weights):
  *   sc_fold [1] projection shortcut folded into the block's last conv | up_fold [1] FPN upsample folded into the CSP's first conv |
- *   c1_fuse [1] stage-0 reduce conv computed inside the previous block's expand conv |
+ *   c1_fuse [1] stage-0 reduce conv computed inside the previous block's expand conv | attn_split [2] bf16 engine: self-attention on
+ *   split-bf16 MFMAs (bit 0 AIFI, bit 1 decoder) |
  *   arena_reuse [1] | stem_fused [0] | dec_fused [1], dec_split [1: 0 fp32 MFMA, 2 bf16 filters], sel_fused [1] | dec_stamps [0] */
 int rtd_debug_option(const char* name, int value);
 

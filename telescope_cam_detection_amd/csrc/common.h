@@ -194,6 +194,7 @@ struct DecLN {
 struct DecArgs {
   int mode;                 // 0 = prologue (enc_bbox head + ref init + next projections), 1 = layer, 2 = last layer (+ class head),
                             // 3 = AIFI prologue (x + pos -> q, K/V fragments), 4 = AIFI encoder layer
+  int attn_split;           // bf16 engine: self-attention on hi/lo bf16 MFMAs with K / V stored as split fragments (0: exact fp32 MFMAs, A/B + tests)
   int split;                // 1: the linear layers run as 3 bf16 MFMAs on hi/lo splits of both operands (bf16 engine), 0: exact fp32 MFMA
   int B, Q, D, heads, S, n_levels, n_points, ffn, C;
   float offset_scale;

@@ -356,8 +356,9 @@ __device__ void self_attention_rows(const DecArgs& a, const float* sQ, int ldq, 
   }
   float m = -INFINITY, l = 0.f;                                 // running max / sum of this lane's query
   f32x4_ O[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // O^T: dims 16 d + 4 q + r of query r16
-  const float* kb = a.kfrag_in + ((size_t)(b * a.heads + head) * tiles) * 512 + lane * 4;
-  const float* vb = a.vfrag_in + ((size_t)(b * a.heads + head) * tiles) * 512 + lane * 4;
+  const int tp = (tiles + 1) & ~1;                              // fragment buffers are strided by an even tile count (the split form stores V per tile PAIR)
+  const float* kb = a.kfrag_in + ((size_t)(b * a.heads + head) * tp) * 512 + lane * 4;
+  const float* vb = a.vfrag_in + ((size_t)(b * a.heads + head) * tp) * 512 + lane * 4;
   f32x4_ kc[2], vc[2], kn[2], vn[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c) { kc[c] = *(const f32x4_*)(kb + c * 256); vc[c] = *(const f32x4_*)(vb + c * 256); }
@@ -398,6 +399,105 @@ __device__ void self_attention_rows(const DecArgs& a, const float* sQ, int ldq, 
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < 2; ++c) { kc[c] = kn[c]; vc[c] = vn[c]; }
+  }
+  const float inv = 1.f / l;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    f32x4_ o = {O[d][0] * inv, O[d][1] * inv, O[d][2] * inv, O[d][3] * inv};
+    *(f32x4_*)(sA + r16 * LDH + head * 32 + 16 * d + 4 * q) = o;
+  }
+}
+
+// The bf16 engine's form: the same transposed scheme on v_mfma_f32_16x16x32_bf16 with hi/lo splits of every operand (x = hi + lo to
+// 2^-17: hi*hi + hi*lo + lo*hi, fp32 accumulate), 12 bf16 MFMAs of 16 cycles per PAIR of key tiles instead of 32 fp32 MFMAs of 32 - the
+// phase is MFMA-issue bound (two waves per SIMD; prefetch depth and tile-level parallelism changed nothing).
+//   S^T_e = K_e Q^T           : one MFMA covers the whole head dim (32); K fragments [hi | lo][lane][8]: key lane & 15, dims 8 (lane >> 4) ..
+//   O^T  += V_pair^T P_pair^T : the 32-deep contraction runs over the pair's keys in the order (tile e, key 4 kq + r) -> position
+//                               8 kq + 4 e + r, which is exactly how a lane's S accumulators of the two tiles are laid out (no shuffle);
+//                               V fragments [d][hi | lo][lane][8] per pair, written half by each tile's producer block.
+__device__ void self_attention_rows_split(const DecArgs& a, const float* sQ, int ldq, float* sA, int LDH, int b, int tiles, int wave, int lane) {
+  const int head = wave;
+  const int r16 = lane & 15, q = lane >> 4;
+  const float scale = rsqrtf(32.f);
+  bf16x8_ qh, ql;                                               // Q[query r16][32 head + 8 q + j] * scale
+  {
+    const f32x4_ q0 = *(const f32x4_*)(sQ + r16 * ldq + head * 32 + 8 * q), q1 = *(const f32x4_*)(sQ + r16 * ldq + head * 32 + 8 * q + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = (j < 4 ? q0[j] : q1[j - 4]) * scale;
+      const bf16 hi = (bf16)x;
+      qh[j] = hi;
+      ql[j] = (bf16)(x - (float)hi);
+    }
+  }
+  float m = -INFINITY, l = 0.f;
+  f32x4_ O[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const int tp = (tiles + 1) & ~1, npairs = tp >> 1;
+  const char* kb = (const char*)a.kfrag_in + ((size_t)(b * a.heads + head) * tp) * 2048 + lane * 16;
+  const char* vb = (const char*)a.vfrag_in + ((size_t)(b * a.heads + head) * tp) * 2048 + lane * 16;
+  bf16x8_ kc[2][2], vc[2][2], kn[2][2], vn[2][2];               // K: [tile of the pair][hi, lo]; V: [d][hi, lo]
+  auto ld = [&](bf16x8_ (&k)[2][2], bf16x8_ (&v)[2][2], int pr) {
+    const int t1 = min(2 * pr + 1, tiles - 1);                  // odd tile count: the second K of the last pair re-reads the last tile (masked)
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl) {
+      k[0][hl] = *(const bf16x8_*)(kb + (size_t)(2 * pr) * 2048 + hl * 1024);
+      k[1][hl] = *(const bf16x8_*)(kb + (size_t)t1 * 2048 + hl * 1024);
+#pragma unroll
+      for (int d = 0; d < 2; ++d) v[d][hl] = *(const bf16x8_*)(vb + (size_t)pr * 4096 + (d * 2 + hl) * 1024);
+    }
+  };
+  ld(kc, vc, 0);
+  for (int pr = 0; pr < npairs; ++pr) {
+    ld(kn, vn, min(pr + 1, npairs - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4_ S[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      S[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[e][1], qh, S[e], 0, 0, 0);
+      S[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[e][0], ql, S[e], 0, 0, 0);
+      S[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[e][0], qh, S[e], 0, 0, 0);
+    }
+    float sv[2][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = 2 * pr + e;
+        sv[e][r] = (t < tiles && t * 16 + 4 * q + r < a.Q) ? S[e][r] : -INFINITY;
+        mx = fmaxf(mx, sv[e][r]);
+      }
+    mx = rows4_max(mx);
+    const float mn = fmaxf(m, mx);
+    const float alpha = __expf(m - mn);
+    bf16x8_ ph, pl;
+    float rs = 0.f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = __expf(sv[e][r] - mn);
+        rs += pv;
+        const bf16 hi = (bf16)pv;
+        ph[4 * e + r] = hi;
+        pl[4 * e + r] = (bf16)(pv - (float)hi);
+      }
+    rs = rows4_sum(rs);
+    l = l * alpha + rs;
+    m = mn;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) O[d][r] *= alpha;
+      O[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc[d][1], ph, O[d], 0, 0, 0);
+      O[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc[d][0], pl, O[d], 0, 0, 0);
+      O[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc[d][0], ph, O[d], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) { kc[e][hl] = kn[e][hl]; vc[e][hl] = vn[e][hl]; }
   }
   const float inv = 1.f / l;
 #pragma unroll
@@ -516,7 +616,8 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
 
   if (has_attn) {
     // ---- self-attention (q in sT, K/V fragments from the previous launch) -> sA ----------------------------
-    self_attention_rows(a, sT, LDQ, sA, LDH, b, tiles, wave, lane);
+    if (SPLIT && a.attn_split) self_attention_rows_split(a, sT, LDQ, sA, LDH, b, tiles, wave, lane);
+    else self_attention_rows(a, sT, LDQ, sA, LDH, b, tiles, wave, lane);
     __syncthreads();
     DEC_STAMP(12);  // self-attention
     // ---- self-attention output projection + residual + LN1 (HF:v2.py:395-405) ---------------------
@@ -668,11 +769,44 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     const int r = e / D, c = e - r * D;
     if (r < nvalid) a.q_out[(row0 + r) * D + c] = sT[r * LDQ + c];
   }
-  {
+  if (SPLIT && a.attn_split) {
+    // split form (self_attention_rows_split): K of this tile as [hi | lo][lane][8] bf16, V into this tile's half of its pair's
+    // [d][hi | lo][lane][8] fragments (8-byte pieces); the last tile of an odd count also zeroes the missing partner's half
+    const int tile = q0 / DR, tp = (tiles + 1) & ~1, pr = tile >> 1, eh = tile & 1;
+    const bool zero_partner = (tile == tiles - 1) && (tiles & 1);
+    for (int e = tid; e < a.heads * 128; e += NT) {              // K: one 16-byte piece per (head, hi/lo, lane)
+      const int h = e >> 7, hl = (e >> 6) & 1, ln = e & 63;
+      const int kr = ln & 15;
+      bf16x8_ o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = kr < nvalid ? sT[kr * LDQ + D + h * 32 + 8 * (ln >> 4) + j] : 0.f;
+        const bf16 hi = (bf16)x;
+        o[j] = hl ? (bf16)(x - (float)hi) : hi;
+      }
+      *(bf16x8_*)((char*)a.kfrag_out + ((size_t)(b * a.heads + h) * tp + tile) * 2048 + hl * 1024 + ln * 16) = o;
+    }
+    typedef __bf16 bf16x4_d __attribute__((ext_vector_type(4)));
+    for (int e = tid; e < a.heads * 256; e += NT) {              // V: one 8-byte piece per (head, d, hi/lo, lane)
+      const int h = e >> 8, d = (e >> 7) & 1, hl = (e >> 6) & 1, ln = e & 63;
+      bf16x4_d o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int vr = 4 * (ln >> 4) + r;
+        const float x = vr < nvalid ? sO[vr * LDO + h * 32 + 16 * d + (ln & 15)] : 0.f;
+        const bf16 hi = (bf16)x;
+        o[r] = hl ? (bf16)(x - (float)hi) : hi;
+      }
+      char* dst = (char*)a.vfrag_out + ((size_t)(b * a.heads + h) * tp + 2 * pr) * 2048 + (d * 2 + hl) * 1024 + ln * 16;
+      *(bf16x4_d*)(dst + eh * 8) = o;
+      if (zero_partner) *(bf16x4_d*)(dst + 8) = bf16x4_d{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    }
+  } else {
     const int tile = q0 / DR;
+    const int tp = (tiles + 1) & ~1;
     for (int e = tid; e < a.heads * 512; e += NT) {
       const int h = e >> 9, rem = e & 511, c = rem >> 8, ln = (rem & 255) >> 2, u = rem & 3;
-      const size_t dst = ((size_t)(b * a.heads + h) * tiles + tile) * 512 + rem;
+      const size_t dst = ((size_t)(b * a.heads + h) * tp + tile) * 512 + rem;
       const int kr = ln & 15;                                   // K: key = lane & 15, dim = 32h + 16c + 4 (lane>>4) + u
       a.kfrag_out[dst] = kr < nvalid ? sT[kr * LDQ + D + h * 32 + 16 * c + 4 * (ln >> 4) + u] : 0.f;
       const int vr = 4 * (ln >> 4) + u;                         // V: key = 4 (lane>>4) + u, dim = 32h + 16c + (lane & 15)

@@ -29,6 +29,10 @@ int g_dec_stamps = 0;  // plan-build switch: record per-phase stamps of decoder 
 int g_dec_split = 1;   // plan-build switch (rtd_debug_option "dec_split"): bf16 engine runs the fused decoder / AIFI linears as bf16 hi/lo splits
 int g_sc_fold = 1;     // plan-build switch (rtd_debug_option "sc_fold"): bf16 plans fold a block's projection shortcut into its last conv (ConvArgs::x2)
 int g_c1_fuse = 1;     // plan-build switch (rtd_debug_option "c1_fuse"): bf16 plans run a stage-0 block's reduce conv inside the previous block's last conv
+// plan-build switch (rtd_debug_option "attn_split"): the bf16 engine's self-attention on hi/lo bf16 MFMAs - bit 0 AIFI, bit 1 decoder.  Default: decoder
+// only (logits agree with the fp32-MFMA attention to 1e-6).  In AIFI the softmax arguments reach tens and the 2^-16 product error becomes 1.7e-4 on the
+// layer output: harmless next to the bf16 conv stack, but that layer stays on fp32 MFMAs (10 us per step)
+int g_attn_split = 2;
 int g_up_fold = 1;     // plan-build switch (rtd_debug_option "up_fold"): bf16 plans read the FPN's upsampled lateral straight from the half-size tensor
 int g_arena_reuse = 1; // plan-build switch (rtd_debug_option "arena_reuse"): backbone stages recycle their activation buffers
 int g_stem_fused = 0;  // plan-build switch (rtd_debug_option "stem_fused"): bf16 engine runs backbone.stem.0 straight from the uint8 frames.
@@ -672,8 +676,9 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     t2 = B.act(P, n, L, 1, d, "aifi_out");
     Tensor qrows = B.act(F32, n, L, 1, d);
     const int tl = (L + 15) / 16;
-    float* kf = (float*)B.alloc((size_t)n * 8 * tl * 512 * 4);
-    float* vf = (float*)B.alloc((size_t)n * 8 * tl * 512 * 4);
+    const int tlp = (tl + 1) & ~1;                              // the kernels stride the fragment buffers by an even tile count
+    float* kf = (float*)B.alloc((size_t)n * 8 * tlp * 512 * 4);
+    float* vf = (float*)B.alloc((size_t)n * 8 * tlp * 512 * 4);
     auto elin = [&](const std::string& name, int N, int K) {
       DecLin Lw{};
       if (!B.dry) {
@@ -684,6 +689,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     };
     DecArgs a0{};
     a0.split = P == BF16 ? g_dec_split : 0;
+    a0.attn_split = g_attn_split & 1;                          // bit 0: AIFI, bit 1: decoder
     a0.B = n; a0.Q = L; a0.D = d; a0.heads = 8; a0.S = 0; a0.n_levels = 3; a0.n_points = 4; a0.ffn = c.enc_ffn; a0.C = 4;
     a0.hs_in = (const float*)t0.p; a0.qpos_in = e->pos_dev;
     a0.q_in = (const float*)qrows.p; a0.q_out = (float*)qrows.p;
@@ -856,8 +862,8 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     const int dtiles = (Q + 15) / 16;
     float* kfrag[2]; float* vfrag[2];
     for (int i = 0; i < 2; ++i) {
-      kfrag[i] = (float*)B.alloc((size_t)n * c.dec_heads * dtiles * 512 * 4);
-      vfrag[i] = (float*)B.alloc((size_t)n * c.dec_heads * dtiles * 512 * 4);
+      kfrag[i] = (float*)B.alloc((size_t)n * c.dec_heads * ((dtiles + 1) & ~1) * 512 * 4);
+      vfrag[i] = (float*)B.alloc((size_t)n * c.dec_heads * ((dtiles + 1) & ~1) * 512 * 4);
     }
     logits = B.act(F32, n, Q, 1, C, "logits");
     auto lin = [&](const std::string& name, int N, int K, int Kuse = 0) {
@@ -875,6 +881,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     };
     DecArgs base{};
     base.split = P == BF16 ? g_dec_split : 0;
+    base.attn_split = (g_attn_split >> 1) & 1;
     base.B = n; base.Q = Q; base.D = dm; base.heads = c.dec_heads; base.S = S; base.n_levels = c.n_levels;
     base.n_points = c.n_points; base.ffn = c.dec_ffn; base.C = C; base.offset_scale = c.offset_scale;
     base.ref8 = ref8; base.ref_unact8 = ref_unact8; base.anchors = e->anchors_dev; base.tk_idx = tk;
@@ -1514,6 +1521,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "maxpool_v1") == 0) { maxpool_set_v1(value); return RTD_OK; }
   if (strcmp(name, "arena_reuse") == 0) { g_arena_reuse = value; return RTD_OK; }
   if (strcmp(name, "up_fold") == 0) { g_up_fold = value; return RTD_OK; }
+  if (strcmp(name, "attn_split") == 0) { g_attn_split = value; return RTD_OK; }
   if (strcmp(name, "c1_fuse") == 0) { g_c1_fuse = value; return RTD_OK; }
   if (strcmp(name, "dec_pf") == 0) { dec_set_pf(value); return RTD_OK; }
   if (strcmp(name, "dec_split") == 0) { g_dec_split = value; return RTD_OK; }
