@@ -34,7 +34,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense)
 HBM_PEAK_GBS = 8000.0
 CANON_GFLOP_PER_FRAME = {"r18": 60.53, "r50": 133.91}  # BASELINE.md §3 @640x640
 
@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--arch", default="r50")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16x3", "bf16", "fp32"])
     ap.add_argument("--streams", type=int, default=3, help="engine handles (batches in flight) per GPU")
     ap.add_argument("--latency-profile", action="store_true", help="A/B: the handles of a multi-handle run use the latency profile too")
     ap.add_argument("--no-graph", action="store_true")
@@ -92,7 +92,7 @@ def main():
     B, H = args.batch, args.size
     w = synth_weights(arch, 0)
     blob = pack_blob(fold_weights(arch, w))
-    prec = _capi.PREC_FP32 if args.precision == "fp32" else _capi.PREC_BF16
+    prec = _capi.precision_code(args.precision)
     S = max(1, args.streams)
     # several handles per GPU run the throughput profile (rtd_config.profile: 256-pixel conv tiles); the one-batch-in-flight
     # figure, the kernel profile / roofline and the latency line come from a latency-profile handle, which is also what

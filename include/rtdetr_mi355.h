@@ -36,7 +36,10 @@ enum {
   RTD_E_STATE = 5    /* call order (e.g. infer before load_weights) */
 };
 
-enum { RTD_PREC_BF16 = 0, RTD_PREC_FP32 = 1 };
+/* RTD_PREC_BF16X3: every trunk activation and filter is a hi + lo pair of bf16 (x = hi + lo to 2^-18) and every contraction runs as
+ * three bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate): fp32-grade results at bf16 MFMA rates - the engine that meets the
+ * reference tolerance (1e-3 on scores, 1e-2 px on boxes against fp32 eager, src/rtdetr_detector.py:256-257) at >= 1000 frames/s. */
+enum { RTD_PREC_BF16 = 0, RTD_PREC_FP32 = 1, RTD_PREC_BF16X3 = 2 };
 enum { RTD_LAYER_BASIC = 0, RTD_LAYER_BOTTLENECK = 1 };
 
 /* Constructor arguments of RTDETRDetector (src/rtdetr_detector.py:29-58) that matter to the device
@@ -158,7 +161,8 @@ int rtd_debug_option(const char* name, int value);
 int rtd_crop_resize_batch(int32_t n, const uint8_t* const* frames_dev, const int32_t* frame_hw, const int32_t* rects,
                           int32_t out_size, const float* mean3, const float* std3, float* out_dev, void* stream);
 
-/* ---- kernel-level test entry points (device pointers; dtype 0 = bf16, 1 = fp32) --------------- */
+/* ---- kernel-level test entry points (device pointers; dtype 0 = bf16, 1 = fp32, 4 = BF16X2: hi/lo bf16 pairs in 32-channel groups
+ * [32 hi | 32 lo], 4 bytes per channel - the storage of RTD_PREC_BF16X3, rtd_op_conv / rtd_op_conv_dual only) --------------- */
 int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* bias, const void* res,
                 void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                 int act, int res_mode, int out_f32);

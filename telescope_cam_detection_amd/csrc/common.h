@@ -8,7 +8,13 @@
 
 namespace rtd {
 
-enum DType : int { BF16 = 0, F32 = 1, U8 = 2, I32 = 3 };
+// BF16X2 ("split"): every value is carried as two bf16, x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <= 2^-18 |x|).
+// Storage: a pixel's channels in groups of 32, each group 128 bytes = [32 x hi | 32 x lo]; 4 bytes per channel, so `ld`, `c` and
+// slice_c() count real channels exactly as for F32 (slices on multiples of 32 channels).  A K-step of the LDS-DMA conv kernels (128
+// bytes per pixel row) is then one channel group, and hi*hi + hi*lo + lo*hi runs as three bf16 MFMAs on the same staged bytes
+// (rtd_config.precision = RTD_PREC_BF16X3: fp32-grade products at 3/16 of the fp32 MFMA cost).
+enum DType : int { BF16 = 0, F32 = 1, U8 = 2, I32 = 3, BF16X2 = 4 };
+constexpr int SPLIT_GROUP = 32;   // channels per [hi | lo] group of a BF16X2 tensor
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GELU = 3 };
 enum ResMode : int { RES_NONE = 0, RES_PRE = 1, RES_POST = 2 };
 
@@ -29,7 +35,7 @@ struct Tensor {
   int64_t ld = 0;
   int64_t bstride = 0;
   int64_t pixels() const { return (int64_t)n * h * w; }
-  Tensor slice_c(int c0, int cn) const {
+  Tensor slice_c(int c0, int cn) const {   // BF16X2: c0 must be a multiple of SPLIT_GROUP (group g lives at byte 128 g)
     Tensor t = *this;
     t.p = (char*)p + (size_t)c0 * dtype_size(dt);
     t.c = cn;
@@ -104,6 +110,10 @@ void launch_conv(const ConvArgs& a, hipStream_t s);
 bool conv_dual_supported(const ConvArgs& a);
 bool conv_next_supported(const ConvArgs& a);   // can `a` (shapes for ONE image) carry a fused following 1x1 conv (ConvArgs::next_*)?   // can this build's kernels run `a` with its second input? (the plan builder asks before fusing)
 int conv_kpad(int K);                 // padded filter row length the kernels expect
+int conv_kpad_split(int K);           // BF16X2 filter row length in bf16 elements (K real taps x channels)
+bool conv_split_supported(const ConvArgs& a);   // BF16X2 input: does the split kernel take this launch?
+void conv_set_split_ws2_min_blocks(int v);
+void conv_set_split_ws64_max_blocks(int v);
 int conv_npad(int N);
 void conv_set_force_v1(int v);      // A/B hook: 1 = never take the large-tile (v2) path
 void conv_set_glds_min_blocks(int v);
@@ -256,8 +266,33 @@ void launch_crop_resize(const CropBatch& cb, int n, int out_size, const float me
 
 void launch_f32_to(const float* src, void* dst, int dt, int64_t n, hipStream_t s);
 void launch_to_f32(const void* src, int dt, float* dst, int64_t n, hipStream_t s);
+// dense [rows][C] fp32 <-> BF16X2 rows (C % 32 == 0); `ld*` in channels
+void launch_f32_to_split(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int C, hipStream_t s);
+void launch_split_to_f32(const void* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int C, hipStream_t s);
 
 #if defined(__HIPCC__)
+// ---- BF16X2 helpers: element offset (in bf16 units, from the tensor base) of the hi half of channel c of a pixel whose first
+// channel sits at channel offset `pix_off` (= pixel index * ld); the lo half is SPLIT_GROUP elements further
+__device__ __forceinline__ long long split_off(long long pix_off, int c) { return 2 * pix_off + ((c >> 5) << 6) + (c & 31); }
+__device__ __forceinline__ void split2(float v, bf16& hi, bf16& lo) {
+  hi = (bf16)v;
+  lo = (bf16)(v - (float)hi);
+}
+// 8 consecutive channels (c % 8 == 0) of a BF16X2 pixel <-> fp32
+__device__ __forceinline__ void split_load8(const bf16* base, long long pix_off, int c, float (&v)[8]) {
+  const bf16* q = base + split_off(pix_off, c);
+  const bf16x8 h = *(const bf16x8*)q, l = *(const bf16x8*)(q + SPLIT_GROUP);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = (float)h[k] + (float)l[k];
+}
+__device__ __forceinline__ void split_store8(bf16* base, long long pix_off, int c, const float (&v)[8]) {
+  bf16* q = base + split_off(pix_off, c);
+  bf16x8 h, l;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { bf16 a, b; split2(v[k], a, b); h[k] = a; l[k] = b; }
+  *(bf16x8*)q = h;
+  *(bf16x8*)(q + SPLIT_GROUP) = l;
+}
 // Reductions over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} (the 16-lane rows of a wave: an MFMA 16x16 accumulator's row groups)
 // on gfx950's row-swap VALU ops instead of two ds_bpermute round trips each: v_permlane16_swap exchanges odd rows of its first
 // operand with even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the second; fed the

@@ -52,6 +52,10 @@ struct ConvK {
   void* next_y;
   long long next_ldy, next_y_bstride;
   int next_kpad, next_act;
+  // BF16X2 operands (common.h): `split` = x / x2 / w are [32 hi | 32 lo] grouped bf16 and Cin, ldx, x_bstride, Kreal, Kpad, k2_start,
+  // ldx2, x2_bstride count bf16 ELEMENTS (twice the channels); y_split / res_split = the output / residual is a BF16X2 tensor, its
+  // ldy / y_bstride (ldr / r_bstride) count channels as for fp32 and addresses go through split_off()
+  int split = 0, y_split = 0, res_split = 0;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -298,7 +302,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] += rv[q];
         }
-        if (a.y_f32) {
+        if (a.y_split) {
+          bf16x4 oh, ol;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { bf16 hi, lo; split2(v[q], hi, lo); oh[q] = hi; ol[q] = lo; }
+          bf16* yb = (bf16*)a.y + split_off(yoff, c);
+          *(bf16x4*)yb = oh;
+          *(bf16x4*)(yb + SPLIT_GROUP) = ol;
+        } else if (a.y_f32) {
           f32x4 o = {v[0], v[1], v[2], v[3]};
           *(f32x4*)((float*)a.y + yoff + c) = o;
         } else {
@@ -823,6 +834,88 @@ __device__ __forceinline__ void ws_copy_out(const ConvK& a, const float* st, int
 }
 
 
+// BF16X2 output, tile already final in LDS as split rows ([pixel][2 BN bf16]: the tile's BN / 32 channel groups, each [32 hi | 32 lo],
+// exactly the bytes of the pixel's slice in global memory): pure 16-byte moves, 4 BN bytes per pixel row.
+template <int BN>
+__device__ __forceinline__ void ws_copy_out_split_rows(const ConvK& a, const bf16* sb, int SLB, int tid, int m0, int n0) {
+  constexpr int CH = 2 * BN / 8, RSTEP = 512 / CH, ITERS = 128 / RSTEP;
+  const int ch = tid % CH;
+  if (n0 + (ch >> 3) * SPLIT_GROUP >= a.N) return;               // whole 32-channel groups (N % 32 == 0)
+  int m = m0 + tid / CH;
+  const int b = m / a.OHW;
+  int p = m - b * a.OHW;
+  long long yoff = 2 * ((long long)b * a.y_bstride + (long long)p * a.ldy + n0) + ch * 8;   // bf16 elements
+  const bf16* srow = sb + (tid / CH) * SLB + ch * 8;
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    if (m < a.M) *(bf16x8*)((bf16*)a.y + yoff) = *(const bf16x8*)srow;
+    m += RSTEP; p += RSTEP; yoff += 2 * RSTEP * a.ldy; srow += RSTEP * SLB;
+    while (p >= a.OHW) { p -= a.OHW; yoff += 2 * (a.y_bstride - (long long)a.OHW * a.ldy); }
+  }
+}
+
+// Copy-out of the split kernels' fp32 staging tile: bias (+ residual: BF16X2 or fp32) -> activation -> BF16X2 or fp32 output, 8 channels
+// per thread and iteration.  ldy / ldr count channels for either type (ConvK::y_split).
+template <int ITERS, int ACT, int BN>
+__device__ __forceinline__ void ws_copy_out_sp(const ConvK& a, const float* st, int SLD, int tid, int m0, int n0) {
+  constexpr int CH8 = BN / 8, RSTEP = 512 / CH8;
+  const int c8 = tid % CH8;
+  const int c = n0 + c8 * 8;
+  if (c >= a.N) return;
+  const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
+  int m = m0 + tid / CH8;
+  const int b = m / a.OHW;
+  int p = m - b * a.OHW;
+  long long ypix = (long long)b * a.y_bstride + (long long)p * a.ldy;
+  long long rpix = (long long)b * a.r_bstride + (long long)p * a.ldr;
+  const float* srow = st + (tid / CH8) * SLD + c8 * 8;
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    if (m < a.M) {
+      const f32x4 s0 = *(const f32x4*)(srow), s1 = *(const f32x4*)(srow + 4);
+      float v[8] = {s0[0] + b0[0], s0[1] + b0[1], s0[2] + b0[2], s0[3] + b0[3],
+                    s1[0] + b1[0], s1[1] + b1[1], s1[2] + b1[2], s1[3] + b1[3]};
+      float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (a.res_mode != RES_NONE) {
+        if (a.res_split) {
+          split_load8((const bf16*)a.res, rpix, c, rv);
+        } else {
+          const f32x4 t0 = *(const f32x4*)((const float*)a.res + rpix + c), t1 = *(const f32x4*)((const float*)a.res + rpix + c + 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { rv[q] = t0[q]; rv[4 + q] = t1[q]; }
+        }
+      }
+      if (a.res_mode == RES_PRE) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = act_c<ACT>(v[q]);
+      if (a.res_mode == RES_POST) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+      }
+      if (a.y_split) {
+        split_store8((bf16*)a.y, ypix, c, v);
+      } else {
+        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        *(f32x4*)((float*)a.y + ypix + c) = o0;
+        *(f32x4*)((float*)a.y + ypix + c + 4) = o1;
+      }
+    }
+    m += RSTEP;
+    p += RSTEP;
+    ypix += RSTEP * a.ldy;
+    rpix += RSTEP * a.ldr;
+    srow += RSTEP * SLD;
+    while (p >= a.OHW) {
+      p -= a.OHW;
+      ypix += a.y_bstride - (long long)a.OHW * a.ldy;
+      rpix += a.r_bstride - (long long)a.OHW * a.ldr;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // v4: wave-specialised LDS-DMA kernel.  Same tile / swizzle / epilogue as v3, but 8 waves per block with
 // fixed roles: waves 0-3 only read fragments and issue MFMAs (one per SIMD, 64x64 outputs each), waves 4-7
@@ -840,11 +933,17 @@ __device__ __forceinline__ void ws_copy_out(const ConvK& a, const float* st, int
 // BN = 64: a 128 pixel x 64 channel tile for grids that leave most CUs idle with 128 x 128 tiles (stage 3 / PAN at batch 8, nearly
 // everything at batch 1): twice the blocks, each MFMA wave owns 32 pixels x 64 channels (one pixel tile, two channel tiles), the
 // loaders stage 24 KiB per K-step.  Same K order per output, so a layer's results do not depend on which tile width ran it.
-template <typename T, int STAGES, bool DEEP = false, int BN = 128>
+// SPLIT (T = bf16): the operands are BF16X2 tensors.  To the loader they are bf16 tensors of twice the channels - a K-step's 128 bytes
+// per row are one channel group [32 hi | 32 lo] of the pixel / the filter row, same DMA, same swizzle, same LDS image - and the MFMA
+// waves combine the four 16-deep fragments of a K-step as hi*hi + hi*lo + lo*hi (6 MFMAs per accumulator tile and K-step instead of 4;
+// the dropped lo*lo is 2^-18 relative).  A K-step stages the same bytes for 1.5x the MFMAs of the bf16 kernel and covers 32 real
+// channels instead of 64.  The epilogue writes BF16X2 (or fp32) rows.
+template <typename T, int STAGES, bool DEEP = false, int BN = 128, bool SPLIT = false>
 __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kernel(const ConvG g) {
   const ConvK& a = g.k;
   constexpr int BM = 128;
   static_assert(BN == 128 || (BN == 64 && !DEEP), "tile widths");
+  static_assert(!SPLIT || (sizeof(T) == 2 && !DEEP), "split operands are bf16 pairs");
   constexpr int TJ = BN == 128 ? 2 : 1;          // pixel tiles (32 rows) per MFMA wave; channel tiles per wave: always 2
   constexpr int NBI = BN / 32;                    // 32-row filter pieces per loader wave and K-step
   constexpr int PPT = 4 + NBI;                    // LDS-DMA pieces per loader wave and K-step (counted waits)
@@ -901,7 +1000,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
   const int c8 = tid % CH8;
   const int c = n0 + c8 * 8;
   bf16x8 rpre[4];
-  if (a.res_mode != RES_NONE && !a.res_f32 && c < a.N) {
+  if (!SPLIT && a.res_mode != RES_NONE && !a.res_f32 && c < a.N) {
     int m = m0 + tid / CH8;
     const int b = m / a.OHW;
     int p = m - b * a.OHW;
@@ -1061,6 +1160,32 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
       if (ks + 1 >= nk) break;
       step(fx1, fw1, fx0, fw0, ks + 1);
     }
+  } else if constexpr (SPLIT) {
+    // ---- MFMA role, BF16X2 operands: 16-deep fragment kk of a K-step = channels 16 (kk & 1) .. +15 of the group, hi (kk < 2) or lo ----
+    int foff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 128 + (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
+    for (int ks = 0; ks < nk; ++ks) {
+      __builtin_amdgcn_s_barrier();
+      const char* sa = smem + (ks % STAGES) * STAGE + wm * (32 * TJ) * 128;
+      const char* sb = smem + (ks % STAGES) * STAGE + (BM + wn * 64) * 128;
+#pragma unroll
+      for (int sh = 0; sh < 2; ++sh) {
+        Frag xh[TJ], xl[TJ], wh[2], wl[2];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) { xh[j] = *(const Frag*)(sa + j * 4096 + foff[sh]); xl[j] = *(const Frag*)(sa + j * 4096 + foff[sh + 2]); }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { wh[i] = *(const Frag*)(sb + i * 4096 + foff[sh]); wl[i] = *(const Frag*)(sb + i * 4096 + foff[sh + 2]); }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) {
+            Mma<T>::run(wh[i], xh[j], acc[i][j]);
+            Mma<T>::run(wh[i], xl[j], acc[i][j]);
+            Mma<T>::run(wl[i], xh[j], acc[i][j]);
+          }
+      }
+    }
   } else {
     // ---- MFMA role ---------------------------------------------------------------------------------
     int foff[4];
@@ -1146,6 +1271,56 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
     __syncthreads();                               // the ticket word in smem is dead before staging overwrites it
   }
 
+  if constexpr (SPLIT) {
+    if (a.y_split && a.res_mode == RES_NONE) {
+      // bias + activation + hi/lo split on the accumulators, the tile's BF16X2 rows through LDS, plain copy-out
+      constexpr int SLB = 2 * BN + 8;
+      bf16* sb = (bf16*)smem;
+      if (!loader) {
+        const int h = lane >> 5;
+        dispatch_act(a.act, [&](auto actc) {
+          constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 bv = *(const f32x4*)(a.bias + n0 + wn * 64 + i * 32 + 8 * q + 4 * h);
+#pragma unroll
+              for (int j = 0; j < TJ; ++j) {
+                const int pl = wm * (32 * TJ) + j * 32 + (lane & 31);
+                bf16x4 oh, ol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bf16 hi, lo; split2(act_c<ACT>(acc[i][j][4 * q + e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
+                bf16* d = sb + pl * SLB + (wn * 2 + i) * 64 + 8 * q + 4 * h;
+                *(bf16x4*)d = oh;
+                *(bf16x4*)(d + SPLIT_GROUP) = ol;
+              }
+            }
+        });
+      }
+      __syncthreads();
+      ws_copy_out_split_rows<BN>(a, sb, SLB, tid, m0, n0);
+      return;
+    }
+    float* st = (float*)smem;
+    if (!loader) {
+      const int h = lane >> 5;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int pl = wm * (32 * TJ) + j * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            *(f32x4*)(&st[pl * SLD + wn * 64 + i * 32 + 8 * q + 4 * h]) = v;
+          }
+      }
+    }
+    __syncthreads();
+    dispatch_act(a.act, [&](auto actc) { ws_copy_out_sp<CITERS, decltype(actc)::value, BN>(a, st, SLD, tid, m0, n0); });
+    return;
+  }
   if (g_reg_epilogue_ok(a) && g.splitk == 1) {
     // no residual, bf16 output: bias + activation on the accumulators, bf16 rows through LDS (half the staging bytes), then a
     // plain copy-out - the fp32 staging + per-element epilogue was ~2 us of every launch
@@ -2432,6 +2607,11 @@ bool conv_dual_supported(const ConvArgs& a) {
   if (a.x_up2 && !(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0)) return false;
   const int OH = (x.h * up + 2 * a.pad - a.KH) / a.stride + 1, OW = (x.w * up + 2 * a.pad - a.KW) / a.stride + 1;
   if (x2.n != x.n || x2.h != OH || x2.w != OW) return false;
+  if (x.dt == BF16X2) {                                           // the split kernel takes every grid size
+    const long long xb = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * 4;
+    const long long x2b = ((long long)(x2.n - 1) * x2.bstride + ((long long)x2.h * x2.w - 1) * x2.ld + x2.c) * 4;
+    return conv_split_supported(a) && xb < (1ll << 31) && x2b < (1ll << 31);
+  }
   const int es = (int)dtype_size(x.dt), bk = 128 / es, epc = 16 / es;
   if ((a.KH * a.KW * x.c) % bk || x2.c % bk || x.c % bk || x2.ld % epc || ((uintptr_t)x2.p & 15)) return false;
   if (!(y.c % 8 == 0 && y.ld % 8 == 0 && ((uintptr_t)y.p & 15) == 0)) return false;                       // v2_ok
@@ -2461,11 +2641,96 @@ bool conv_next_supported(const ConvArgs& a) {
   return ntiles * (y.c / 64) >= g_stream_min_tiles;
 }
 
+// BF16X2 operands: the wave-specialised LDS-DMA kernel's SPLIT instantiation is the one kernel of this precision (conv_igemm_ws_kernel).
+// Shapes: Cin (and C2) multiples of 32 - one channel group per K-step; output BF16X2 (N % 32 == 0) or fp32; residual BF16X2 or fp32.
+int conv_kpad_split(int K) { return 2 * ((K + SPLIT_GROUP - 1) / SPLIT_GROUP * SPLIT_GROUP); }   // bf16 elements of a filter row
+static int g_split_ws2_min_blocks = 257;   // A/B hook (rtd_debug_option "split_ws2_min_blocks")
+void conv_set_split_ws2_min_blocks(int v) { g_split_ws2_min_blocks = v; }
+static int g_split_ws64_max_blocks = 160;  // A/B hook (rtd_debug_option "split_ws64_max_blocks")
+void conv_set_split_ws64_max_blocks(int v) { g_split_ws64_max_blocks = v; }
+bool conv_split_supported(const ConvArgs& a) {
+  const Tensor& x = a.x;
+  const Tensor& y = a.y;
+  if (x.dt != BF16X2 || !(y.dt == BF16X2 || y.dt == F32)) return false;
+  if (x.c % SPLIT_GROUP || x.ld % SPLIT_GROUP || ((uintptr_t)x.p & 15) || ((uintptr_t)a.w & 15)) return false;
+  if (a.x2.p && (a.x2.dt != BF16X2 || a.x2.c % SPLIT_GROUP || a.x2.ld % SPLIT_GROUP || ((uintptr_t)a.x2.p & 15))) return false;
+  if (a.x_up2 && !(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.x2.p)) return false;
+  if (y.dt == BF16X2 && (y.c % SPLIT_GROUP || y.ld % SPLIT_GROUP)) return false;
+  if (y.c % 8 || y.ld % 4 || ((uintptr_t)y.p & 15)) return false;
+  if (a.res_mode != RES_NONE) {
+    const Tensor& r = a.res;
+    if (!(r.dt == BF16X2 || r.dt == F32) || !r.p || ((uintptr_t)r.p & 15) || r.ld % 4) return false;
+    if (r.dt == BF16X2 && r.ld % SPLIT_GROUP) return false;
+  }
+  return a.next_y.p == nullptr;
+}
+static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
+  const Tensor& x = a.x;
+  const Tensor& y = a.y;
+  RTD_CHECK(conv_split_supported(a), 1, "conv (bf16x3): shape / layout not supported by the split kernel (channels % 32, 16-byte alignment)");
+  const int up = a.x_up2 ? 2 : 1;
+  const int OH = (x.h * up + 2 * a.pad - a.KH) / a.stride + 1;
+  const int OW = (x.w * up + 2 * a.pad - a.KW) / a.stride + 1;
+  RTD_CHECK(OH == y.h && OW == y.w && x.n == y.n, 1, "conv: output shape mismatch");
+  const bool dual = a.x2.p != nullptr;
+  if (dual) RTD_CHECK(a.x2.n == x.n && a.x2.h == OH && a.x2.w == OW, 1, "conv: second input shape");
+  const int K = a.KH * a.KW * x.c + (dual ? a.x2.c : 0);
+  RTD_CHECK(a.Kpad == conv_kpad_split(K) && a.Npad >= y.c && a.Npad % 128 == 0, 1, "conv: split filter padding");
+  RTD_CHECK((long long)x.n * OH * OW < (1ll << 31), 1, "conv: M overflow");
+  ConvG g;
+  ConvK& k = g.k;
+  k.x = x.p; k.w = a.w; k.bias = a.bias; k.y = y.p;
+  k.res = a.res_mode != RES_NONE ? a.res.p : nullptr;
+  k.M = x.n * OH * OW; k.H = x.h * up; k.W = x.w * up;
+  k.Cin = 2 * x.c; k.ldx = 2 * x.ld; k.x_bstride = 2 * x.bstride;                    // bf16 elements
+  k.x_up2 = a.x_up2;
+  k.next_w = nullptr; k.next_bias = nullptr; k.next_y = nullptr; k.next_ldy = 0; k.next_y_bstride = 0; k.next_kpad = 0; k.next_act = 0;
+  k.OH = OH; k.OW = OW; k.OHW = OH * OW;
+  k.N = y.c; k.Kreal = 2 * K; k.Kpad = a.Kpad;
+  k.KH = a.KH; k.KW = a.KW; k.stride = a.stride; k.pad = a.pad;
+  k.ldy = y.ld; k.y_bstride = y.bstride;                                            // channels (fp32 or BF16X2 alike)
+  k.ldr = 0; k.r_bstride = 0; k.res_f32 = 0;
+  if (a.res_mode != RES_NONE) {
+    RTD_CHECK(a.res.n == y.n && a.res.h == y.h && a.res.w == y.w && a.res.c == y.c, 1, "conv: residual shape");
+    k.ldr = a.res.ld; k.r_bstride = a.res.bstride; k.res_f32 = a.res.dt == F32;
+  }
+  k.act = a.act; k.res_mode = a.res_mode; k.y_f32 = y.dt == F32;
+  k.split = 1; k.y_split = y.dt == BF16X2; k.res_split = a.res_mode != RES_NONE && a.res.dt == BF16X2;
+  k.x2 = nullptr; k.ldx2 = 0; k.x2_bstride = 0; k.k2_start = 0;
+  long long x2_bytes = 0;
+  if (dual) {
+    k.x2 = a.x2.p; k.ldx2 = 2 * a.x2.ld; k.x2_bstride = 2 * a.x2.bstride; k.k2_start = 2 * a.KH * a.KW * x.c;
+    x2_bytes = ((long long)(a.x2.n - 1) * a.x2.bstride + ((long long)a.x2.h * a.x2.w - 1) * a.x2.ld + a.x2.c) * 4;
+  }
+  k.reg_epi = 1;
+  k.prefer256 = 0;
+  k.pf = g_prefetch ? a.pf : nullptr;
+  k.pf_bytes = (g_prefetch && a.pf && a.pf_bytes < (1ull << 31)) ? (unsigned)a.pf_bytes : 0u;
+  const long long x_bytes = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * 4;
+  const long long w_bytes = (long long)a.Npad * a.Kpad * 2;
+  RTD_CHECK(x_bytes < (1ll << 31) && x2_bytes < (1ll << 31) && w_bytes < (1ll << 31), 1, "conv (bf16x3): operand larger than a buffer descriptor (2 GiB)");
+  g.probe = 0; g.splitk = 1; g.slab = nullptr; g.cnt = nullptr; g.y_bytes = 0;
+  g.x_bytes = (unsigned)x_bytes; g.w_bytes = (unsigned)w_bytes; g.x2_bytes = (unsigned)x2_bytes;
+  const long long mt = (k.M + 127) / 128, ntn = (k.N + 127) / 128, ntn64 = (k.N + 63) / 64;
+  if (k.N <= 64 || (mt * ntn < g_split_ws64_max_blocks && ntn64 > ntn)) {
+    k.ntn = (int)ntn64;
+    hipLaunchKernelGGL((conv_igemm_ws_kernel<bf16, 4, false, 64, true>), dim3((unsigned)(mt * ntn64)), dim3(512), 0, s, g);
+  } else {
+    k.ntn = (int)ntn;
+    if (mt * ntn < g_split_ws2_min_blocks) hipLaunchKernelGGL((conv_igemm_ws_kernel<bf16, 4, false, 128, true>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((conv_igemm_ws_kernel<bf16, 2, false, 128, true>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
 void launch_conv(const ConvArgs& a, hipStream_t s) {
   const Tensor& x = a.x;
   const Tensor& y = a.y;
+  if (x.dt == BF16X2) { launch_conv_split(a, s); return; }
   RTD_CHECK(x.dt == BF16 || x.dt == F32, 1, "conv: input dtype");
-  RTD_CHECK(y.dt == BF16 || y.dt == F32, 1, "conv: output dtype");
+  RTD_CHECK(y.dt == BF16 || y.dt == F32 || (y.dt == BF16X2 && x.dt == F32), 1, "conv: output dtype");
+  if (y.dt == BF16X2) RTD_CHECK(y.c % SPLIT_GROUP == 0 && y.ld % SPLIT_GROUP == 0 && a.res_mode == RES_NONE && !a.x2.p && !a.next_y.p && ((uintptr_t)y.p & 15) == 0, 1,
+                                "conv: fp32 -> BF16X2 output needs 32-channel groups and no residual / second input");
   const int epc = x.dt == BF16 ? 8 : 4;
   const int up = a.x_up2 ? 2 : 1;
   if (a.x_up2) RTD_CHECK(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.x2.p, 1, "conv: x_up2 needs a 1x1 conv with a second input");
@@ -2501,6 +2766,7 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     k.ldr = a.res.ld; k.r_bstride = a.res.bstride; k.res_f32 = a.res.dt == F32;
   }
   k.act = a.act; k.res_mode = a.res_mode; k.y_f32 = y.dt == F32;
+  k.y_split = y.dt == BF16X2;
   k.x2 = nullptr; k.ldx2 = 0; k.x2_bstride = 0; k.k2_start = 0;
   long long x2_bytes = 0;
   if (dual) {
@@ -2517,6 +2783,11 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
   bool v2_ok = (x.c % bk2 == 0) && (y.c % 8 == 0) && (y.ld % 8 == 0) && (((uintptr_t)y.p & 15) == 0);
   if (a.res_mode != RES_NONE) v2_ok = v2_ok && (a.res.ld % 8 == 0) && (((uintptr_t)a.res.p & 15) == 0);
   bool done = false;
+  if (k.y_split) {                        // fp32 input, BF16X2 output (the split engine's stem.0): the register-staged kernel's epilogue writes it
+    dispatch<float>(k, smallc, s);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   {
     const long long es = (long long)dtype_size(x.dt);
     const long long x_bytes = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * es;

@@ -166,9 +166,42 @@ const HostTensor& host_tensor(rtd_engine* e, const std::string& name) {
   return it->second;
 }
 
+// host [Npad][Kcols] fp32 (zero padded) -> device filter in dt: fp32 as is, bf16 rounded, BF16X2 as [32 hi | 32 lo] groups along K
+// (Kcols % 32 == 0: a row has 2 * Kcols bf16 elements, the layout of an activation pixel with Kcols channels)
+static const char* dt_tag(int dt) { return dt == BF16 ? "#bf16" : (dt == BF16X2 ? "#bf16x2" : "#f32"); }
+static void* upload_filter(rtd_engine* e, const std::vector<float>& pad, int Npad, int Kcols, int dt) {
+  float* tmp = nullptr;
+  void* out = nullptr;
+  HIP_CHECK(hipMalloc((void**)&tmp, pad.size() * 4));
+  hipError_t er = hipMemcpy(tmp, pad.data(), pad.size() * 4, hipMemcpyHostToDevice);
+  try {
+    if (er == hipSuccess) {
+      if (dt == F32) {
+        out = tmp;
+        e->allocs.push_back(tmp);
+        tmp = nullptr;
+      } else if (dt == BF16X2) {
+        out = e->dmalloc(pad.size() * 4);
+        launch_f32_to_split(tmp, Kcols, out, Kcols, Npad, Kcols, e->stream);
+        er = hipStreamSynchronize(e->stream);
+      } else {
+        out = e->dmalloc(pad.size() * 2);
+        launch_f32_to(tmp, out, BF16, (int64_t)pad.size(), e->stream);
+        er = hipStreamSynchronize(e->stream);
+      }
+    }
+  } catch (...) {
+    if (tmp) (void)hipFree(tmp);
+    throw;
+  }
+  if (tmp) (void)hipFree(tmp);
+  HIP_CHECK(er);
+  return out;
+}
+
 // filter [N][K] fp32 -> device [Npad][Kpad] in dt (zero padded), bias -> fp32 [Npad]
 DevWeight get_weight(rtd_engine* e, const std::string& name, int dt, int N, int K) {
-  const std::string key = name + (dt == BF16 ? "#bf16" : "#f32");
+  const std::string key = name + dt_tag(dt);
   auto it = e->wcache.find(key);
   if (it != e->wcache.end()) return it->second;
   const HostTensor& w = host_tensor(e, name + ".w");
@@ -176,25 +209,11 @@ DevWeight get_weight(rtd_engine* e, const std::string& name, int dt, int N, int 
   RTD_CHECK(!w.shape.empty() && w.shape[0] == N && w.numel() == (int64_t)N * K, RTD_E_WEIGHTS, "weight shape mismatch: " + name);
   RTD_CHECK(b.numel() == N, RTD_E_WEIGHTS, "bias shape mismatch: " + name);
   DevWeight d;
-  d.N = N; d.K = K; d.Kpad = conv_kpad(K); d.Npad = conv_npad(N); d.dt = dt;
-  std::vector<float> pad((size_t)d.Npad * d.Kpad, 0.f);
-  for (int r = 0; r < N; ++r) memcpy(&pad[(size_t)r * d.Kpad], w.data + (size_t)r * K, (size_t)K * 4);
-  float* tmp = nullptr;
-  HIP_CHECK(hipMalloc((void**)&tmp, pad.size() * 4));
-  hipError_t er = hipMemcpy(tmp, pad.data(), pad.size() * 4, hipMemcpyHostToDevice);
-  if (er == hipSuccess) {
-    if (dt == F32) {
-      d.w = tmp;
-      e->allocs.push_back(tmp);
-      tmp = nullptr;
-    } else {
-      d.w = e->dmalloc(pad.size() * 2);
-      launch_f32_to(tmp, d.w, BF16, (int64_t)pad.size(), e->stream);
-      er = hipStreamSynchronize(e->stream);
-    }
-  }
-  if (tmp) (void)hipFree(tmp);
-  HIP_CHECK(er);
+  d.N = N; d.K = K; d.Kpad = dt == BF16X2 ? conv_kpad_split(K) : conv_kpad(K); d.Npad = conv_npad(N); d.dt = dt;
+  const int kcols = dt == BF16X2 ? d.Kpad / 2 : d.Kpad;
+  std::vector<float> pad((size_t)d.Npad * kcols, 0.f);
+  for (int r = 0; r < N; ++r) memcpy(&pad[(size_t)r * kcols], w.data + (size_t)r * K, (size_t)K * 4);
+  d.w = upload_filter(e, pad, d.Npad, kcols, dt);
   std::vector<float> bp(d.Npad, 0.f);
   memcpy(bp.data(), b.data, (size_t)N * 4);
   d.bias = (float*)e->dmalloc(bp.size() * 4);
@@ -206,7 +225,7 @@ DevWeight get_weight(rtd_engine* e, const std::string& name, int dt, int N, int 
 // two filters over the same output channels, concatenated along K: [N][K1 | K2] -> device [Npad][Kpad], bias = b1 + b2
 // (a block's last conv with its projection shortcut folded in, ConvArgs::x2)
 DevWeight get_weight_cat(rtd_engine* e, const std::string& n1, const std::string& n2, int dt, int N, int K1, int K2) {
-  const std::string key = n1 + "+" + n2 + (dt == BF16 ? "#bf16" : "#f32");
+  const std::string key = n1 + "+" + n2 + dt_tag(dt);
   auto it = e->wcache.find(key);
   if (it != e->wcache.end()) return it->second;
   const HostTensor& w1 = host_tensor(e, n1 + ".w");
@@ -216,28 +235,14 @@ DevWeight get_weight_cat(rtd_engine* e, const std::string& n1, const std::string
   RTD_CHECK(w1.numel() == (int64_t)N * K1 && w2.numel() == (int64_t)N * K2 && b1.numel() == N && b2.numel() == N, RTD_E_WEIGHTS,
             "weight shape mismatch: " + n1 + " + " + n2);
   DevWeight d;
-  d.N = N; d.K = K1 + K2; d.Kpad = conv_kpad(d.K); d.Npad = conv_npad(N); d.dt = dt;
-  std::vector<float> pad((size_t)d.Npad * d.Kpad, 0.f);
+  d.N = N; d.K = K1 + K2; d.Kpad = dt == BF16X2 ? conv_kpad_split(d.K) : conv_kpad(d.K); d.Npad = conv_npad(N); d.dt = dt;
+  const int kcols = dt == BF16X2 ? d.Kpad / 2 : d.Kpad;
+  std::vector<float> pad((size_t)d.Npad * kcols, 0.f);
   for (int r = 0; r < N; ++r) {
-    memcpy(&pad[(size_t)r * d.Kpad], w1.data + (size_t)r * K1, (size_t)K1 * 4);
-    memcpy(&pad[(size_t)r * d.Kpad + K1], w2.data + (size_t)r * K2, (size_t)K2 * 4);
+    memcpy(&pad[(size_t)r * kcols], w1.data + (size_t)r * K1, (size_t)K1 * 4);
+    memcpy(&pad[(size_t)r * kcols + K1], w2.data + (size_t)r * K2, (size_t)K2 * 4);
   }
-  float* tmp = nullptr;
-  HIP_CHECK(hipMalloc((void**)&tmp, pad.size() * 4));
-  hipError_t er = hipMemcpy(tmp, pad.data(), pad.size() * 4, hipMemcpyHostToDevice);
-  if (er == hipSuccess) {
-    if (dt == F32) {
-      d.w = tmp;
-      e->allocs.push_back(tmp);
-      tmp = nullptr;
-    } else {
-      d.w = e->dmalloc(pad.size() * 2);
-      launch_f32_to(tmp, d.w, BF16, (int64_t)pad.size(), e->stream);
-      er = hipStreamSynchronize(e->stream);
-    }
-  }
-  if (tmp) (void)hipFree(tmp);
-  HIP_CHECK(er);
+  d.w = upload_filter(e, pad, d.Npad, kcols, dt);
   std::vector<float> bp(d.Npad, 0.f);
   for (int r = 0; r < N; ++r) bp[r] = b1.data[r] + b2.data[r];
   d.bias = (float*)e->dmalloc(bp.size() * 4);
@@ -457,7 +462,7 @@ struct Builder {
     DevWeight w;
     // name2 empty: `name` is already the filter over [x | x2] (a conv over a concatenation that is read from its two sources)
     if (!dry) w = (x2 && !name2.empty()) ? get_weight_cat(e, name, name2, x.dt, y.c, k * k * x.c, x2->c) : get_weight(e, name, x.dt, y.c, K);
-    else { w.Kpad = conv_kpad(K); w.Npad = conv_npad(y.c); }
+    else { w.Kpad = x.dt == BF16X2 ? conv_kpad_split(K) : conv_kpad(K); w.Npad = conv_npad(y.c); }
     ConvArgs a;
     a.x = x; a.y = y; a.w = w.w; a.bias = w.bias;
     if (x2) a.x2 = *x2;
@@ -481,7 +486,7 @@ struct Builder {
     auto ap = std::make_shared<ConvArgs>(a);
     if (!dry) {
       // chain: the previous conv launch of the plan prefetches THIS filter while it runs (ConvArgs::pf)
-      if (last_conv) { last_conv->pf = w.w; last_conv->pf_bytes = (size_t)w.Npad * w.Kpad * dtype_size(x.dt); }
+      if (last_conv) { last_conv->pf = w.w; last_conv->pf_bytes = (size_t)w.Npad * w.Kpad * (x.dt == F32 ? 4 : 2); }
       last_conv = ap;
     }
     push(name, "conv_igemm", flops, bytes, [ap](hipStream_t s) { launch_conv(*ap, s); });
@@ -493,7 +498,15 @@ struct Builder {
     conv(name, x, y, 1, 1, 0, act, res, RES_PRE);
     return y;
   }
+  // dense fp32 rows -> BF16X2 rows (the split engine's trunk type) as its own launch
+  Tensor to_split(const std::string& name, const Tensor& x, const std::string& tname = "") {
+    Tensor y = act(BF16X2, x.n, x.h, x.w, x.c, tname);
+    const int64_t rows = x.pixels();
+    push(name, "convert", 0.0, tbytes(x) + tbytes(y), [x, y, rows](hipStream_t s) { launch_f32_to_split((const float*)x.p, x.ld, y.p, y.ld, rows, x.c, s); });
+    return y;
+  }
   Tensor layernorm(const std::string& name, const Tensor& x, int odt, const std::string& tname = "") {
+    if (odt == BF16X2) return to_split(name + ".split", layernorm(name, x, F32), tname);
     Tensor y = act(odt, x.n, x.h, x.w, x.c, tname);
     if (dry) return y;
     const float* g = get_vec(e, name + ".g", x.c);
@@ -507,6 +520,7 @@ struct Builder {
 void build_graph(rtd_engine* e, Builder& B, int n) {
   const rtd_config& c = e->cfg;
   const int P = e->P;
+  const bool SP = P == BF16X2;            // rtd_config.precision = RTD_PREC_BF16X3: the trunk carries hi/lo bf16 pairs
   const int H = c.input_h, W = c.input_w;
   Plan* plan = B.plan;
   auto nm = [](const char* fmt, int a = 0, int b = 0) {
@@ -516,7 +530,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   };
 
   // ---- input + stem (HF:rt_detr_resnet.py:71-114) ----------------------------------------------
-  Tensor x = B.act(P, n, H, W, 8, "input");
+  Tensor x = B.act(SP ? F32 : P, n, H, W, 8, "input");   // split engine: fp32 pixels, stem.0 runs on fp32 MFMAs (K = 27) and writes BF16X2
   plan->input = x;
   const int eh = c.embedding_size / 2;
   int h = down2(H), w = down2(W);
@@ -596,7 +610,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
                  [cur, pooled](hipStream_t s) { launch_avgpool2(cur, pooled, s); });
           sc_in = pooled;
         }
-        if (P == BF16 && g_sc_fold) {
+        if ((P == BF16 || SP) && g_sc_fold) {
           // shapes only: would the kernels take the folded launch?  Asked for ONE image whatever this plan's batch: every plan
           // of an engine must use the same filters (the host copies are dropped after the first plan) and the same arithmetic
           // (batch invariance), and a single image has the smallest grid
@@ -682,13 +696,13 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     auto elin = [&](const std::string& name, int N, int K) {
       DecLin Lw{};
       if (!B.dry) {
-        DevWeight w = get_weight_packed(e, name, N, K, K, g_dec_split && P == BF16);
+        DevWeight w = get_weight_packed(e, name, N, K, K, g_dec_split && P != F32);
         Lw.w = (const float*)w.w; Lw.b = w.bias; Lw.ldw = w.Kpad; Lw.N = N; Lw.K = w.K;
       }
       return Lw;
     };
     DecArgs a0{};
-    a0.split = P == BF16 ? g_dec_split : 0;
+    a0.split = P != F32 ? g_dec_split : 0;
     a0.attn_split = g_attn_split & 1;                          // bit 0: AIFI, bit 1: decoder
     a0.B = n; a0.Q = L; a0.D = d; a0.heads = 8; a0.S = 0; a0.n_levels = 3; a0.n_points = 4; a0.ffn = c.enc_ffn; a0.C = 4;
     a0.hs_in = (const float*)t0.p; a0.qpos_in = e->pos_dev;
@@ -705,9 +719,19 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       a4.ln1.g = get_vec(e, "enc.aifi.ln1.g", d); a4.ln1.b = get_vec(e, "enc.aifi.ln1.b", d);
       a4.ln3.g = get_vec(e, "enc.aifi.ln2.g", d); a4.ln3.b = get_vec(e, "enc.aifi.ln2.b", d);
     }
-    if (P == BF16) a4.out_bf16 = t2.p; else a4.hs_out = (float*)t2.p;
+    Tensor t2f;
+    if (SP) { t2f = B.act(F32, n, L, 1, d); a4.hs_out = (float*)t2f.p; }
+    else if (P == BF16) a4.out_bf16 = t2.p;
+    else a4.hs_out = (float*)t2.p;
     B.push("enc.aifi.layer", "dec_layer", 4.0 * n * (double)L * L * d + 2.0 * n * L * ((double)d * d + 2.0 * d * c.enc_ffn),
            (double)n * L * d * 4 * 4, [a4](hipStream_t s) { launch_dec_layer(a4, s); });
+    if (SP) {
+      const Tensor src = t2f, dst = t2;
+      const int64_t rows = src.pixels();
+      B.push("enc.aifi.out_split", "convert", 0.0, 2 * Builder::tbytes(src), [src, dst, rows](hipStream_t s) {
+        launch_f32_to_split((const float*)src.p, src.ld, dst.p, dst.ld, rows, src.c, s);
+      });
+    }
   } else {
   Tensor xp = B.act(F32, n, L, 1, d);
   B.push("enc.aifi.addpos", "add", (double)xp.pixels() * d, 3 * Builder::tbytes(xp), [t0, pos, xp](hipStream_t s) { launch_add(t0, pos, xp, s); });
@@ -732,7 +756,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   auto csp = [&](const std::string& pfx, const Tensor& cat, const std::string& oname, const Tensor* up_src = nullptr) {
     Tensor h12 = B.act(P, cat.n, cat.h, cat.w, 2 * hh);
     bool up_fold = false;
-    if (up_src && P == BF16 && g_up_fold) {
+    if (up_src && (P == BF16 || SP) && g_up_fold) {
       ConvArgs probe;                                          // shapes for ONE image, like the shortcut fold
       probe.x = *up_src; probe.x.p = (void*)16; probe.x.n = 1;
       probe.x2 = cat.slice_c(d, d); probe.x2.p = (void*)16; probe.x2.n = 1;
@@ -790,7 +814,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     B.conv(nm("dec.proj.%d", l), pan[l], v, 1, 1, 0, ACT_NONE);
   }
   // value_proj of every decoder layer in ONE GEMM (they all read `mem`, HF:v2.py:177)
-  Tensor vall = B.linear("dec.vp_all", mem, NL * dm, P, ACT_NONE, nullptr, "value_all");
+  Tensor vall = B.linear("dec.vp_all", mem, NL * dm, SP ? F32 : P, ACT_NONE, nullptr, "value_all");   // the samplers read bf16 or fp32 values
   // enc_output on masked memory, fp32 from here on (selection + decoder are exact fp32)
   Tensor eo = B.linear("dec.enc_out.fc", mem, dm, F32, ACT_NONE);
   if (!B.dry && e->n_invalid > 0) {
@@ -869,7 +893,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     auto lin = [&](const std::string& name, int N, int K, int Kuse = 0) {
       DecLin L{};
       if (!B.dry) {
-        DevWeight w = get_weight_packed(e, name, N, K, Kuse ? Kuse : K, g_dec_split && P == BF16);
+        DevWeight w = get_weight_packed(e, name, N, K, Kuse ? Kuse : K, g_dec_split && P != F32);
         L.w = (const float*)w.w; L.b = w.bias; L.ldw = w.Kpad; L.N = N; L.K = w.K;
       }
       return L;
@@ -880,7 +904,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       return P;
     };
     DecArgs base{};
-    base.split = P == BF16 ? g_dec_split : 0;
+    base.split = P != F32 ? g_dec_split : 0;
     base.attn_split = (g_attn_split >> 1) & 1;
     base.B = n; base.Q = Q; base.D = dm; base.heads = c.dec_heads; base.S = S; base.n_levels = c.n_levels;
     base.n_points = c.n_points; base.ffn = c.dec_ffn; base.C = C; base.offset_scale = c.offset_scale;
@@ -1195,7 +1219,7 @@ int rtd_create(const rtd_config* cfg, rtd_handle* out) {
   if (!cfg || !out) { g_create_error = "null argument"; return RTD_E_INVALID; }
   try {
     RTD_CHECK(cfg->struct_size == (int32_t)sizeof(rtd_config), RTD_E_INVALID, "rtd_config.struct_size mismatch");
-    RTD_CHECK(cfg->precision == RTD_PREC_BF16 || cfg->precision == RTD_PREC_FP32, RTD_E_INVALID, "precision");
+    RTD_CHECK(cfg->precision == RTD_PREC_BF16 || cfg->precision == RTD_PREC_FP32 || cfg->precision == RTD_PREC_BF16X3, RTD_E_INVALID, "precision");
     RTD_CHECK(cfg->max_batch >= 1 && cfg->max_batch <= 64, RTD_E_INVALID, "max_batch must be in [1,64]");
     RTD_CHECK(cfg->profile == RTD_PROFILE_LATENCY || cfg->profile == RTD_PROFILE_THROUGHPUT, RTD_E_INVALID, "profile");
     // the FPN concatenates a 2x-upsampled map with the next level: every level must halve exactly
@@ -1210,7 +1234,13 @@ int rtd_create(const rtd_config* cfg, rtd_handle* out) {
     RTD_CHECK((cfg->dec_heads * cfg->n_levels * cfg->n_points * 3) % 4 == 0, RTD_E_INVALID, "sampling head width");
     rtd_engine* e = new rtd_engine();
     e->cfg = *cfg;
-    e->P = cfg->precision == RTD_PREC_BF16 ? BF16 : F32;
+    e->P = cfg->precision == RTD_PREC_BF16 ? BF16 : (cfg->precision == RTD_PREC_BF16X3 ? BF16X2 : F32);
+    if (e->P == BF16X2) {
+      // hi/lo pairs travel in 32-channel groups (common.h BF16X2): every trunk width must be whole groups
+      bool ok = (cfg->embedding_size / 2) % SPLIT_GROUP == 0 && cfg->enc_dim % SPLIT_GROUP == 0 && cfg->csp_hidden % SPLIT_GROUP == 0 && cfg->d_model % SPLIT_GROUP == 0;
+      for (int i = 0; i < 4; ++i) ok = ok && cfg->hidden_sizes[i] % SPLIT_GROUP == 0 && (cfg->layer_type != RTD_LAYER_BOTTLENECK || (cfg->hidden_sizes[i] / 4) % SPLIT_GROUP == 0);
+      if (!ok) { delete e; RTD_CHECK(false, RTD_E_INVALID, "precision bf16x3 needs every trunk channel count to be a multiple of 32 (embedding_size of 64)"); }
+    }
     *out = e;
     return RTD_OK;
   } catch (const Error& er) {
@@ -1395,13 +1425,15 @@ int rtd_debug_tensor(rtd_handle h, const char* name, float* out, int64_t capacit
     RTD_CHECK(t.bstride == (int64_t)t.h * t.w * t.ld, RTD_E_INVALID, "debug tensor: non-dense batch stride");
     HIP_CHECK(hipSetDevice(h->cfg.device));
     const size_t es = dtype_size(t.dt);
+    if (t.dt == BF16X2) RTD_CHECK(t.c % SPLIT_GROUP == 0, RTD_E_INVALID, "debug tensor: split tensor with a partial channel group");
     void* dense = nullptr;
     float* f32 = nullptr;
     HIP_CHECK(hipMalloc(&dense, (size_t)numel * es));
     hipError_t er = hipMalloc((void**)&f32, (size_t)numel * 4);
     if (er == hipSuccess) er = hipMemcpy2DAsync(dense, (size_t)t.c * es, t.p, (size_t)t.ld * es, (size_t)t.c * es, (size_t)t.pixels(), hipMemcpyDeviceToDevice, h->stream);
     if (er == hipSuccess) {
-      launch_to_f32(dense, t.dt, f32, numel, h->stream);
+      if (t.dt == BF16X2) launch_split_to_f32(dense, t.c, f32, t.c, t.pixels(), t.c, h->stream);
+      else launch_to_f32(dense, t.dt, f32, numel, h->stream);
       er = hipMemcpyAsync(out, f32, (size_t)numel * 4, hipMemcpyDeviceToHost, h->stream);
     }
     if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
@@ -1542,6 +1574,8 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "profile_twice") == 0) { g_profile_twice = value; return RTD_OK; }
   if (strcmp(name, "bench_rewarm") == 0) { g_bench_rewarm = value; return RTD_OK; }
   if (strcmp(name, "splitk") == 0) { conv_set_splitk(value); return RTD_OK; }
+  if (strcmp(name, "split_ws2_min_blocks") == 0) { conv_set_split_ws2_min_blocks(value); return RTD_OK; }
+  if (strcmp(name, "split_ws64_max_blocks") == 0) { conv_set_split_ws64_max_blocks(value); return RTD_OK; }
   if (strcmp(name, "glds_drop") == 0) { conv_set_glds_drop(value); return RTD_OK; }
   if (strcmp(name, "glds_min_blocks") == 0) { conv_set_glds_min_blocks(value); return RTD_OK; }
   return RTD_E_INVALID;
@@ -1551,18 +1585,23 @@ static int op_conv_impl(int dtype, const void* x, const void* x2, int C2, const 
                         int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int act, int res_mode, int out_f32, int x_up2 = 0) {
   return op_guard([&] {
     RTD_CHECK(KH == KW, RTD_E_INVALID, "square filters only");
-    const int K = KH * KW * Cin + (x2 ? C2 : 0), Kpad = conv_kpad(K), Npad = conv_npad(Cout);
+    const int K = KH * KW * Cin + (x2 ? C2 : 0), Npad = conv_npad(Cout);
+    const int Kpad = dtype == BF16X2 ? conv_kpad_split(K) : conv_kpad(K);
+    const int kcols = dtype == BF16X2 ? Kpad / 2 : Kpad;          // fp32 staging row (BF16X2: 2 bf16 per column)
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     float* wpad = nullptr; void* wdev = nullptr; float* bpad = nullptr;
-    HIP_CHECK(hipMalloc((void**)&wpad, (size_t)Npad * Kpad * 4));
-    HIP_CHECK(hipMemset(wpad, 0, (size_t)Npad * Kpad * 4));
-    HIP_CHECK(hipMemcpy2D(wpad, (size_t)Kpad * 4, w_ohwi_f32, (size_t)K * 4, (size_t)K * 4, Cout, hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipMalloc((void**)&wpad, (size_t)Npad * kcols * 4));
+    HIP_CHECK(hipMemset(wpad, 0, (size_t)Npad * kcols * 4));
+    HIP_CHECK(hipMemcpy2D(wpad, (size_t)kcols * 4, w_ohwi_f32, (size_t)K * 4, (size_t)K * 4, Cout, hipMemcpyDeviceToDevice));
     HIP_CHECK(hipMalloc((void**)&bpad, (size_t)Npad * 4));
     HIP_CHECK(hipMemset(bpad, 0, (size_t)Npad * 4));
     HIP_CHECK(hipMemcpy(bpad, bias, (size_t)Cout * 4, hipMemcpyDeviceToDevice));
     if (dtype == BF16) {
       HIP_CHECK(hipMalloc(&wdev, (size_t)Npad * Kpad * 2));
       launch_f32_to(wpad, wdev, BF16, (int64_t)Npad * Kpad, nullptr);
+    } else if (dtype == BF16X2) {
+      HIP_CHECK(hipMalloc(&wdev, (size_t)Npad * Kpad * 2));
+      launch_f32_to_split(wpad, kcols, wdev, kcols, Npad, kcols, nullptr);
     } else wdev = wpad;
     ConvArgs a;
     a.x = x_up2 ? mk(x, dtype, B, H / 2, W / 2, Cin) : mk(x, dtype, B, H, W, Cin);      // x_up2: H, W are the OUTPUT extents

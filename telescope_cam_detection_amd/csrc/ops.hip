@@ -44,6 +44,41 @@ void launch_to_f32(const void* src, int dt, float* dst, int64_t n, hipStream_t s
   HIP_CHECK(hipGetLastError());
 }
 
+// fp32 rows <-> BF16X2 rows (common.h: groups of 32 channels, [32 hi | 32 lo]); a thread moves 8 channels
+__global__ void k_f32_to_split(const float* __restrict__ src, int64_t lds_, bf16* __restrict__ dst, int64_t ldd, int64_t rows, int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c8 = C / 8;
+  if (i >= rows * c8) return;
+  const int64_t r = i / c8;
+  const int c = (int)(i - r * c8) * 8;
+  const f32x4 a = *(const f32x4*)(src + r * lds_ + c), b = *(const f32x4*)(src + r * lds_ + c + 4);
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  split_store8(dst, r * ldd, c, v);
+}
+__global__ void k_split_to_f32(const bf16* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd, int64_t rows, int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c8 = C / 8;
+  if (i >= rows * c8) return;
+  const int64_t r = i / c8;
+  const int c = (int)(i - r * c8) * 8;
+  float v[8];
+  split_load8(src, r * lds_, c, v);
+  *(f32x4*)(dst + r * ldd + c) = f32x4{v[0], v[1], v[2], v[3]};
+  *(f32x4*)(dst + r * ldd + c + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+void launch_f32_to_split(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows, int C, hipStream_t s) {
+  if (rows == 0) return;
+  RTD_CHECK(C % SPLIT_GROUP == 0 && lds_ % 4 == 0 && ldd % SPLIT_GROUP == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, 1, "f32 -> split: 32-channel groups, 16-byte rows");
+  hipLaunchKernelGGL(k_f32_to_split, dim3(blocks_for(rows * (C / 8), 256)), dim3(256), 0, s, src, lds_, (bf16*)dst, ldd, rows, C);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_split_to_f32(const void* src, int64_t lds_, float* dst, int64_t ldd, int64_t rows, int C, hipStream_t s) {
+  if (rows == 0) return;
+  RTD_CHECK(C % SPLIT_GROUP == 0 && lds_ % SPLIT_GROUP == 0 && ldd % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, 1, "split -> f32: 32-channel groups, 16-byte rows");
+  hipLaunchKernelGGL(k_split_to_f32, dim3(blocks_for(rows * (C / 8), 256)), dim3(256), 0, s, (const bf16*)src, lds_, dst, ldd, rows, C);
+  HIP_CHECK(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------ layer norm
 // y = LN(x (+ res)) * g + b over the last dim; one wave per row.  torch.nn.functional.layer_norm
 // semantics (biased variance, eps inside the sqrt).  HF:v2.py:861,886 (post-norm residual blocks).
@@ -224,12 +259,52 @@ __global__ __launch_bounds__(256) void k_maxpool_bf16_2x2(const bf16* __restrict
     }
 }
 
+// BF16X2: 8 channels (one 16-byte hi chunk + one 16-byte lo chunk) of one output per thread; hi + lo is exact in fp32, so the max
+// is the max of the represented values and re-splitting it reproduces the winning tap's (hi, lo) pair bit for bit
+__global__ __launch_bounds__(256) void k_maxpool_split(const bf16* __restrict__ x, bf16* __restrict__ y, int B, int H, int W, int C, int64_t ldx,
+                                                       int OH, int OW, int64_t ldy) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c8 = C / 8;
+  const int64_t total = (int64_t)B * OH * OW * c8;
+  if (i >= total) return;
+  const int cc = (int)(i % c8) * 8;
+  int64_t p = i / c8;
+  const int ox = (int)(p % OW); p /= OW;
+  const int oy = (int)(p % OH);
+  const int b = (int)(p / OH);
+  float m[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = oy * 2 - 1 + dy;
+    if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = ox * 2 - 1 + dx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      float v[8];
+      split_load8(x, (((int64_t)b * H + iy) * W + ix) * ldx, cc, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], v[k]);
+    }
+  }
+  split_store8(y, (((int64_t)b * OH + oy) * OW + ox) * ldy, cc, m);
+}
+
 static int g_maxpool_v1 = 0;   // A/B + test hook (rtd_debug_option "maxpool_v1"): 1 = the one-output-per-thread kernel for every dtype
 void maxpool_set_v1(int v) { g_maxpool_v1 = v; }
 void launch_maxpool3x3s2(const Tensor& x, const Tensor& y, hipStream_t s) {
   RTD_CHECK(x.dt == y.dt && x.c == y.c && x.c % 4 == 0 && x.n == y.n, 1, "maxpool: dtype/channels");
   RTD_CHECK(y.h == (x.h + 2 - 3) / 2 + 1 && y.w == (x.w + 2 - 3) / 2 + 1, 1, "maxpool: shape");
   RTD_CHECK(x.bstride == (int64_t)x.h * x.w * x.ld && y.bstride == (int64_t)y.h * y.w * y.ld, 1, "maxpool: dense images");
+  if (x.dt == BF16X2) {
+    RTD_CHECK(x.c % SPLIT_GROUP == 0 && x.ld % SPLIT_GROUP == 0 && y.ld % SPLIT_GROUP == 0 && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0, 1, "maxpool: split layout");
+    const int64_t total = (int64_t)y.n * y.h * y.w * (y.c / 8);
+    hipLaunchKernelGGL(k_maxpool_split, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const bf16*)x.p, (bf16*)y.p, x.n, x.h, x.w, x.c, x.ld, y.h, y.w, y.ld);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (!g_maxpool_v1 && x.dt == BF16 && x.c % 8 == 0 && x.ld % 8 == 0 && y.ld % 8 == 0 && y.h % 2 == 0 && y.w % 2 == 0 && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0) {
     const int64_t total2 = (int64_t)y.n * (y.h / 2) * (y.w / 2) * (y.c / 8);
     hipLaunchKernelGGL(k_maxpool_bf16_2x2, dim3(blocks_for(total2, 256)), dim3(256), 0, s, (const bf16*)x.p, (bf16*)y.p, x.n, x.h, x.w, x.c,
@@ -268,7 +343,34 @@ __global__ void k_avgpool2(const T* __restrict__ x, T* __restrict__ y, int B, in
   for (int k = 0; k < V; ++k) o[k] = (T)((((float)a0[k] + (float)a1[k]) + ((float)a2[k] + (float)a3[k])) * 0.25f);
   *(VT*)(y + (((int64_t)b * OH + oy) * OW + ox) * ldy + cc) = o;
 }
+__global__ void k_avgpool2_split(const bf16* __restrict__ x, bf16* __restrict__ y, int B, int H, int W, int C, int64_t ldx, int64_t ldy) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cv = C / 8;
+  const int OH = H / 2, OW = W / 2;
+  const int64_t total = (int64_t)B * OH * OW * cv;
+  if (i >= total) return;
+  const int cc = (int)(i % cv) * 8;
+  int64_t p = i / cv;
+  const int ox = (int)(p % OW); p /= OW;
+  const int oy = (int)(p % OH);
+  const int b = (int)(p / OH);
+  const int64_t q = (((int64_t)b * H + 2 * oy) * W + 2 * ox) * ldx;
+  float a0[8], a1[8], a2[8], a3[8], o[8];
+  split_load8(x, q, cc, a0); split_load8(x, q + ldx, cc, a1); split_load8(x, q + (int64_t)W * ldx, cc, a2); split_load8(x, q + (int64_t)(W + 1) * ldx, cc, a3);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = ((a0[k] + a1[k]) + (a2[k] + a3[k])) * 0.25f;
+  split_store8(y, (((int64_t)b * OH + oy) * OW + ox) * ldy, cc, o);
+}
 void launch_avgpool2(const Tensor& x, const Tensor& y, hipStream_t s) {
+  if (x.dt == BF16X2) {
+    RTD_CHECK(y.dt == BF16X2 && x.c == y.c && x.c % SPLIT_GROUP == 0 && x.ld % SPLIT_GROUP == 0 && y.ld % SPLIT_GROUP == 0 && x.n == y.n, 1, "avgpool: split layout");
+    RTD_CHECK(x.h % 2 == 0 && x.w % 2 == 0 && y.h == x.h / 2 && y.w == x.w / 2, 1, "avgpool: even extents only");
+    RTD_CHECK(x.bstride == (int64_t)x.h * x.w * x.ld && y.bstride == (int64_t)y.h * y.w * y.ld && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0, 1, "avgpool: dense images");
+    const int64_t total = (int64_t)y.n * y.h * y.w * (y.c / 8);
+    hipLaunchKernelGGL(k_avgpool2_split, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const bf16*)x.p, (bf16*)y.p, x.n, x.h, x.w, x.c, x.ld, y.ld);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   const int V = x.dt == BF16 ? 8 : 4;
   RTD_CHECK(x.dt == y.dt && x.c == y.c && x.c % V == 0 && x.ld % V == 0 && y.ld % V == 0 && x.n == y.n, 1, "avgpool: dtype/channels");
   RTD_CHECK(x.h % 2 == 0 && x.w % 2 == 0 && y.h == x.h / 2 && y.w == x.w / 2, 1, "avgpool: even extents only");

@@ -116,7 +116,7 @@ class RTDETRDetector:
                 state, arch_name = load_state(self.model_path)
                 arch = ARCHS[arch_name] if arch_name else arch_from_config_path(self.config_path)
                 blob = pack_blob(fold_weights(arch, state))
-                prec = _capi.PREC_FP32 if str(self.precision).lower() in ("fp32", "f32", "float32") else _capi.PREC_BF16
+                prec = _capi.precision_code(self.precision)
                 engine = _capi.Engine(arch, blob, device=dev, precision=prec, max_batch=self.max_batch,
                                       input_size=tuple(self.input_size), use_graph=self.use_graph,
                                       profile=_capi.PROFILE_THROUGHPUT if str(self.profile).lower() == "throughput" else _capi.PROFILE_LATENCY)

@@ -274,6 +274,73 @@ def test_conv(L, dt, case):
     _capi.debug_option("splitk", 0)
 
 
+SPLIT_CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, act, res_mode, out_f32   (Cin % 32 == 0; BF16X2 output: Cout % 32 == 0)
+    (2, 20, 20, 64, 64, 1, 1, 0, "relu", 0, 0),         # 128 x 64 tile
+    (1, 33, 29, 32, 96, 3, 1, 1, "silu", 0, 0),         # one channel group per tap, ragged M, Cout not a tile multiple
+    (2, 40, 40, 64, 128, 3, 2, 1, "relu", 1, 0),        # stride 2, pre-activation BF16X2 residual
+    (1, 16, 16, 128, 256, 1, 1, 0, "none", 2, 0),       # post-activation residual
+    (4, 60, 264, 32, 32, 3, 1, 1, "relu", 0, 0),        # stem.1: half-empty 64-channel tile
+    (4, 80, 80, 128, 128, 3, 1, 1, "silu", 1, 0),       # 2-stage kernel (>= 257 blocks)
+    (4, 100, 97, 128, 192, 3, 1, 1, "silu", 2, 0),      # ragged M, partial last N tile, post residual
+    (2, 160, 160, 64, 256, 1, 1, 0, "relu", 1, 0),      # stage-0 c3
+    (1, 8400, 1, 256, 1536, 1, 1, 0, "none", 0, 1),     # value projection: fp32 output
+    (1, 400, 1, 2048, 256, 1, 1, 0, "none", 0, 1),      # enc.proj.2: long K, fp32 output, 4-stage kernel
+    (2, 20, 20, 512, 512, 3, 1, 1, "relu", 0, 0),       # stage-3 c2: K = 4608 real channels x taps
+    (1, 70, 50, 256, 64, 1, 1, 0, "gelu", 0, 0),
+    (2, 40, 41, 256, 1024, 1, 1, 0, "relu", 1, 1),      # fp32 output with a BF16X2 residual
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CONV_CASES)
+def test_conv_split_bf16x3(L, case):
+    """BF16X2 operands (hi/lo bf16 pairs, 32-channel groups), three MFMAs per product: against fp64 on the values the kernel sees
+    (inputs rounded to hi + lo).  Error budget: the dropped lo*lo term (2^-18 per product) + fp32 accumulation + one hi/lo rounding
+    of the output (2^-18) -> 2e-5 relative, 250x tighter than the bf16 kernels' tolerance."""
+    from telescope_cam_detection_amd import _capi
+    B, H, W, Cin, Cout, k, stride, pad, act, res_mode, out_f32 = case
+    g = torch.Generator().manual_seed(4000 + SPLIT_CONV_CASES.index(case))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, OH, OW, Cout, generator=g) if res_mode else None
+    xs = _capi.to_split(x.numpy())
+    xq = torch.from_numpy(_capi.from_split(xs)).permute(0, 3, 1, 2)
+    wq = torch.from_numpy(_capi.from_split(_capi.to_split(w.permute(0, 2, 3, 1).reshape(Cout, -1).numpy()))).reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    rs = _capi.to_split(res.numpy()) if res is not None else None
+    rq = torch.from_numpy(_capi.from_split(rs)).permute(0, 3, 1, 2).double() if res is not None else None
+    y = F.conv2d(xq.double(), wq.double(), b.double(), stride=stride, padding=pad)
+    if res_mode == 1:
+        y = y + rq
+    y = {"none": lambda t: t, "relu": F.relu, "silu": F.silu, "gelu": F.gelu}[act](y)
+    if res_mode == 2:
+        y = y + rq
+    xd = torch.from_numpy(xs.view(np.int16)).cuda()
+    wd = w.permute(0, 2, 3, 1).contiguous().cuda()
+    bd = b.cuda()
+    rd = torch.from_numpy(rs.view(np.int16)).cuda() if rs is not None else None
+    if out_f32:
+        yd = torch.full((B, OH, OW, Cout), float("nan"), dtype=torch.float32, device="cuda")
+    else:
+        yd = torch.full((B, OH, OW, 2 * Cout), -1, dtype=torch.int16, device="cuda")
+    for ws2, ws64 in ((257, 160), (1, 0), (1 << 30, 1 << 30)):      # auto | 2-stage 128-wide tiles everywhere | 4-stage, 64-wide tiles everywhere
+        _capi.debug_option("split_ws2_min_blocks", ws2)
+        _capi.debug_option("split_ws64_max_blocks", ws64)
+        ck(L, L.rtd_op_conv(_capi.DT_BF16X2, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None,
+                            yd.data_ptr(), B, H, W, Cin, Cout, k, k, stride, pad, {"none": 0, "relu": 1, "silu": 2, "gelu": 3}[act],
+                            res_mode, out_f32))
+        got = yd.cpu().numpy() if out_f32 else _capi.from_split(yd.cpu().numpy().view(np.uint16))
+        got = torch.from_numpy(got).permute(0, 3, 1, 2).double()
+        assert torch.isfinite(got).all()
+        err = (got - y).abs().max().item() / y.abs().max().item()
+        rel = (torch.linalg.norm(got - y) / torch.linalg.norm(y)).item()
+        print(f"split conv {case}: max err / max |y| {err:.2e}, rel l2 {rel:.2e}")
+        assert err < 2e-5 and rel < 1e-5, (case, ws2, ws64, err, rel)
+    _capi.debug_option("split_ws2_min_blocks", 257)
+    _capi.debug_option("split_ws64_max_blocks", 160)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("dim", [64, 256, 384])
 def test_layernorm(L, dt, dim):

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Run GPU steps one after another on a gpurun box: each step under its own `timeout -k 10`, logs under gpurun_out/.
+# A step that FAILS (test assertion, non-zero exit) does not stop the chain; a step that TIMES OUT or is KILLED does -
+# after a hang no further GPU step may start in the same call.
+#   tools/gpu_chain.sh "<secs> <logname> <command...>" ...
+mkdir -p gpurun_out
+for spec in "$@"; do
+  secs=${spec%% *}; rest=${spec#* }; log=${rest%% *}; cmd=${rest#* }
+  echo "[chain] $log: $cmd (limit ${secs}s)"
+  timeout -k 10 "$secs" bash -c "$cmd" > "gpurun_out/$log" 2>&1
+  rc=$?
+  echo "[chain] $log rc=$rc"; tail -n 6 "gpurun_out/$log"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[chain] step timed out / was killed: stopping"; exit $rc; fi
+done
+exit 0
