@@ -2,32 +2,42 @@
 """bench.py - frames/s of the MI355X-native RT-DETR path (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): RT-DETR-R50, 640x640, bs=8 per GPU, bf16, synthetic uniform-noise
-uint8 BGR frames (the reference benchmark's input, tests/test_inference.py:76) already resident in HBM,
-seeded synthetic weights (no checkpoint exists offline).  One "step" = one batch of 8 frames through
-preprocess -> network -> post-process on the device (the fixed [8,300,6] result block stays in HBM).
-N > 1: one process per GPU, cameras sharded over ranks (weak scaling), and one RCCL all-gather of
-every rank's result block per step - the collate step for rank 0's web server.
+N > 1 without WORLD_SIZE in the environment: this process touches no GPU and starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>` as a child;
+rank 0 of that world prints the JSON line.  Launched by torch.distributed.run directly (RANK / LOCAL_RANK / WORLD_SIZE set)
+it runs as one rank.
 
---streams S (default 3): S engine handles per GPU, each with its own HIP stream, hipGraph and camera group, take the K
-timed steps round-robin, so S batches are in flight - the reference's deployment shape (one inference engine per camera
-group sharing the GPU, main.py:1236-1291).  Every step is still one full bs-8 pass; the kernels of one batch fill the CUs
-the other batches' small grids and launch ramps leave idle (same-box: S = 1 / 2 / 3 / 4 -> 2256 / 2930 / 3127 / 2868 frames/s).
-`single_stream` in the JSON is the same measurement with S = 1.
+Workload (BASELINE.json configs[1]): RT-DETR-R50, 640x640, bs=8 per GPU, synthetic uniform-noise uint8 BGR frames (the
+reference benchmark's input, tests/test_inference.py:76) already resident in HBM, seeded synthetic weights (no checkpoint
+exists offline).  One "step" = one batch of 8 frames through preprocess -> network -> post-process on the device (the
+fixed [8,300,6] result block stays in HBM).  N > 1: one process per GPU, cameras sharded over ranks (weak scaling), and one
+RCCL all-gather of every rank's result block per step - the collate step for rank 0's web server.
+
+Engine (--precision): "bf16x3" (default) = hi/lo bf16 pairs, three MFMAs per product, fp32 accumulate - the engine that meets
+the north-star tolerance (1e-3 on scores, 1e-2 px on boxes; tests/test_gpu_parity.py) AND the throughput target;
+"bf16" = plain bf16 storage / MFMA (faster, 2-4x outside the tolerance - printed as `bf16_engine` beside the headline);
+"fp32" = exact fp32 MFMAs.
+
+`value` is measured with ONE batch in flight (--streams 1: BASELINE's "bs=8" read strictly; ms_per_step is then the latency of a
+step).  `multi_stream` repeats the measurement with --multi-streams S (default 3) engine handles per GPU, each with its own HIP
+stream, hipGraph and camera group, taking the K timed steps round-robin - the reference's deployment shape (one inference engine
+per camera group sharing the GPU, main.py:1236-1291); every step is still one full bs-8 pass.
 
 Prints ONE JSON line on rank 0 with the contract fields plus:
-  roofline     - MFMA roofline of the dominant kernel family (conv_igemm), from HIP-event timings of
-                 every launch on the engine's stream (rtd_profile) and the algorithmic FLOPs per launch
-  cpu_baseline - the CPU oracle (oracle/rtdetr_oracle.py, fp32 eager PyTorch) timed on this box's host
-                 cores on a bounded sample of the same workload (rank 0, N = 1 only)
+  roofline     - MFMA roofline of the dominant kernel family (conv_igemm), from HIP-event timings of every launch on the
+                 engine's stream (rtd_profile) and the algorithmic FLOPs per launch
+  cpu_baseline - the CPU oracle (oracle/rtdetr_oracle.py, fp32 eager PyTorch) timed on this box's host cores on a bounded
+                 sample of the same workload (rank 0, N = 1 only)
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,8 +45,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+MFMA_PER_PRODUCT = {"bf16": 1, "bf16x3": 3, "fp32": 1}                  # MFMA flops issued per algorithmic flop
 HBM_PEAK_GBS = 8000.0
-CANON_GFLOP_PER_FRAME = {"r18": 60.53, "r50": 133.91}  # BASELINE.md §3 @640x640
+CANON_GFLOP_PER_FRAME = {"r18": 60.53, "r50": 133.91}  # BASELINE.md 3 @640x640
 
 
 class _DevPtr:
@@ -46,7 +57,18 @@ class _DevPtr:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
-def main():
+def csrc_sha() -> str:
+    """hash of the kernel sources: profiles/*.json carry the value they were measured at (tools/summarize_profiles.py)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "telescope_cam_detection_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -54,30 +76,75 @@ def main():
     ap.add_argument("--arch", default="r50")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--precision", default="bf16", choices=["bf16x3", "bf16", "fp32"])
-    ap.add_argument("--streams", type=int, default=3, help="engine handles (batches in flight) per GPU")
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32"])
+    ap.add_argument("--streams", type=int, default=1, help="engine handles (batches in flight) per GPU behind `value`")
+    ap.add_argument("--multi-streams", type=int, default=3, help="handles of the extra `multi_stream` measurement (0 = skip)")
+    ap.add_argument("--workload", default="detect", choices=["detect", "two_stage"],
+                    help="two_stage: detect + Stage-2 crop batch (BASELINE config 5; the classifier network itself is out of scope)")
     ap.add_argument("--latency-profile", action="store_true", help="A/B: the handles of a multi-handle run use the latency profile too")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-bf16-line", action="store_true", help="skip the secondary plain-bf16 engine measurement")
     ap.add_argument("--profile-out", default="")
     ap.add_argument("--opt", action="append", default=[], help="rtd_debug_option name=value (A/B runs)")
-    args = ap.parse_args()
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="CPU-only: form the world (gloo), all-gather the rank ids, print them as JSON - tests the self-launch path")
+    return ap.parse_args(argv)
+
+
+def self_launch(args) -> int:
+    """--gpus N > 1 without a torch.distributed environment: start the N ranks as a child job.  Nothing in this process has
+    touched the GPU (no torch.cuda call, no HIP library loaded); the child job's rank 0 prints the JSON line on our stdout."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_selftest(args, rank, world) -> int:
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([rank], dtype=torch.int64)
+    out = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(out, t)
+    if rank == 0:
+        print(json.dumps({"selftest": "launch", "world": dist.get_world_size(), "ranks": [int(x.item()) for x in out], "gpus": args.gpus}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.launch_selftest:
+        sys.exit(launch_selftest(args, rank, world))
 
     import numpy as np
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the hot path"
     torch.cuda.set_device(local_rank)
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        rccl_ranks = dist.get_world_size()
 
     from telescope_cam_detection_amd import _capi
     from telescope_cam_detection_amd.arch import ARCHS
@@ -90,91 +157,87 @@ def main():
         _capi.debug_option(name, int(val))
     arch = ARCHS[args.arch]
     B, H = args.batch, args.size
+    Q = arch.num_queries
     w = synth_weights(arch, 0)
     blob = pack_blob(fold_weights(arch, w))
-    prec = _capi.precision_code(args.precision)
-    S = max(1, args.streams)
-    # several handles per GPU run the throughput profile (rtd_config.profile: 256-pixel conv tiles); the one-batch-in-flight
-    # figure, the kernel profile / roofline and the latency line come from a latency-profile handle, which is also what
-    # `--streams 1` (the rocprofv3 runs under profiles/) measures
-    prof_mode = _capi.PROFILE_THROUGHPUT if (S > 1 and not args.latency_profile) else _capi.PROFILE_LATENCY
-    engs = [_capi.Engine(arch, blob, device=local_rank, precision=prec, max_batch=B, input_size=(H, H), use_graph=not args.no_graph,
-                         profile=prof_mode) for _ in range(S)]
-    eng = engs[0]
-    eng_lat = eng
-    if prof_mode != _capi.PROFILE_LATENCY:
-        eng_lat = _capi.Engine(arch, blob, device=local_rank, precision=prec, max_batch=B, input_size=(H, H), use_graph=not args.no_graph)
-    # frame i of config c = default_rng(1000*c+i).integers(0,255,(H,W,3),uint8); camera k -> rank k
-    frames_of = [[torch.from_numpy(noise_frame(2000 + (rank * S + si) * B + i, H, H)).cuda() for i in range(B)] for si in range(S)]
-    frames = frames_of[0]
-    prepared = [e.make_async_args(f) for e, f in zip(engs, frames_of)]
-    Q = arch.num_queries
 
-    streams = [torch.cuda.ExternalStream(e.stream(), device=torch.device("cuda", local_rank)) for e in engs]
-    gathered = None
-    if world > 1:
-        gathered = [torch.empty(world * B * Q * 6, dtype=torch.float32, device="cuda") for _ in range(S)]
-
-    prepared_lat = eng_lat.make_async_args(frames) if eng_lat is not eng else prepared[0]
-
-    def step(k, n_handles):
-        si = k % n_handles
-        if n_handles == 1 and world == 1:        # one batch in flight: the latency-profile handle
-            eng_lat.infer_async_prepared(prepared_lat)
-            return
-        engs[si].infer_async_prepared(prepared[si])
-        if world > 1:
-            ptr, n = engs[si].result_block()
-            block = torch.as_tensor(_DevPtr(ptr, n), device=f"cuda:{local_rank}")
-            with torch.cuda.stream(streams[si]):              # ordered after the forward on that engine's stream
-                collate_blocks(block, out=gathered[si])
-
-    def fence():
+    def fence(engs):
         for e in engs:
             e.sync()
-        eng_lat.sync()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n_handles):
+    def measure(precision: str, S: int, crops=None):
+        """K timed steps round-robin over S engine handles of `precision`; returns (elapsed seconds, handles, their frames)."""
+        prec = _capi.precision_code(precision)
+        # several handles per GPU run the throughput profile (rtd_config.profile); a lone handle the latency profile
+        prof_mode = _capi.PROFILE_THROUGHPUT if (S > 1 and not args.latency_profile) else _capi.PROFILE_LATENCY
+        engs = [_capi.Engine(arch, blob, device=local_rank, precision=prec, max_batch=B, input_size=(H, H), use_graph=not args.no_graph,
+                             profile=prof_mode) for _ in range(S)]
+        # SURVEY.md 8(d): frame i of config c = default_rng(1000*c+i).integers(0,255,(H,W,3),uint8); camera k -> rank k
+        frames_of = [[torch.from_numpy(noise_frame(2000 + (rank * S + si) * B + i, H, H)).cuda() for i in range(B)] for si in range(S)]
+        prepared = [e.make_async_args(f) for e, f in zip(engs, frames_of)]
+        streams = [torch.cuda.ExternalStream(e.stream(), device=torch.device("cuda", local_rank)) for e in engs]
+        gathered = [torch.empty(world * B * Q * 6, dtype=torch.float32, device="cuda") for _ in range(S)] if world > 1 else None
+
+        def step(k):
+            si = k % S
+            engs[si].infer_async_prepared(prepared[si])
+            if crops is not None:
+                crops(engs[si], frames_of[si], streams[si])
+            if world > 1:
+                ptr, n = engs[si].result_block()
+                block = torch.as_tensor(_DevPtr(ptr, n), device=f"cuda:{local_rank}")
+                with torch.cuda.stream(streams[si]):              # ordered after the forward on that engine's stream
+                    collate_blocks(block, out=gathered[si])
+
         for k in range(args.warmup):
-            step(k, n_handles)
-        fence()
+            step(k)
+        fence(engs)
         t0 = time.perf_counter()
         for k in range(args.steps):
-            step(k, n_handles)
-        fence()
+            step(k)
+        fence(engs)
         el = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return el
+        return el, engs, frames_of
 
-    single = timed(1) if S > 1 else None
-    elapsed = timed(S)
+    crops_fn, crop_info = None, None
+    if args.workload == "two_stage":
+        from telescope_cam_detection_amd.stage2 import bench_crop_step
+        crops_fn, crop_info = bench_crop_step(B, H, seed=5000 + rank)
+
+    S = max(1, args.streams)
+    elapsed, engs, frames_of = measure(args.precision, S, crops_fn)
+    eng, frames = engs[0], frames_of[0]
     fps = world * B * args.steps / elapsed
     out = {
         "metric": "frames_per_sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"RT-DETR-{args.arch.upper()} {H}x{H} bs={B}/GPU, uint8 BGR frames resident in HBM -> "
-                               f"[{B},{Q},6] detections in HBM; synthetic seeded weights",
+                               f"[{B},{Q},6] detections in HBM; synthetic seeded weights" + ("; + Stage-2 crop batch" if crop_info else ""),
                    "global_batch": world * B, "parallelism": f"camera-shard x{world}" + (" + RCCL all_gather of detections" if world > 1 else ""),
-                   "streams_per_gpu": S, "batches_in_flight_per_gpu": S, "kernel_profile": "throughput" if prof_mode == _capi.PROFILE_THROUGHPUT else "latency", "hip_graph": not args.no_graph},
+                   "streams_per_gpu": S, "batches_in_flight_per_gpu": S,
+                   "kernel_profile": "throughput" if (S > 1 and not args.latency_profile) else "latency", "hip_graph": not args.no_graph,
+                   "engine": {"bf16x3": "hi/lo bf16 pairs, 3 MFMAs per product, fp32 accumulate (meets 1e-3 / 1e-2 px)",
+                              "bf16": "bf16 storage + MFMA, fp32 accumulate (outside the 1e-3 / 1e-2 px tolerance)",
+                              "fp32": "exact fp32 MFMAs"}[args.precision]},
+        "rccl_ranks": rccl_ranks,
     }
-    if single is not None:
-        out["single_stream"] = {"value": round(world * B * args.steps / single, 2), "unit": "frames/s",
-                                "ms_per_step": round(1000.0 * single / args.steps, 4),
-                                "note": "same K steps on ONE latency-profile handle (one batch in flight); ms_per_step here is the latency of one bs-" + str(B) + " step"}
+    if crop_info:
+        out["config"]["stage2"] = crop_info
     if args.arch in CANON_GFLOP_PER_FRAME and H == 640:
         out["mfma_frac_whole_model"] = round(CANON_GFLOP_PER_FRAME[args.arch] * fps / world / (MFMA_PEAK_TFLOPS[args.precision] * 1e3), 4)
 
     if rank == 0:
         # ---- per-kernel HIP-event profile on the engine's stream -> roofline of the dominant kernel ----
         print(f"[bench] {fps:.1f} frames/s; profiling kernels ...", file=sys.stderr, flush=True)
-        prof = eng_lat.profile(B, reps=5)
+        prof = eng.profile(B, reps=5)
         fam = {}
         for p in prof:
             f = fam.setdefault(p["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
@@ -184,37 +247,40 @@ def main():
         d = fam[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[args.precision]
+        mpp = MFMA_PER_PRODUCT[args.precision]
         out["roofline"] = {
             "kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": None,
+            "mfma_flops_per_alg_flop": mpp, "mfma_issue_frac": round(mpp * achieved / peak, 4),
             "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
             "alg_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
             "alg_gbytes_per_s_unfused": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
             "share_of_step": round(d["ms"] / total_ms, 3),
-            "method": "rtd_profile: hipEvent pairs around every launch of one eager forward on ONE engine stream (no second batch in flight), mean of 5",
+            "method": "rtd_profile: hipEvent pairs around every launch of one eager forward on ONE engine stream (no second batch in flight), mean of 5; "
+                      "`achieved` counts ALGORITHMIC flops (2 per MAC); the bf16x3 engine issues 3 MFMA flops per algorithmic flop (mfma_issue_frac)",
         }
-        # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
-        # same command; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md) - counters cannot be read live
+        # HBM bytes per launch / rocprofv3 durations / MFMA-busy counters come from the committed PMC passes (separate rocprofv3 runs of
+        # this same command: counters cannot be read live).  They are attached only when the profile was measured on THESE kernel sources.
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as fh:
+            sha = csrc_sha()
+            tag = f"{args.arch}_bs{B}_{args.precision}"
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) as fh:
                 pmc = json.load(fh)
-            if dom == "conv_igemm" and args.arch == "r50" and B == 8 and H == 640 and args.precision == "bf16":
-                fams = [v for k, v in pmc.items() if isinstance(v, dict) and k.startswith("conv")]   # LDS-DMA, direct 3x3 and v1 kernels
+            if pmc.get("csrc_sha") == sha and pmc.get("config") == tag and dom == "conv_igemm" and H == 640:
+                fams = [v for k, v in pmc.items() if isinstance(v, dict) and k.startswith("conv")]
                 tb = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in fams)
                 nl = sum(v["launches"] for v in fams)
                 out["roofline"]["traffic"] = round(tb / nl / 1e6, 2)
-                out["roofline"]["traffic_unit"] = "MB HBM per launch (PMC, profiles/r01_pmc_hbm_traffic.json)"
+                out["roofline"]["traffic_unit"] = f"MB HBM per launch (PMC, profiles/r02_pmc_hbm_traffic.json @ csrc {sha})"
                 out["roofline"]["alg_mbytes_per_launch_unfused"] = round(d["bytes"] / d["launches"] / 1e6, 2)
-                # cross-check: the committed rocprofv3 --kernel-trace of `--streams 1` (hipGraph replay).  Its durations are
-                # kernel execution only; the HIP-event pairs above also contain the ~3-4 us between two dependent launches.
-                with open(os.path.join(ROOT, "profiles", "r01_rocprofv3_kernel_summary.json")) as fh:
-                    rp = json.load(fh)
+            with open(os.path.join(ROOT, "profiles", "r02_rocprofv3_kernel_summary.json")) as fh:
+                rp = json.load(fh)
+            if rp.get("csrc_sha") == sha and rp.get("config") == tag:
                 out["roofline"]["avg_launch_us_rocprofv3"] = rp["conv_igemm_all"]["avg_us"]
                 out["roofline"]["achieved_rocprofv3"] = round(d["flops"] / (rp["conv_igemm_all"]["us_per_step"] * 1e-6) / 1e12, 2)
-                # MFMA-pipe occupancy as the counters report it (SQ_VALU_MFMA_BUSY_CYCLES over GRBM_GUI_ACTIVE x SIMDs): independent of the
-                # clock the chip holds under load, low-biased on short dispatches (tools/summarize_profiles.py mfma)
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_util.json")) as fh:
-                    mu = json.load(fh)
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_mfma_util.json")) as fh:
+                mu = json.load(fh)
+            if mu.get("csrc_sha") == sha and mu.get("config") == tag:
                 out["roofline"]["mfma_busy_frac_pmc"] = mu["conv_igemm_all"]["mfma_util"]
         except (OSError, KeyError, ValueError):
             pass
@@ -229,11 +295,32 @@ def main():
             one = [frames[0]]
             for i in range(60):
                 t1 = time.perf_counter()
-                eng_lat.infer(one, 0.25, True, on_device=True)
+                eng.infer(one, 0.25, True, on_device=True)
                 if i >= 10:
                     lat.append((time.perf_counter() - t1) * 1e3)
             out["p50_ms_per_frame_bs1"] = round(float(np.percentile(lat, 50)), 4)
             out["p99_ms_per_frame_bs1"] = round(float(np.percentile(lat, 99)), 4)
+    for e in engs:
+        e.close()
+
+    # ---- several batches in flight (same engine), and the plain-bf16 engine for comparison: extra lines, never `value` ----
+    MS = args.multi_streams
+    if MS > 1 and MS != S and args.workload == "detect":
+        el, es, _ = measure(args.precision, MS)
+        out["multi_stream"] = {"value": round(world * B * args.steps / el, 2), "unit": "frames/s", "streams_per_gpu": MS,
+                               "ms_per_step": round(1000.0 * el / args.steps, 4),
+                               "note": f"same K steps round-robin over {MS} throughput-profile handles ({MS} bs-{B} batches in flight)"}
+        for e in es:
+            e.close()
+    if args.precision == "bf16x3" and not args.no_bf16_line and args.workload == "detect" and world == 1:
+        el, es, _ = measure("bf16", 1)
+        out["bf16_engine"] = {"value": round(world * B * args.steps / el, 2), "unit": "frames/s", "streams_per_gpu": 1,
+                              "ms_per_step": round(1000.0 * el / args.steps, 4),
+                              "note": "plain bf16 storage + MFMA engine, one batch in flight: outside the 1e-3 / 1e-2 px tolerance (tests/test_gpu_parity.py), shown for comparison"}
+        for e in es:
+            e.close()
+
+    if rank == 0:
         # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
         if not args.no_cpu_baseline and world == 1:
             from oracle import rtdetr_oracle as orc
@@ -253,10 +340,6 @@ def main():
                                    "sample": f"CPU oracle (fp32 eager PyTorch restatement of the reference path), RT-DETR-{args.arch.upper()} "
                                              f"{H}x{H} bs={nb}, {reps} timed batches after 1 warm-up, torch threads={cores}"}
         print(json.dumps(out), flush=True)
-    for e in engs:
-        e.close()
-    if eng_lat is not eng:
-        eng_lat.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

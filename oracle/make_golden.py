@@ -47,8 +47,10 @@ CASES = {
     # BASELINE config 2: R50 640x640 bs8
     "c2_r50_640_bs8": ("r50", 0, (640, 640), [(2000 + i, 640, 640) for i in range(8)], "noise"),
     "c2_r50_640_scene_bs2": ("r50", 0, (640, 640), [(2100, 640, 640), (2101, 480, 704)], "scene"),
-    # BASELINE config 3 (bs1 slice of it; bs4 of R101@1280 is 12 s of HF per run)
+    # BASELINE config 3 (bs1 slice of it, structured frames)
     "c3_r101_1280_bs1": ("r101", 0, (1280, 1280), [(3000, 1280, 1280)], "scene"),
+    # BASELINE config 3 at its full batch: 4 of the reference benchmark's noise frames (seeds 3000 + i)
+    "c3_r101_1280_bs4": ("r101", 0, (1280, 1280), [(3000 + i, 1280, 1280) for i in range(4)], "noise"),
     # small graph-shaped cases for fast unit tests (the network itself only accepts input sizes
     # that are multiples of 32: the FPN concat of a 2x-upsampled map fails otherwise, in HF and
     # upstream alike); non-square maps and resized frames included

@@ -80,7 +80,7 @@ def test_fp32_engine_matches_oracle_and_golden(name):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["c2_r50_640_bs8", "c3_r101_1280_bs1"])
+@pytest.mark.parametrize("name", ["c2_r50_640_bs8", "c3_r101_1280_bs1", "c3_r101_1280_bs4"])
 def test_fp32_engine_full_size_configs_against_hf_fixtures(name):
     """BASELINE configs 2 (R50 640 bs8) and 3 (R101 1280) at full size, against the committed HF outputs only
     (the CPU oracle would need ~10 s per case on the box)."""
@@ -95,8 +95,8 @@ def test_fp32_engine_full_size_configs_against_hf_fixtures(name):
         m, n, ws, wb = match_detections(g["labels"][b], g["boxes"][b], g["scores"][b], labels[b], boxes[b], scores[b], 1e-3, 1e-2)
         print(f"{name}[{b}] matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
         miss += n - m
-        assert m >= n - 8, (m, n)          # noise frames: the K-th / K+1-th encoder scores differ by ~1e-5 (make_golden log)
-    assert miss <= 12
+        assert m >= n - 3, (m, n)          # measured 300/300 on every frame; a selection flip at the K-th / K+1-th near-tie (gap ~1e-5) may move a row
+    assert miss <= 3
     eng.close()
 
 
@@ -135,7 +135,7 @@ def test_bf16x3_engine_matches_oracle_and_golden(name):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["c2_r50_640_bs8", "c3_r101_1280_bs1"])
+@pytest.mark.parametrize("name", ["c2_r50_640_bs8", "c3_r101_1280_bs1", "c3_r101_1280_bs4"])
 def test_bf16x3_engine_full_size_configs_against_hf_fixtures(name):
     """BASELINE configs 2 (R50 640 bs8 = the benchmark frames) and 3 (R101 1280) on the default engine, hipGraph, against the
     committed HF outputs at the north-star tolerance."""
@@ -350,9 +350,70 @@ def test_bf16_engine_stagewise(name):
         m, n, ws, wb = match_detections(ol[b].numpy(), ob[b].numpy(), osc[b].numpy(), labels[b], boxes[b], scores[b], 2e-2, 2.0)
         print(f"{name}[{b}] bf16 (forced selection) matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
         tot_m += m; tot_n += n
-    assert tot_m >= 0.9 * tot_n
-    # free-running selection: report the overlap of the selected token sets
-    eng.infer_raw(frames)
+        assert n - m <= max(6, int(0.055 * n)), (b, m, n)      # measured: <= 11 of 300 (R18 / R50), <= 4 of 50 (tiny) miss at 2e-2 / 2 px; bound = 1.5x
+    assert tot_m >= 0.95 * tot_n
+    # free-running selection (what a user of precision="bf16" gets): overlap of the selected token set with the oracle's, and matched
+    # rows at the same 2e-2 / 2 px.  bf16 score noise (3.5e-2 on the encoder logits) reorders near-ties around rank Q, so some queries
+    # start from other tokens: the bounds are 1.5x the measured misses, and they are why bf16 is an opt-in, not the default engine.
+    labels, boxes, scores = eng.infer_raw(frames)
+    mx = eng.debug_tensor("enc_cls_max")[:, :, 0, 0]
+    Q = arch.num_queries
+    tot_m = tot_n = 0
+    for b in range(len(frames)):
+        mine = set(np.argsort(-mx[b], kind="stable")[:Q].tolist())
+        ref = set(col["topk"][b].numpy().tolist())
+        ov = len(mine & ref) / Q
+        m, n, ws, wb = match_detections(ol[b].numpy(), ob[b].numpy(), osc[b].numpy(), labels[b], boxes[b], scores[b], 2e-2, 2.0)
+        print(f"{name}[{b}] bf16 (free-running) token overlap {ov:.3f}, matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
+        tot_m += m; tot_n += n
+        assert ov >= 0.80, (b, ov)
+        assert m >= 0.70 * n, (b, m, n)
+    assert tot_m >= 0.75 * tot_n
+    eng.close()
+
+
+def test_bf16_engine_on_the_benchmark_frames_against_hf_fixture():
+    """precision="bf16" on BASELINE config 2's own frames (R50 640 bs8, seeds 2000-2007), free-running, against the committed HF
+    outputs: what the faster opt-in engine delivers, with the measured figures as bounds (the default bf16x3 engine is held to
+    1e-3 / 1e-2 px on the same fixture above)."""
+    arch, wseed, input_size, frames, g = load_case("c2_r50_640_bs8")
+    w = weights_for(arch, wseed)
+    eng = make_engine(arch, w, frames, input_size, "bf16", use_graph=True)
+    for _ in range(2):
+        labels, boxes, scores = eng.infer_raw(frames)
+    mx = eng.debug_tensor("enc_cls_max")[:, :, 0, 0]
+    print(f"bf16 c2_r50_640_bs8 enc score max abs err {np.abs(mx - g['enc_cls_max']).max():.2e}")
+    assert np.abs(mx - g["enc_cls_max"]).max() < 8e-2
+    tot_m = tot_n = 0
+    Q = arch.num_queries
+    for b in range(len(frames)):
+        ov = len(set(np.argsort(-mx[b], kind="stable")[:Q].tolist()) & set(g["topk"][b].tolist())) / Q
+        m, n, ws, wb = match_detections(g["labels"][b], g["boxes"][b], g["scores"][b], labels[b], boxes[b], scores[b], 2e-2, 2.0)
+        print(f"bf16 c2_r50_640_bs8[{b}] token overlap {ov:.3f}, matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
+        tot_m += m; tot_n += n
+        assert ov >= 0.80 and m >= 0.70 * n, (b, ov, m, n)
+    assert tot_m >= 0.75 * tot_n
+    eng.close()
+
+
+def test_bf16_engine_r101_1280_bs4_against_hf_fixture():
+    """BASELINE config 3 at its full batch on the bf16 engine (the bs-4 plan takes other tiles than bs 1): stage-level sanity +
+    matched rows at bf16 tolerances against the committed HF outputs."""
+    arch, wseed, input_size, frames, g = load_case("c3_r101_1280_bs4")
+    w = weights_for(arch, wseed)
+    eng = make_engine(arch, w, frames, input_size, "bf16", use_graph=True)
+    for _ in range(2):
+        labels, boxes, scores = eng.infer_raw(frames)
+    mx = eng.debug_tensor("enc_cls_max")[:, :, 0, 0]
+    print(f"bf16 c3_r101_1280_bs4 enc score max abs err {np.abs(mx - g['enc_cls_max']).max():.2e}")
+    assert np.isfinite(boxes).all() and (np.diff(scores, axis=1) <= 0).all()
+    assert np.abs(mx - g["enc_cls_max"]).max() < 0.15
+    tot_m = tot_n = 0
+    for b in range(len(frames)):
+        m, n, ws, wb = match_detections(g["labels"][b], g["boxes"][b], g["scores"][b], labels[b], boxes[b], scores[b], 2e-2, 4.0)
+        print(f"bf16 c3_r101_1280_bs4[{b}] matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
+        tot_m += m; tot_n += n
+    assert tot_m >= 0.6 * tot_n
     eng.close()
 
 
@@ -450,6 +511,7 @@ def test_fused_uint8_stem_matches_the_generic_preprocess_plus_conv():
     np.testing.assert_array_equal(out[("input", 0)], out[("input", 1)])
     for b in range(len(frames)):
         m, n, ws, wb = match_detections(out[0][0][b], out[0][1][b], out[0][2][b], out[1][0][b], out[1][1][b], out[1][2][b], 2e-2, 2.0)
+        print(f"fused stem vs generic [{b}]: matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
         assert m >= n - 30, (b, m, n, ws, wb)
 
 
@@ -483,4 +545,69 @@ def test_non_square_input_with_partial_tiles_bf16_and_fp32():
         l2, bx2, sc2 = (t[b] for t in res[_capi.PREC_BF16])
         assert np.isfinite(bx2).all() and (np.diff(sc2) <= 0).all()
         m, n, ws, wb = match_detections(l, bx, sc, l2, bx2, sc2, 3e-2, 4.0)
+        print(f"non-square bf16 vs fp32 [{b}]: matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
         assert m >= n - 60, ("bf16", b, m, n, ws, wb)
+
+
+def test_detector_keeps_working_after_the_callers_degrade_writes():
+    """src/inference_engine_yolox.py:726-748 on the real engine: `detector.input_size = ...`, `detector.device = "cpu"` and
+    `detector.model.to("cpu")` (raises, caught by the caller) - then detect, detect_batch and the pipelined pair must give what
+    they gave before (the engine stays on its GPU)."""
+    from telescope_cam_detection_amd.rtdetr_detector import RTDETRDetector
+    arch, wseed, input_size, frames, g = load_case("t_tinyb_192x128")
+    det = RTDETRDetector(config_path="tinyb", model_path=f"synthetic:tinyb:{wseed}", device="cuda:0", conf_threshold=0.1,
+                         input_size=input_size, wildlife_only=False, precision="fp32", max_batch=4)
+    assert det.load_model() is True
+    before = det.detect_batch(frames)
+    det.input_size = (96, 64)
+    det.device = "cpu"
+    with pytest.raises(RuntimeError):
+        det.model.to("cpu")
+    assert det.detect(frames[0]) == before[0]
+    assert det.detect_batch(frames) == before
+    ticket = det.detect_batch_async(frames)
+    assert det.detect_batch_collect(ticket) == before
+    x, wh = det.preprocess(frames[1])
+    assert x.is_cuda and tuple(x.shape) == (1, 3) + tuple(input_size) and wh.tolist() == [[frames[1].shape[1], frames[1].shape[0]]]
+
+
+def test_out_of_memory_surfaces_as_torch_cuda_out_of_memory_error():
+    """A batch whose activation arena cannot be allocated (R18 at 4096 x 4096, 64 frames: several hundred GB) makes the library
+    return RTD_E_OOM, which the shim re-raises as torch.cuda.OutOfMemoryError out of detect_batch - the one exception the caller's
+    recovery path handles (src/inference_engine_yolox.py:607-623).  Smaller batches keep working on the same handle afterwards."""
+    from telescope_cam_detection_amd.rtdetr_detector import RTDETRDetector
+    from telescope_cam_detection_amd.synth import scene_frame
+    det = RTDETRDetector(config_path="r18", model_path="synthetic:r18:0", device="cuda:0", conf_threshold=0.0, input_size=(4096, 4096),
+                         wildlife_only=False, precision="fp32", max_batch=64)
+    assert det.load_model(max_retries=1) is True
+    one = det.model.engine.arena_bytes()
+    free, total = torch.cuda.mem_get_info(0)
+    if one * 64 < 1.2 * total:
+        pytest.skip(f"bs-64 arena ({one * 64 / 1e9:.0f} GB) would fit this GPU ({total / 1e9:.0f} GB)")
+    small = [scene_frame(300 + i, 48, 64) for i in range(64)]
+    with pytest.raises(torch.cuda.OutOfMemoryError):
+        det.detect_batch(small)
+    got = det.detect(small[0])                                # the bs-1 plan of the same handle still runs
+    assert isinstance(got, list) and len(got) > 0
+
+
+def test_device_frames_are_ordered_after_the_stream_that_produced_them():
+    """a device-resident frame that torch has just computed on its current stream (here: a large flip + slice made
+    contiguous inside the detector) must be complete before the engine's own non-blocking stream reads it."""
+    from telescope_cam_detection_amd.rtdetr_detector import RTDETRDetector
+    from telescope_cam_detection_amd.synth import scene_frame
+    det = RTDETRDetector(config_path="tinyb", model_path="synthetic:tinyb:2", device="cuda:0", conf_threshold=0.05, input_size=(192, 128),
+                         wildlife_only=False, precision="fp32", max_batch=2)
+    assert det.load_model() is True
+    big = scene_frame(400, 1500, 2000)
+    want = det.detect(np.ascontiguousarray(big[::-1, 100:1900]))
+    assert len(want) > 0
+    dev = torch.from_numpy(big).cuda()
+    torch.cuda.synchronize()
+    for _ in range(5):
+        filler = [torch.empty(64 << 20, device="cuda").normal_() for _ in range(4)]   # keeps torch's stream busy ahead of the producer ops
+        view = dev.flip(0)[:, 100:1900]                                             # flip kernel + non-contiguous slice -> .contiguous() on torch's stream
+        assert det.detect(view) == want
+        t = det.detect_batch_async([view])
+        assert det.detect_batch_collect(t) == [want]
+        del filler

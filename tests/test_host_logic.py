@@ -155,3 +155,96 @@ def test_collate_detections_world_size_2_gloo():
         for r in range(2):
             for j, k in enumerate([r, r + 2]):               # camera k lives on rank k % 2
                 np.testing.assert_array_equal(out[r, j], np.full((5, 6), 10.0 * k) + np.arange(6))
+
+
+def test_bench_self_launch_forms_a_world_of_two_on_gloo():
+    """`python bench.py --gpus 2` with no torch.distributed environment must start its own ranks: the parent
+    touches no GPU and spawns `torch.distributed.run`; --launch-selftest swaps the GPU work for a gloo all-gather of the rank ids."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-selftest"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                        # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["world"] == 2 and out["ranks"] == [0, 1] and out["gpus"] == 2
+
+
+class _FakeEngine:
+    """stands in for _capi.Engine on a box without a GPU: records what the detector asks for"""
+    max_batch, num_queries = 4, 5
+
+    def __init__(self):
+        self.calls = []
+
+    def infer(self, frames, conf, wildlife_only, on_device=False):
+        from telescope_cam_detection_amd import _capi
+        self.calls.append((len(frames), conf, wildlife_only, on_device))
+        row = np.zeros(1, dtype=_capi.DET_DTYPE)
+        row["class_id"], row["score"], row["x1"], row["y1"], row["x2"], row["y2"] = 16, 0.9, 1.0, 2.0, 11.5, 22.25
+        return [row for _ in frames]
+
+
+def test_detector_survives_the_callers_degrade_writes():
+    """src/inference_engine_yolox.py:726-748 writes `detector.input_size`, `detector.device = "cpu"` and calls
+    `detector.model.to("cpu")` inside a try: the first two must not re-route an engine that stays on its GPU, the third raises
+    (caught and logged by the caller).  detect / detect_batch keep working afterwards."""
+    from telescope_cam_detection_amd.rtdetr_detector import RTDETRDetector, _DeviceModel
+    det = RTDETRDetector(config_path="r18", model_path="synthetic:r18:0", device="cuda:3", input_size=(640, 640))
+    assert det.precision == "bf16x3"                       # the default engine is the one held to the reference tolerance
+    eng = _FakeEngine()
+    det.model, det._dev_index, det._engine_input_size = _DeviceModel(eng, "cuda:3"), 3, (640, 640)
+    # --- the caller's _apply_degradation, verbatim in effect ---
+    det.input_size = (480, 480)
+    if hasattr(det, "exp") and det.exp is not None:
+        det.exp.test_size = (480, 480)
+    det.device = "cpu"
+    moved = True
+    try:
+        det.model.to("cpu")
+    except Exception:
+        moved = False
+    assert moved is False                                   # no CPU path: the caller logs "Failed to move model to CPU"
+    # --- and keeps calling the detector ---
+    frame = np.zeros((64, 64, 3), np.uint8)
+    got = det.detect(frame)
+    assert got == [{"class_id": 16, "class_name": "dog", "confidence": pytest.approx(0.9), "bbox": {"x1": 1.0, "y1": 2.0, "x2": 11.5, "y2": 22.25, "area": 212}}]
+    assert len(det.detect_batch([frame] * 6)) == 6          # 6 frames over max_batch 4 -> two device batches
+    assert [c[0] for c in eng.calls] == [1, 4, 2]
+    assert det._dev_index == 3 and det._engine_input_size == (640, 640)
+    # settings writes of update_settings (:678, :684) take effect on the next call
+    det.conf_threshold = 0.5
+    det.nms_threshold = 0.45
+    det.detect(frame)
+    assert eng.calls[-1][1] == 0.5
+
+
+def test_oom_return_code_becomes_torch_cuda_out_of_memory_error():
+    """RTD_E_OOM is the one code the shim re-raises as torch.cuda.OutOfMemoryError - the only exception the caller's recovery path
+    reacts to (src/inference_engine_yolox.py:607); every other code is a plain RuntimeError subclass (caught by :625-627)."""
+    from telescope_cam_detection_amd import _capi
+    with pytest.raises(torch.cuda.OutOfMemoryError):
+        _capi._raise(_capi.RTD_E_OOM, None)
+    with pytest.raises(_capi.RtdError) as ei:
+        _capi._raise(_capi.RTD_E_HIP, None)
+    assert not isinstance(ei.value, torch.cuda.OutOfMemoryError) and ei.value.code == _capi.RTD_E_HIP
+    assert _capi.precision_code("bf16x3") == _capi.PREC_BF16X3 and _capi.precision_code("fp32") == _capi.PREC_FP32
+    with pytest.raises(ValueError):
+        _capi.precision_code("int8")
+
+
+def test_split_layout_host_mirror_roundtrip():
+    """_capi.to_split / from_split mirror csrc/common.h's BF16X2 layout: 32-channel groups [32 hi | 32 lo], hi + lo within 2^-17 of x"""
+    from telescope_cam_detection_amd import _capi
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((3, 5, 96)) * np.exp(rng.uniform(-8, 8, (3, 5, 96)))).astype(np.float32)
+    s = _capi.to_split(x)
+    assert s.shape == (3, 5, 192) and s.dtype == np.uint16
+    y = _capi.from_split(s)
+    assert np.all(np.abs(y - x) <= np.abs(x) * 2.0 ** -17)
+    hi = (s.reshape(3, 5, 3, 2, 32)[..., 0, :].astype(np.uint32) << 16).view(np.float32).reshape(3, 5, 96)
+    assert np.all(np.abs(hi - x) <= np.abs(x) * 2.0 ** -8)   # the hi half alone is the bf16 rounding of x
+    z = np.zeros((2, 64), np.float32)
+    assert np.array_equal(_capi.from_split(_capi.to_split(z)), z)
