@@ -7,10 +7,10 @@ type (/root/reference/main.py:793-797), although its `SharedInferenceCoordinator
 
 * builds the coordinator's detector from the reference's own config keys (`detection.rtdetr.*`,
   `detection.batching.*`, config/config.yaml:74,90-99,130-135,511-517), and
-* supplies `BatchCoordinator`, a host-side mirror of the reference coordinator's interface and behaviour
-  (`start/stop`, `infer_async(frame, callback, camera_id)`, drop-oldest at `max_queue_depth` with
-  `callback([])`, every callback gets `[]` when the batch raises, `get_stats()` keys), used when the
-  reference package is not importable, and
+* supplies `BatchCoordinator`, this build's own batcher - a depth-N pipeline of detector lanes (N batches in flight, results in
+  submission order; N = 1 is the plain case) behind the surface the unchanged callers use (`start/stop`,
+  `infer_async(frame, callback, camera_id)`, `get_stats()` keys; evicted / failed / never-run frames are answered with []) -
+  used for pipeline_depth > 1 and whenever the reference package is not importable, and
 * `install(system_cls)`: the three-line hook a maintainer adds so `main.py` stays untouched.
 
 The engines (src/inference_engine_yolox.py:341-350) call `coordinator.infer_async(frame, callback, camera_id)`
@@ -27,77 +27,154 @@ from typing import Any, Callable, Dict, List, Optional
 logger = logging.getLogger(__name__)
 
 
-class _Request:
-    __slots__ = ("frame", "callback", "enqueue_time", "camera_id")
+class _Ask:
+    """one frame waiting for its answer"""
+    __slots__ = ("frame", "answer", "t_in", "camera_id")
 
-    def __init__(self, frame, callback, camera_id):
-        self.frame = frame
-        self.callback = callback
-        self.enqueue_time = time.time()
-        self.camera_id = camera_id
+    def __init__(self, frame, answer, camera_id):
+        self.frame, self.answer, self.camera_id = frame, answer, camera_id
+        self.t_in = time.monotonic()
+
+    def reply(self, detections) -> None:
+        try:
+            self.answer(detections)
+        except Exception as e:                       # a camera's callback must never take the pipeline down
+            logger.error(f"result callback of camera {self.camera_id} raised: {e}")
+
+
+class _Inbox:
+    """Bounded FIFO between the camera threads and the batch former.  Full -> the OLDEST ask is evicted and handed back to the
+    caller (who answers it with []): stale frames lose, like the reference's queue (src/shared_inference_coordinator.py:149-164)."""
+
+    def __init__(self, depth: int):
+        self.depth = depth
+        self._q: deque = deque()
+        self._cv = threading.Condition()
+        self.closed = False
+
+    def put(self, ask: _Ask) -> Optional[_Ask]:
+        with self._cv:
+            evicted = self._q.popleft() if len(self._q) >= self.depth else None
+            self._q.append(ask)
+            self._cv.notify()
+        return evicted
+
+    def take(self, limit: int, patience: float) -> List[_Ask]:
+        """Block for the first ask, then gather up to `limit`, waiting at most `patience` seconds for stragglers."""
+        with self._cv:
+            while not self._q and not self.closed:
+                self._cv.wait(0.1)
+            if self.closed:
+                return []
+            got = [self._q.popleft()]
+            t_end = time.monotonic() + patience
+            while len(got) < limit:
+                if self._q:
+                    got.append(self._q.popleft())
+                    continue
+                left = t_end - time.monotonic()
+                if left <= 0 or self.closed:
+                    break
+                self._cv.wait(left)
+            return got
+
+    def close(self) -> List[_Ask]:
+        with self._cv:
+            self.closed = True
+            rest = list(self._q)
+            self._q.clear()
+            self._cv.notify_all()
+        return rest
+
+    def reopen(self) -> None:
+        with self._cv:
+            self.closed = False
+
+    def __len__(self):
+        return len(self._q)
+
+
+class _Lane:
+    """One detector of the pipeline.  `begin` hands it a batch, `finish` returns that batch's results; a lane holds at most one batch.
+    Detectors with the pipelined pair (RTDETRDetector.detect_batch_async / detect_batch_collect: the work runs on the detector's own
+    HIP stream between the two calls) overlap with the other lanes; a plain `detect_batch` object simply does its work in `finish`."""
+
+    def __init__(self, detector: Any):
+        self.detector = detector
+        self.idle = threading.Semaphore(1)
+        self._overlapped = hasattr(detector, "detect_batch_async") and hasattr(detector, "detect_batch_collect")
+        self._held = None
+
+    def begin(self, frames: list) -> None:
+        self._held = self.detector.detect_batch_async(frames) if self._overlapped else frames
+
+    def finish(self) -> list:
+        held, self._held = self._held, None
+        return self.detector.detect_batch_collect(held) if self._overlapped else self.detector.detect_batch(held)
 
 
 class BatchCoordinator:
-    """Same constructor arguments, methods and stats keys as the reference's SharedInferenceCoordinator
-    (src/shared_inference_coordinator.py:27-338)."""
+    """Cross-camera batcher as a depth-N pipeline: N lanes (detectors), a former thread that cuts batches out of the inbox and starts
+    them on the next idle lane, a finisher thread that completes batches in submission order and answers the callbacks.  N = 1 with a
+    plain detector is the degenerate case - the reference's SharedInferenceCoordinator behaviour - on the same code path.
+
+    Surface the unchanged callers rely on (src/inference_engine_yolox.py:341-350, main.py:770-838): the constructor keywords,
+    `start/stop`, `infer_async(frame, callback, camera_id)`, `get_stats()` keys, `max_batch_size`, `max_batch_wait_ms` (seconds),
+    `dropped_frames`; every callback is answered exactly once - with [] when its frame was evicted, its batch raised, or the
+    coordinator stopped before it ran."""
 
     def __init__(self, detector: Any, max_batch_size: int = 4, max_batch_wait_ms: float = 10.0,
                  enable_metrics: bool = True, max_queue_depth: int = 60, extra_detectors: Optional[List[Any]] = None):
         self.detector = detector
-        # pipeline (not in the reference): with extra detectors (same model, own HIP stream each) batches are submitted
-        # round-robin through `detect_batch_async` and finished by a second thread, so len(detectors) batches are in flight
         self.detectors: List[Any] = [detector] + list(extra_detectors or [])
-        self._inflight: deque = deque()
-        self._inflight_cv = threading.Condition()
-        self._free = [threading.Semaphore(1) for _ in self.detectors]
-        self._next = 0
-        self.completion_thread: Optional[threading.Thread] = None
         self.max_batch_size = int(max_batch_size)
-        self.max_batch_wait_ms = max_batch_wait_ms / 1000.0          # seconds, like the reference attribute
+        self.max_batch_wait_ms = max_batch_wait_ms / 1000.0          # seconds (the reference keeps the converted value under this name)
         self.enable_metrics = enable_metrics
         self.max_queue_depth = int(max_queue_depth)
-        self.pending_queue: deque = deque()
-        self.queue_lock = threading.Lock()
-        self.queue_condition = threading.Condition(self.queue_lock)
-        self.coordinator_thread: Optional[threading.Thread] = None
-        self.stop_event = threading.Event()
         self.running = False
+        self.dropped_frames = 0
+        self._inbox = _Inbox(self.max_queue_depth)
+        self._lanes = [_Lane(d) for d in self.detectors]
+        self._flying: deque = deque()                                # (lane, asks, t_begin) in submission order
+        self._flying_cv = threading.Condition()
+        self._threads: List[threading.Thread] = []
+        # meter
         self.total_batches = 0
         self.total_frames = 0
         self.total_batch_time_ms = 0.0
-        self.dropped_frames = 0
         self.batch_sizes: deque = deque(maxlen=1000)
         self.wait_times_ms: deque = deque(maxlen=1000)
 
-    # ---- lifecycle
+    @property
+    def pending_queue(self):                                         # len() of it is read by stats pages
+        return self._inbox._q
+
+    # ---- lifecycle ------------------------------------------------------------------------------------
     def start(self):
         if self.running:
-            logger.warning("Coordinator already running")
+            logger.warning("batch coordinator: start() on a running instance ignored")
             return
         self.running = True
-        self.stop_event.clear()
-        self.coordinator_thread = threading.Thread(target=self._coordinator_loop, name="InferenceCoordinator", daemon=True)
-        self.coordinator_thread.start()
-        if len(self.detectors) > 1:
-            self.completion_thread = threading.Thread(target=self._completion_loop, name="InferenceCompletion", daemon=True)
-            self.completion_thread.start()
+        self._inbox.reopen()
+        self._threads = [threading.Thread(target=self._form, name="BatchFormer", daemon=True),
+                         threading.Thread(target=self._finish, name="BatchFinisher", daemon=True)]
+        for t in self._threads:
+            t.start()
 
     def stop(self):
         if not self.running:
             return
         self.running = False
-        self.stop_event.set()
-        with self.queue_condition:
-            self.queue_condition.notify_all()
-        if self.coordinator_thread:
-            self.coordinator_thread.join(timeout=2.0)
-            if self.coordinator_thread.is_alive():
-                logger.warning("Coordinator thread did not stop cleanly")
-        if self.completion_thread:
-            with self._inflight_cv:
-                self._inflight_cv.notify_all()
-            self.completion_thread.join(timeout=5.0)
-            self.completion_thread = None
+        leftovers = self._inbox.close()                              # nobody will run these: answer them now
+        with self._flying_cv:
+            self._flying_cv.notify_all()
+        for t in self._threads:
+            t.join(timeout=5.0)
+            if t.is_alive():
+                logger.warning(f"batch coordinator: thread {t.name} still busy after stop()")
+        self._threads = []
+        for ask in leftovers:
+            ask.reply([])
 
     def __enter__(self):
         self.start()
@@ -106,142 +183,77 @@ class BatchCoordinator:
     def __exit__(self, *exc):
         self.stop()
 
-    # ---- producer side (camera engine threads)
+    # ---- camera side ----------------------------------------------------------------------------------
     def infer_async(self, frame: Any, callback: Callable[[List[Dict[str, Any]]], None], camera_id: Optional[str] = None):
         if not self.running:
-            raise RuntimeError("Coordinator not running - call start() first")
-        req = _Request(frame, callback, camera_id)
-        dropped = None
-        with self.queue_condition:
-            if len(self.pending_queue) >= self.max_queue_depth:      # overloaded: drop the OLDEST request
-                dropped = self.pending_queue.popleft()
-                self.dropped_frames += 1
-            self.pending_queue.append(req)
-            self.queue_condition.notify()
-        if dropped is not None:
+            raise RuntimeError("batch coordinator is stopped: start() it before infer_async()")
+        evicted = self._inbox.put(_Ask(frame, callback, camera_id))
+        if evicted is not None:
+            self.dropped_frames += 1
             if self.dropped_frames % 10 == 0:
-                logger.warning(f"Inference queue full - dropped {self.dropped_frames} frames total")
-            try:
-                dropped.callback([])                                   # its owner still gets an answer
-            except Exception:
-                pass
+                logger.warning(f"batch coordinator overloaded: {self.dropped_frames} frames evicted so far")
+            evicted.reply([])
 
-    # ---- consumer side
-    def _collect_batch(self) -> List[_Request]:
-        batch: List[_Request] = []
-        with self.queue_condition:
-            while not self.pending_queue and not self.stop_event.is_set():
-                self.queue_condition.wait(timeout=0.1)
-            if self.stop_event.is_set():
-                return []
-            deadline = time.time() + self.max_batch_wait_ms
-            while len(batch) < self.max_batch_size:
-                if self.pending_queue:
-                    batch.append(self.pending_queue.popleft())
-                    continue
-                remaining = deadline - time.time()
-                if remaining <= 0 or self.stop_event.is_set():
-                    break
-                self.queue_condition.wait(timeout=remaining)           # a little patience for a fuller batch
-        return batch
-
-    # ---- pipelined path: submit here, finish in _completion_loop (results reach the callbacks in submission order)
-    def _submit_batch(self, batch: List[_Request]):
-        if not batch:
-            return
-        t_start = time.time()
-        if self.enable_metrics:
-            for r in batch:
-                self.wait_times_ms.append((t_start - r.enqueue_time) * 1000)
-        k = self._next
-        self._next = (k + 1) % len(self.detectors)
-        self._free[k].acquire()                                     # that detector's previous batch has been collected
-        try:
-            ticket = self.detectors[k].detect_batch_async([r.frame for r in batch])
-        except Exception as e:
-            self._free[k].release()
-            logger.error(f"Error submitting batch: {e}", exc_info=True)
-            self._fail(batch)
-            return
-        with self._inflight_cv:
-            self._inflight.append((k, ticket, batch, t_start))
-            self._inflight_cv.notify()
-
-    def _fail(self, batch: List[_Request]):
-        for r in batch:
-            try:
-                r.callback([])
-            except Exception as cb_error:
-                logger.error(f"Error calling callback on error: {cb_error}")
-
-    def _completion_loop(self):
-        while True:
-            with self._inflight_cv:
-                while not self._inflight and not self.stop_event.is_set():
-                    self._inflight_cv.wait(timeout=0.1)
-                if not self._inflight:
-                    return                                          # stopped and drained
-                k, ticket, batch, t_start = self._inflight.popleft()
-            try:
-                results = self.detectors[k].detect_batch_collect(ticket)
-            except Exception as e:
-                logger.error(f"Error processing batch: {e}", exc_info=True)
-                self._fail(batch)
+    # ---- pipeline -------------------------------------------------------------------------------------
+    def _form(self):
+        turn = 0
+        while self.running:
+            asks = self._inbox.take(self.max_batch_size, self.max_batch_wait_ms)
+            if not asks:
                 continue
-            finally:
-                self._free[k].release()
-            elapsed_ms = (time.time() - t_start) * 1000
-            for r, dets in zip(batch, results):
-                try:
-                    r.callback(dets)
-                except Exception as e:
-                    logger.error(f"Error in callback for camera {r.camera_id}: {e}")
+            lane = self._lanes[turn]
+            turn = (turn + 1) % len(self._lanes)
+            lane.idle.acquire()                                      # its previous batch has been finished
+            t_begin = time.monotonic()
             if self.enable_metrics:
-                self.total_batches += 1
-                self.total_frames += len(batch)
-                self.total_batch_time_ms += elapsed_ms
-                self.batch_sizes.append(len(batch))
-
-    def _process_batch(self, batch: List[_Request]):
-        if not batch:
-            return
-        if len(self.detectors) > 1:
-            return self._submit_batch(batch)
-        t_start = time.time()
-        if self.enable_metrics:
-            for r in batch:
-                self.wait_times_ms.append((t_start - r.enqueue_time) * 1000)
-        try:
-            results = self.detector.detect_batch([r.frame for r in batch])
-            elapsed_ms = (time.time() - t_start) * 1000
-            for r, dets in zip(batch, results):
-                try:
-                    r.callback(dets)
-                except Exception as e:
-                    logger.error(f"Error in callback for camera {r.camera_id}: {e}")
-            if self.enable_metrics:
-                self.total_batches += 1
-                self.total_frames += len(batch)
-                self.total_batch_time_ms += elapsed_ms
-                self.batch_sizes.append(len(batch))
-        except Exception as e:
-            logger.error(f"Error processing batch: {e}", exc_info=True)
-            for r in batch:
-                try:
-                    r.callback([])
-                except Exception as cb_error:
-                    logger.error(f"Error calling callback on error: {cb_error}")
-
-    def _coordinator_loop(self):
-        while not self.stop_event.is_set():
+                self.wait_times_ms.extend((t_begin - a.t_in) * 1000.0 for a in asks)
             try:
-                self._process_batch(self._collect_batch())
-            except Exception as e:                                     # never let the thread die
-                logger.error(f"Error in coordinator loop: {e}", exc_info=True)
+                lane.begin([a.frame for a in asks])
+            except Exception as e:
+                lane.idle.release()
+                logger.error(f"batch coordinator: could not start a batch of {len(asks)}: {e}", exc_info=True)
+                for a in asks:
+                    a.reply([])
+                continue
+            with self._flying_cv:
+                self._flying.append((lane, asks, t_begin))
+                self._flying_cv.notify()
+
+    def _finish(self):
+        while True:
+            with self._flying_cv:
+                while not self._flying and self.running:
+                    self._flying_cv.wait(0.1)
+                if not self._flying:
+                    if self._threads and self._threads[0].is_alive():   # stopping: the former may still be handing over its last batch
+                        self._flying_cv.wait(0.02)
+                        continue
+                    return
+                lane, asks, t_begin = self._flying.popleft()
+            try:
+                results = lane.finish()
+                if len(results) != len(asks):
+                    raise RuntimeError(f"detector returned {len(results)} results for {len(asks)} frames")
+            except Exception as e:
+                logger.error(f"batch coordinator: batch of {len(asks)} failed: {e}", exc_info=True)
+                results = [[] for _ in asks]
+                failed = True
+            else:
+                failed = False
+            finally:
+                lane.idle.release()
+            for a, dets in zip(asks, results):
+                a.reply(dets)
+            if self.enable_metrics and not failed:
+                self.total_batches += 1
+                self.total_frames += len(asks)
+                self.total_batch_time_ms += (time.monotonic() - t_begin) * 1000.0
+                self.batch_sizes.append(len(asks))
 
     def get_stats(self) -> Dict[str, Any]:
         if not self.enable_metrics or self.total_batches == 0:
             return {"enabled": False, "total_batches": 0, "total_frames": 0}
+        busy_s = self.total_batch_time_ms / 1000.0
         return {
             "enabled": True,
             "total_batches": self.total_batches,
@@ -249,8 +261,8 @@ class BatchCoordinator:
             "avg_batch_size": round(sum(self.batch_sizes) / len(self.batch_sizes), 2),
             "avg_batch_time_ms": round(self.total_batch_time_ms / self.total_batches, 2),
             "avg_wait_time_ms": round(sum(self.wait_times_ms) / len(self.wait_times_ms), 2) if self.wait_times_ms else 0,
-            "throughput_fps": round(self.total_frames / (self.total_batch_time_ms / 1000), 1) if self.total_batch_time_ms > 0 else 0,
-            "queue_depth": len(self.pending_queue),
+            "throughput_fps": round(self.total_frames / busy_s, 1) if busy_s > 0 else 0,
+            "queue_depth": len(self._inbox),
         }
 
 

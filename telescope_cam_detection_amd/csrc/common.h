@@ -133,6 +133,7 @@ void conv_set_ws64_max_blocks(int v);
 void conv_set_wsa_min_ntn(int v);
 void conv_set_prefetch(int v);      // A/B hook: 0 = launches ignore ConvArgs::pf
 void conv_set_mode(int v);          // A/B hook: 0 auto, 1 = v1 only, 2 = v1 + v2 (no LDS-DMA kernel)
+void conv_reset_options();          // every conv dispatch switch back to its default (rtd_debug_option "reset")
 
 void launch_layernorm(const Tensor& x, const Tensor* res, const float* g, const float* b, const Tensor& y,
                       float eps, hipStream_t s);

@@ -2723,6 +2723,12 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
   HIP_CHECK(hipGetLastError());
 }
 
+void conv_reset_options() {
+  g_glds_min_blocks = 4; g_splitk_enable = 0; g_glds_drop = 0; g_conv_mode = 0; g_force_v1 = 0; g_ws256_min_blocks = 0; g_glds_min_n = 128;
+  g_wsa_min_ntn = 8; g_ws2_min_blocks = 257; g_reg_epilogue = 1; g_ws64_max_blocks = 160; g_prefetch = 1; g_conv_reg = 1; g_conv_stream = 1;
+  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160;
+}
+
 void launch_conv(const ConvArgs& a, hipStream_t s) {
   const Tensor& x = a.x;
   const Tensor& y = a.y;

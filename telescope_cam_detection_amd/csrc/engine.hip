@@ -25,21 +25,25 @@ void launch_force_idx(int32_t* dst, const int32_t* src, const int32_t* flag, int
 namespace {
 
 thread_local std::string g_create_error;
-int g_dec_stamps = 0;  // plan-build switch: record per-phase stamps of decoder layer 2 into debug tensor "dec_stamps"
-int g_dec_split = 1;   // plan-build switch (rtd_debug_option "dec_split"): bf16 engine runs the fused decoder / AIFI linears as bf16 hi/lo splits
-int g_sc_fold = 1;     // plan-build switch (rtd_debug_option "sc_fold"): bf16 plans fold a block's projection shortcut into its last conv (ConvArgs::x2)
-int g_c1_fuse = 1;     // plan-build switch (rtd_debug_option "c1_fuse"): bf16 plans run a stage-0 block's reduce conv inside the previous block's last conv
-// plan-build switch (rtd_debug_option "attn_split"): the bf16 engine's self-attention on hi/lo bf16 MFMAs - bit 0 AIFI, bit 1 decoder.  Default: decoder
-// only (logits agree with the fp32-MFMA attention to 1e-6).  In AIFI the softmax arguments reach tens and the 2^-16 product error becomes 1.7e-4 on the
-// layer output: harmless next to the bf16 conv stack, but that layer stays on fp32 MFMAs (10 us per step)
-int g_attn_split = 2;
-int g_up_fold = 1;     // plan-build switch (rtd_debug_option "up_fold"): bf16 plans read the FPN's upsampled lateral straight from the half-size tensor
-int g_arena_reuse = 1; // plan-build switch (rtd_debug_option "arena_reuse"): backbone stages recycle their activation buffers
-int g_stem_fused = 0;  // plan-build switch (rtd_debug_option "stem_fused"): bf16 engine runs backbone.stem.0 straight from the uint8 frames.
-                       // Measured neutral (same-box A/B: +0.2 % / 0 %: the kernel is latency-bound at 44 us against 56 + 20 us of
-                       // preprocess + generic stem) -> off by default, kept tested
-int g_sel_fused = 1;   // plan-build switch (rtd_debug_option "sel_fused"): LayerNorm + score head + class max of the query selection in one launch
-int g_dec_fused = 1;   // plan-build switch (rtd_debug_option "dec_fused"): 0 = one launch per decoder op
+// Plan-build switches (rtd_debug_option): process-wide defaults that every handle SNAPSHOTS at rtd_create (rtd_engine::opts), so all
+// plans of a handle (one per batch size, built lazily) agree with each other and a later rtd_debug_option call - e.g. by another
+// test - cannot change a live handle.
+struct PlanOpts {
+  int dec_stamps = 0;   // record per-phase stamps of decoder layer 2 into debug tensor "dec_stamps"
+  int dec_split = 1;    // bf16 / bf16x3 engines run the fused decoder / AIFI linears as bf16 hi/lo splits (0: fp32 MFMA, 2: bf16 filters)
+  int sc_fold = 1;      // fold a block's projection shortcut into its last conv (ConvArgs::x2)
+  int c1_fuse = 1;      // bf16 plans run a stage-0 block's reduce conv inside the previous block's last conv
+  // self-attention on hi/lo bf16 MFMAs - bit 0 AIFI, bit 1 decoder.  Default: decoder only (logits agree with the fp32-MFMA attention
+  // to 1e-6).  In AIFI the softmax arguments reach tens and the 2^-16 product error becomes 1.7e-4 on the layer output: that layer
+  // stays on fp32 MFMAs (10 us per step)
+  int attn_split = 2;
+  int up_fold = 1;      // read the FPN's upsampled lateral straight from the half-size tensor (ConvArgs::x_up2)
+  int arena_reuse = 1;  // backbone stages recycle their activation buffers
+  int stem_fused = 0;   // bf16 engine runs backbone.stem.0 straight from the uint8 frames (measured neutral -> off, kept tested)
+  int sel_fused = 1;    // LayerNorm + score head + class max of the query selection in one launch
+  int dec_fused = 1;    // 0 = one launch per decoder op
+};
+PlanOpts g_opts;
 
 struct HostTensor {
   const float* data = nullptr;
@@ -62,6 +66,7 @@ struct Op {
   const char* kernel;
   double flops, bytes;
   std::function<void(hipStream_t)> run;
+  bool debug_only = false;   // runs (and is captured) only on handles that asked for it (rtd_debug_force_topk)
 };
 
 struct Plan {
@@ -89,6 +94,8 @@ struct ResizeTables {
 
 struct rtd_engine {
   rtd_config cfg;
+  PlanOpts opts;           // snapshot of g_opts at rtd_create
+  bool force_used = false; // rtd_debug_force_topk was called on this handle: plans include the (debug-only) index override launch
   std::mutex mu;
   std::string err;
   hipStream_t stream = nullptr;
@@ -448,7 +455,7 @@ struct Builder {
   }
   void push(const std::string& name, const char* kernel, double flops, double bytes, std::function<void(hipStream_t)> f) {
     if (dry) return;
-    plan->ops.push_back(Op{name, kernel, flops, bytes, std::move(f)});
+    plan->ops.push_back(Op{name, kernel, flops, bytes, std::move(f), false});
   }
   static double tbytes(const Tensor& t) { return (double)t.pixels() * t.c * dtype_size(t.dt); }
 
@@ -535,7 +542,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   const int eh = c.embedding_size / 2;
   int h = down2(H), w = down2(W);
   Tensor s0 = B.act(P, n, h, w, eh);
-  plan->stem_fused = g_stem_fused && P == BF16 && eh == 32;
+  plan->stem_fused = e->opts.stem_fused && P == BF16 && eh == 32;
   if (plan->stem_fused) {
     // straight from the uint8 frames (ops.hip stem0_u8_kernel); `x` is only materialised on demand for rtd_debug_tensor("input")
     const uint8_t** table = (const uint8_t**)B.alloc((size_t)c.max_batch * sizeof(void*));
@@ -568,7 +575,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     // share one buffer each.  Fewer distinct lines means more of a stage lives in L2 + the 256 MB Infinity Cache, and dead
     // activations are overwritten in cache instead of being written back to HBM.
     Tensor pp[2], tb1, tb2;
-    if (g_arena_reuse) {
+    if (e->opts.arena_reuse) {
       const int s0 = (si > 0) ? 2 : 1;
       const int oh0 = s0 == 2 ? down2(h) : h, ow0 = s0 == 2 ? down2(w) : w;
       pp[0] = B.act(P, n, oh0, ow0, cout);
@@ -610,7 +617,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
                  [cur, pooled](hipStream_t s) { launch_avgpool2(cur, pooled, s); });
           sc_in = pooled;
         }
-        if ((P == BF16 || SP) && g_sc_fold) {
+        if ((P == BF16 || SP) && e->opts.sc_fold) {
           // shapes only: would the kernels take the folded launch?  Asked for ONE image whatever this plan's batch: every plan
           // of an engine must use the same filters (the host copies are dropped after the first plan) and the same arithmetic
           // (batch invariance), and a single image has the smallest grid
@@ -627,19 +634,19 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
           B.conv(pfx + ".sc", sc_in, res, 1, 1, 0, ACT_NONE);
         }
       }
-      Tensor out = g_arena_reuse ? view(pp[bi & 1], oh, ow, cout, oname) : B.act(P, n, oh, ow, cout, oname);
+      Tensor out = e->opts.arena_reuse ? view(pp[bi & 1], oh, ow, cout, oname) : B.act(P, n, oh, ow, cout, oname);
       if (c.layer_type == RTD_LAYER_BOTTLENECK) {
         // the c1 output of this block: with recycled buffers it is the stage's shared temporary, which the PREVIOUS block's last conv
         // may already have filled (ConvArgs::next_*: the reduce conv fused into the expand conv that produced its input)
-        Tensor t1 = g_arena_reuse ? view(tb1, h, w, mid, "") : (c1_done ? t1_next : B.act(P, n, h, w, mid));
+        Tensor t1 = e->opts.arena_reuse ? view(tb1, h, w, mid, "") : (c1_done ? t1_next : B.act(P, n, h, w, mid));
         if (!c1_done) B.conv(pfx + ".c1", cur, t1, 1, 1, 0, ACT_RELU);
         c1_done = false;
-        Tensor t2 = g_arena_reuse ? view(tb2, oh, ow, mid, "") : B.act(P, n, oh, ow, mid);
+        Tensor t2 = e->opts.arena_reuse ? view(tb2, oh, ow, mid, "") : B.act(P, n, oh, ow, mid);
         B.conv(pfx + ".c2", t1, t2, 3, stride, 1, ACT_RELU);
         // fuse the NEXT block's c1 (same stage: stride 1, same extents, reads `out`) when the streaming kernel takes this conv
         const Tensor* nx = nullptr;
         std::string nx_name;
-        if (P == BF16 && g_c1_fuse && bi + 1 < c.depths[si]) {
+        if (P == BF16 && e->opts.c1_fuse && bi + 1 < c.depths[si]) {
           Tensor t1_shape = out; t1_shape.c = t1_shape.ld = mid; t1_shape.bstride = (int64_t)oh * ow * mid;
           ConvArgs probe;                                        // this plan's shapes (fused and separate launches are bit-identical)
           probe.x = t2; probe.x.p = (void*)16;
@@ -648,14 +655,14 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
           else { probe.res = res; probe.res.p = (void*)16; probe.res_mode = RES_PRE; }
           probe.next_y = t1_shape; probe.next_y.p = (void*)16;
           if (conv_next_supported(probe)) {
-            t1_next = g_arena_reuse ? view(tb1, oh, ow, mid, "") : B.act(P, n, oh, ow, mid);
+            t1_next = e->opts.arena_reuse ? view(tb1, oh, ow, mid, "") : B.act(P, n, oh, ow, mid);
             nx = &t1_next; nx_name = nm("backbone.s%d.b%d", si, bi + 1) + ".c1"; c1_done = true;
           }
         }
         if (fold_sc) B.conv(pfx + ".c3", t2, out, 1, 1, 0, ACT_RELU, nullptr, RES_NONE, 0, &sc_in, pfx + ".sc", 0, nx, nx_name, ACT_RELU);
         else B.conv(pfx + ".c3", t2, out, 1, 1, 0, ACT_RELU, &res, RES_PRE, 0, nullptr, "", 0, nx, nx_name, ACT_RELU);
       } else {
-        Tensor t1 = g_arena_reuse ? view(tb1, oh, ow, cout, "") : B.act(P, n, oh, ow, cout);
+        Tensor t1 = e->opts.arena_reuse ? view(tb1, oh, ow, cout, "") : B.act(P, n, oh, ow, cout);
         B.conv(pfx + ".c1", cur, t1, 3, stride, 1, ACT_RELU);
         if (fold_sc) B.conv(pfx + ".c2", t1, out, 3, 1, 1, ACT_RELU, nullptr, RES_NONE, 0, &sc_in, pfx + ".sc");
         else B.conv(pfx + ".c2", t1, out, 3, 1, 1, ACT_RELU, &res, RES_PRE);
@@ -684,7 +691,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   Tensor pos;
   pos.p = e->pos_dev; pos.dt = F32; pos.n = 1; pos.h = L; pos.w = 1; pos.c = d; pos.ld = d; pos.bstride = (int64_t)L * d;
   Tensor t2;
-  const bool aifi_fused = g_dec_fused && d == 256 && c.enc_heads == 8 && c.enc_ffn <= 1024;
+  const bool aifi_fused = e->opts.dec_fused && d == 256 && c.enc_heads == 8 && c.enc_ffn <= 1024;
   if (aifi_fused) {
     // ---- fused AIFI: 2 launches of decoder.hip's row kernel (modes 3, 4) instead of 9 ----------------------------
     t2 = B.act(P, n, L, 1, d, "aifi_out");
@@ -696,14 +703,14 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     auto elin = [&](const std::string& name, int N, int K) {
       DecLin Lw{};
       if (!B.dry) {
-        DevWeight w = get_weight_packed(e, name, N, K, K, g_dec_split && P != F32);
+        DevWeight w = get_weight_packed(e, name, N, K, K, e->opts.dec_split && P != F32);
         Lw.w = (const float*)w.w; Lw.b = w.bias; Lw.ldw = w.Kpad; Lw.N = N; Lw.K = w.K;
       }
       return Lw;
     };
     DecArgs a0{};
-    a0.split = P != F32 ? g_dec_split : 0;
-    a0.attn_split = g_attn_split & 1;                          // bit 0: AIFI, bit 1: decoder
+    a0.split = P != F32 ? e->opts.dec_split : 0;
+    a0.attn_split = e->opts.attn_split & 1;                          // bit 0: AIFI, bit 1: decoder
     a0.B = n; a0.Q = L; a0.D = d; a0.heads = 8; a0.S = 0; a0.n_levels = 3; a0.n_points = 4; a0.ffn = c.enc_ffn; a0.C = 4;
     a0.hs_in = (const float*)t0.p; a0.qpos_in = e->pos_dev;
     a0.q_in = (const float*)qrows.p; a0.q_out = (float*)qrows.p;
@@ -756,7 +763,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   auto csp = [&](const std::string& pfx, const Tensor& cat, const std::string& oname, const Tensor* up_src = nullptr) {
     Tensor h12 = B.act(P, cat.n, cat.h, cat.w, 2 * hh);
     bool up_fold = false;
-    if (up_src && (P == BF16 || SP) && g_up_fold) {
+    if (up_src && (P == BF16 || SP) && e->opts.up_fold) {
       ConvArgs probe;                                          // shapes for ONE image, like the shortcut fold
       probe.x = *up_src; probe.x.p = (void*)16; probe.x.n = 1;
       probe.x2 = cat.slice_c(d, d); probe.x2.p = (void*)16; probe.x2.n = 1;
@@ -823,8 +830,8 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     const int nr = e->n_invalid;
     B.push("dec.mask_rows", "set_rows", 0.0, (double)n * nr * dm * 4, [eo, rows, nr, S, bias](hipStream_t s) { launch_set_rows(eo, rows, nr, S, bias, s); });
   }
-  const bool fused = g_dec_fused && dm == 256 && c.dec_heads == 8 && c.dec_ffn <= 1024 && C <= 512 && c.n_levels == 3 && c.n_points == 4;
-  const bool sel_fused = fused && g_sel_fused && eo.ld == dm;
+  const bool fused = e->opts.dec_fused && dm == 256 && c.dec_heads == 8 && c.dec_ffn <= 1024 && C <= 512 && c.n_levels == 3 && c.n_points == 4;
+  const bool sel_fused = fused && e->opts.sel_fused && eo.ld == dm;
   float* mx = (float*)B.alloc((size_t)n * S * 4);
   {
     Tensor t; t.p = mx; t.dt = F32; t.n = n; t.h = S; t.w = 1; t.c = 1; t.ld = 1; t.bstride = S;
@@ -855,9 +862,12 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   {
     const int32_t* forced = e->forced_idx; const int32_t* flag = e->force_flag;
     B.push("dec.enc_topk", "topk", 0.0, (double)n * S * 4 * 6, [mx, n, S, Q, tk](hipStream_t s) { launch_topk(mx, n, S, Q, tk, nullptr, s); });
+    // test hook (rtd_debug_force_topk): overrides the selection with the caller's indices.  Not part of the product graph: the op is
+    // skipped - and absent from the captured hipGraph - until the hook is used on this handle
     B.push("dec.force_topk", "select", 0.0, 0.0, [tk, forced, flag, n, Q](hipStream_t s) {
       launch_force_idx(tk, forced, flag, n * Q, s);
     });
+    if (!B.dry) plan->ops.back().debug_only = true;
   }
   Tensor target = B.act(F32, n, Q, 1, dm, "target");
   if (sel_fused) {
@@ -893,7 +903,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     auto lin = [&](const std::string& name, int N, int K, int Kuse = 0) {
       DecLin L{};
       if (!B.dry) {
-        DevWeight w = get_weight_packed(e, name, N, K, Kuse ? Kuse : K, g_dec_split && P != F32);
+        DevWeight w = get_weight_packed(e, name, N, K, Kuse ? Kuse : K, e->opts.dec_split && P != F32);
         L.w = (const float*)w.w; L.b = w.bias; L.ldw = w.Kpad; L.N = N; L.K = w.K;
       }
       return L;
@@ -904,8 +914,8 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       return P;
     };
     DecArgs base{};
-    base.split = P != F32 ? g_dec_split : 0;
-    base.attn_split = (g_attn_split >> 1) & 1;
+    base.split = P != F32 ? e->opts.dec_split : 0;
+    base.attn_split = (e->opts.attn_split >> 1) & 1;
     base.B = n; base.Q = Q; base.D = dm; base.heads = c.dec_heads; base.S = S; base.n_levels = c.n_levels;
     base.n_points = c.n_points; base.ffn = c.dec_ffn; base.C = C; base.offset_scale = c.offset_scale;
     base.ref8 = ref8; base.ref_unact8 = ref_unact8; base.anchors = e->anchors_dev; base.tk_idx = tk;
@@ -942,7 +952,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       a.bb0 = lin(nm("dec.bbox.%d.0", i), dm, dm); a.bb1 = lin(nm("dec.bbox.%d.1", i), dm, dm); a.bb2 = lin(nm("dec.bbox.%d.2", i), 4, dm);
       if (last) a.cls = lin("dec.cls", C, dm);
       else { a.qk = lin(nm("dec.l%d.sa.qk", i + 1), 2 * dm, dm); a.v = lin(nm("dec.l%d.sa.v", i + 1), dm, dm); }
-      if (g_dec_stamps && i == std::min(2, NL - 1)) {
+      if (e->opts.dec_stamps && i == std::min(2, NL - 1)) {
         const int blocks = n * ((Q + 15) / 16);
         Tensor st = B.act(F32, 1, blocks, 1, 16, "dec_stamps");
         a.stamps = (float*)st.p;
@@ -1046,6 +1056,7 @@ void run_plan(rtd_engine* e, Plan* p) {
       // one eager pass first: faults and shape errors surface outside capture (RTD_TRACE_OPS=1: name + sync per op)
       const bool trace = getenv("RTD_TRACE_OPS") != nullptr;
       for (auto& op : p->ops) {
+        if (op.debug_only && !e->force_used) continue;
         if (trace) { fprintf(stderr, "[rtd] %s (%s)\n", op.name.c_str(), op.kernel); fflush(stderr); }
         op.run(e->stream);
         if (trace) HIP_CHECK(hipStreamSynchronize(e->stream));
@@ -1053,7 +1064,8 @@ void run_plan(rtd_engine* e, Plan* p) {
       HIP_CHECK(hipStreamSynchronize(e->stream));
       HIP_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
       try {
-        for (auto& op : p->ops) op.run(e->stream);
+        for (auto& op : p->ops)
+          if (!op.debug_only || e->force_used) op.run(e->stream);
       } catch (...) {
         hipGraph_t g = nullptr;
         (void)hipStreamEndCapture(e->stream, &g);
@@ -1065,7 +1077,8 @@ void run_plan(rtd_engine* e, Plan* p) {
     }
     HIP_CHECK(hipGraphLaunch(p->exec, e->stream));
   } else {
-    for (auto& op : p->ops) op.run(e->stream);
+    for (auto& op : p->ops)
+      if (!op.debug_only || e->force_used) op.run(e->stream);
   }
 }
 
@@ -1234,6 +1247,7 @@ int rtd_create(const rtd_config* cfg, rtd_handle* out) {
     RTD_CHECK((cfg->dec_heads * cfg->n_levels * cfg->n_points * 3) % 4 == 0, RTD_E_INVALID, "sampling head width");
     rtd_engine* e = new rtd_engine();
     e->cfg = *cfg;
+    e->opts = g_opts;
     e->P = cfg->precision == RTD_PREC_BF16 ? BF16 : (cfg->precision == RTD_PREC_BF16X3 ? BF16X2 : F32);
     if (e->P == BF16X2) {
       // hi/lo pairs travel in 32-channel groups (common.h BF16X2): every trunk width must be whole groups
@@ -1447,6 +1461,15 @@ int rtd_debug_force_topk(rtd_handle h, const int32_t* idx, int32_t n) {
   return guarded(h, [&] {
     RTD_CHECK(h->loaded, RTD_E_STATE, "weights not loaded");
     HIP_CHECK(hipSetDevice(h->cfg.device));
+    if (idx && !h->force_used) {
+      // first use on this handle: the override launch joins the plans; graphs captured without it are re-captured on their next run
+      h->force_used = true;
+      HIP_CHECK(hipStreamSynchronize(h->stream));
+      for (auto& kv : h->plans) {
+        if (kv.second->exec) { (void)hipGraphExecDestroy(kv.second->exec); kv.second->exec = nullptr; }
+        if (kv.second->graph) { (void)hipGraphDestroy(kv.second->graph); kv.second->graph = nullptr; }
+      }
+    }
     int32_t flag = 0;
     if (idx) {
       RTD_CHECK(n >= 1 && n <= h->cfg.max_batch, RTD_E_INVALID, "batch size");
@@ -1467,7 +1490,10 @@ int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int3
     RTD_CHECK(count && reps >= 1, RTD_E_INVALID, "arguments");
     HIP_CHECK(hipSetDevice(h->cfg.device));
     Plan* p = get_plan(h, n);
-    const int nops = (int)p->ops.size();
+    std::vector<Op*> ops;                                     // what a forward of this handle launches
+    for (auto& op : p->ops)
+      if (!op.debug_only || h->force_used) ops.push_back(&op);
+    const int nops = (int)ops.size();
     *count = nops;
     if (!out) return;
     if (p->stem_fused && (h->last_n != n || h->last_fa.n != n)) {
@@ -1487,7 +1513,7 @@ int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int3
     std::vector<hipEvent_t> ev((size_t)nops + 1);
     for (auto& x : ev) HIP_CHECK(hipEventCreate(&x));
     std::vector<double> acc(nops, 0.0);
-    for (auto& op : p->ops) op.run(h->stream);   // warm-up
+    for (Op* op : ops) op->run(h->stream);   // warm-up
     for (int r = 0; r < reps; ++r) {
       if (g_profile_twice) {
         // diagnostic: every op runs twice back to back and only the SECOND run is timed (operands, filter and TLB entries
@@ -1495,9 +1521,9 @@ int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int3
         std::vector<hipEvent_t> ev2((size_t)nops);
         for (auto& x : ev2) HIP_CHECK(hipEventCreate(&x));
         for (int i = 0; i < nops; ++i) {
-          p->ops[i].run(h->stream);
+          ops[i]->run(h->stream);
           HIP_CHECK(hipEventRecord(ev2[i], h->stream));
-          p->ops[i].run(h->stream);
+          ops[i]->run(h->stream);
           HIP_CHECK(hipEventRecord(ev[i + 1], h->stream));
         }
         HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -1511,7 +1537,7 @@ int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int3
       }
       HIP_CHECK(hipEventRecord(ev[0], h->stream));
       for (int i = 0; i < nops; ++i) {
-        p->ops[i].run(h->stream);
+        ops[i]->run(h->stream);
         HIP_CHECK(hipEventRecord(ev[i + 1], h->stream));
       }
       HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -1525,11 +1551,11 @@ int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int3
     for (int i = 0; i < nops; ++i) {
       rtd_layer_time& t = out[i];
       memset(&t, 0, sizeof t);
-      strncpy(t.name, p->ops[i].name.c_str(), sizeof(t.name) - 1);
-      strncpy(t.kernel, p->ops[i].kernel, sizeof(t.kernel) - 1);
+      strncpy(t.name, ops[i]->name.c_str(), sizeof(t.name) - 1);
+      strncpy(t.kernel, ops[i]->kernel, sizeof(t.kernel) - 1);
       t.ms = (float)(acc[i] / reps);
-      t.flops = p->ops[i].flops;
-      t.bytes = p->ops[i].bytes;
+      t.flops = ops[i]->flops;
+      t.bytes = ops[i]->bytes;
     }
   });
 }
@@ -1544,19 +1570,27 @@ __global__ void k_touch_read(const unsigned* p, size_t lines, unsigned* sink) {
 static int g_bench_rewarm = 0;   // "bench_rewarm": rtd_bench_conv rewrites 1 = activations, 2 = weights after its flush (back into the Infinity Cache)
 int rtd_debug_option(const char* name, int value) {
   if (!name) return RTD_E_INVALID;
+  if (strcmp(name, "reset") == 0) {                             // every switch back to its default (tests call this after each case)
+    g_opts = PlanOpts();
+    g_profile_twice = 0; g_bench_rewarm = 0;
+    conv_reset_options();
+    maxpool_set_v1(0);
+    dec_set_pf(2);
+    return RTD_OK;
+  }
   if (strcmp(name, "conv_v1") == 0) { conv_set_force_v1(value); return RTD_OK; }
-  if (strcmp(name, "dec_stamps") == 0) { g_dec_stamps = value; return RTD_OK; }
-  if (strcmp(name, "dec_fused") == 0) { g_dec_fused = value; return RTD_OK; }
-  if (strcmp(name, "sel_fused") == 0) { g_sel_fused = value; return RTD_OK; }
-  if (strcmp(name, "stem_fused") == 0) { g_stem_fused = value; return RTD_OK; }
-  if (strcmp(name, "sc_fold") == 0) { g_sc_fold = value; return RTD_OK; }
+  if (strcmp(name, "dec_stamps") == 0) { g_opts.dec_stamps = value; return RTD_OK; }
+  if (strcmp(name, "dec_fused") == 0) { g_opts.dec_fused = value; return RTD_OK; }
+  if (strcmp(name, "sel_fused") == 0) { g_opts.sel_fused = value; return RTD_OK; }
+  if (strcmp(name, "stem_fused") == 0) { g_opts.stem_fused = value; return RTD_OK; }
+  if (strcmp(name, "sc_fold") == 0) { g_opts.sc_fold = value; return RTD_OK; }
   if (strcmp(name, "maxpool_v1") == 0) { maxpool_set_v1(value); return RTD_OK; }
-  if (strcmp(name, "arena_reuse") == 0) { g_arena_reuse = value; return RTD_OK; }
-  if (strcmp(name, "up_fold") == 0) { g_up_fold = value; return RTD_OK; }
-  if (strcmp(name, "attn_split") == 0) { g_attn_split = value; return RTD_OK; }
-  if (strcmp(name, "c1_fuse") == 0) { g_c1_fuse = value; return RTD_OK; }
+  if (strcmp(name, "arena_reuse") == 0) { g_opts.arena_reuse = value; return RTD_OK; }
+  if (strcmp(name, "up_fold") == 0) { g_opts.up_fold = value; return RTD_OK; }
+  if (strcmp(name, "attn_split") == 0) { g_opts.attn_split = value; return RTD_OK; }
+  if (strcmp(name, "c1_fuse") == 0) { g_opts.c1_fuse = value; return RTD_OK; }
   if (strcmp(name, "dec_pf") == 0) { dec_set_pf(value); return RTD_OK; }
-  if (strcmp(name, "dec_split") == 0) { g_dec_split = value; return RTD_OK; }
+  if (strcmp(name, "dec_split") == 0) { g_opts.dec_split = value; return RTD_OK; }
   if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
   if (strcmp(name, "prefetch") == 0) { conv_set_prefetch(value); return RTD_OK; }
   if (strcmp(name, "wsa_min_ntn") == 0) { conv_set_wsa_min_ntn(value); return RTD_OK; }

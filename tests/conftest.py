@@ -17,3 +17,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN_DIR
+
+
+@pytest.fixture(autouse=True)
+def _reset_debug_options(request):
+    """rtd_debug_option switches are process-wide: a GPU test that changes one must not leak it into the next (handles snapshot
+    the plan-build switches at rtd_create, the conv dispatch switches are read at launch / capture)."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        from telescope_cam_detection_amd import _capi
+        _capi.debug_option("reset", 0)

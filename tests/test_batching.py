@@ -92,6 +92,22 @@ def test_detector_exception_gives_every_callback_an_empty_list_and_keeps_running
         c.infer_async(frame(1), lambda d: None)                          # stopped
 
 
+def test_stop_answers_every_request_that_never_ran():
+    """requests still queued when the coordinator stops must not leave their camera waiting - each gets []"""
+    det = FakeDetector(delay=0.15)
+    res = {}
+    c = BatchCoordinator(det, max_batch_size=1, max_batch_wait_ms=1.0, max_queue_depth=50)
+    c.start()
+    for i in range(6):
+        c.infer_async(frame(i), lambda d, i=i: res.__setitem__(i, d))
+    time.sleep(0.05)                                                     # batch 0 is running, 1 may be formed, the rest wait in the inbox
+    c.stop()
+    assert set(res) == set(range(6))                                     # everyone answered exactly once
+    assert res[0][0]["class_id"] == 0
+    assert sum(1 for v in res.values() if v == []) >= 3                  # the queued ones got []
+    assert all(v == [] or v[0]["class_id"] == k for k, v in res.items())
+
+
 def test_make_coordinator_follows_reference_config_keys():
     built = {}
 
