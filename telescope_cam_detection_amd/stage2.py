@@ -4,7 +4,13 @@ The reference classifies every detection separately, bs=1: crop geometry in
 `TwoStageDetectionPipeline.classify_detection` (/root/reference/src/two_stage_pipeline_yolox.py:244-289) then
 `SpeciesClassifier.preprocess` (src/species_classifier.py:298-352) per crop.  Here all crops of a frame (or of
 several frames) become ONE `[N, 3, S, S]` classifier batch with one HIP launch (`rtd_crop_resize_batch`).
-The classifier network itself (timm EVA02, fetched by name) is out of scope - this module stops at its input.
+`BatchedStage2` is the consumer of that batch: it replaces the per-detection loop of
+`TwoStageDetectionPipeline.process_detections` (src/two_stage_pipeline_yolox.py:453-481 -> :203-451) with crop geometry for
+every detection -> ONE crop launch -> ONE classifier forward per taxonomic category -> the same per-detection result rules
+(`SpeciesClassifier.classify`'s formatting, src/species_classifier.py:383-413, the time-of-day re-ranking and the rejected
+taxonomic levels of :393-445), detections returned in their input order.  The classifier network itself (timm EVA02-L/14@336,
+fetched by name, src/species_classifier.py:252-262) is out of scope; `StandInSpeciesClassifier` - declared as a stand-in - gives
+the glue something with the reference classifier's attributes to drive in tests and in `bench.py --workload two_stage`.
 """
 from __future__ import annotations
 
@@ -19,7 +25,7 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)      # defaults of the reference classifie
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
-def crop_rect(bbox: Dict[str, float], frame_hw: Tuple[int, int], min_crop_size: int = 32,
+def crop_rect(bbox: Dict[str, float], frame_hw: Tuple[int, int], min_crop_size: int = 64,
               crop_padding_percent: float = 20) -> Optional[Tuple[int, int, int, int]]:
     """Crop rectangle (x1, y1, x2, y2) of one detection, or None when Stage 2 skips it.
 
@@ -46,7 +52,8 @@ class CropBatcher:
     """Builds the classifier input batch on the GPU.  Frames must be HWC uint8 BGR torch tensors on the device."""
 
     def __init__(self, input_size: int = 336, mean: Sequence[float] = IMAGENET_MEAN, std: Sequence[float] = IMAGENET_STD,
-                 min_crop_size: int = 32, crop_padding_percent: float = 20):
+                 min_crop_size: int = 64, crop_padding_percent: float = 20):
+        # defaults of the reference pipeline: min_crop_size 64, 20 % padding (src/two_stage_pipeline_yolox.py:42-43, main.py:1067)
         self.input_size = int(input_size)
         self.mean = (C.c_float * 3)(*mean)
         self.std = (C.c_float * 3)(*std)
@@ -87,3 +94,233 @@ class CropBatcher:
         if code != _capi.RTD_OK:
             _capi._raise(code, None)
         return out
+
+
+def normalised_bbox(bbox: Dict[str, float], min_size: int = 1) -> Dict[str, float]:
+    """What the pipeline does to a bbox before cropping (src/two_stage_pipeline_yolox.py:232-238 via src/bbox_utils.py:12-59):
+    inverted corners swapped, extents of at least `min_size`, width / height / area recomputed (un-truncated floats).  The
+    reference's own function is used when its package is importable."""
+    try:
+        from src.bbox_utils import ensure_valid_bbox  # type: ignore
+        return ensure_valid_bbox(bbox, min_size)
+    except Exception:
+        pass
+    xa, xb = sorted((bbox["x1"], bbox["x2"]))
+    ya, yb = sorted((bbox["y1"], bbox["y2"]))
+    xb = xb if xb - xa >= min_size else xa + min_size
+    yb = yb if yb - ya >= min_size else ya + min_size
+    return {"x1": xa, "y1": ya, "x2": xb, "y2": yb, "width": xb - xa, "height": yb - ya, "area": (xb - xa) * (yb - ya)}
+
+
+def format_predictions(classifier, probs_row, top_k: int) -> List[Dict]:
+    """Top-k of one softmax row -> the result dicts of `SpeciesClassifier.classify` (src/species_classifier.py:383-413): threshold
+    (0.1 in hierarchical mode, else `confidence_threshold`), hierarchical label for the confidence, geographic whitelist."""
+    import torch
+
+    top_probs, top_idx = torch.topk(probs_row, min(top_k, probs_row.numel()))
+    out = []
+    floor = 0.1 if getattr(classifier, "use_hierarchical", False) else classifier.confidence_threshold
+    for prob, idx in zip(top_probs.tolist(), top_idx.tolist()):
+        if prob < floor:
+            continue
+        label, level = classifier.get_hierarchical_label(idx, prob)
+        if label is None:
+            continue
+        if getattr(classifier, "enable_geographic_filter", False) and getattr(classifier, "allowed_species", None):
+            if label not in classifier.allowed_species:
+                continue
+        out.append({"species": label, "confidence": prob, "class_id": idx, "taxonomic_level": level})
+    return out
+
+
+class BatchedStage2:
+    """Batched stand-in for `TwoStageDetectionPipeline.process_detections`.  `pipeline` is the reference pipeline object (or
+    anything with its attributes: enable_species_classification, class_id_to_category, species_classifiers, min_crop_size,
+    crop_padding_percent, rejected_taxonomic_levels, time_of_day_top_k, time_of_day_penalty, enhancer); its classifiers need
+    `.model` (callable on a [N,3,S,S] batch) plus the attributes `format_predictions` reads.  Pipelines with an image enhancer
+    (Real-ESRGAN, ~1 s per crop) keep the reference's own per-detection path."""
+
+    def __init__(self, pipeline, batcher: Optional[CropBatcher] = None, activity_fn=None):
+        self.pipeline = pipeline
+        self.batcher = batcher or CropBatcher(min_crop_size=pipeline.min_crop_size, crop_padding_percent=pipeline.crop_padding_percent)
+        if activity_fn is None:
+            try:
+                from src.species_activity_patterns import is_species_likely_active as activity_fn  # type: ignore
+            except Exception:
+                activity_fn = None
+        self.activity_fn = activity_fn
+
+    @staticmethod
+    def _set(det, species, confidence, category, level):            # src/two_stage_pipeline_yolox.py:180-201
+        det["species"] = species
+        det["species_confidence"] = float(confidence)
+        det["stage2_category"] = category
+        det["taxonomic_level"] = level
+
+    def _conclude(self, det, category, results):
+        """From the classifier's result list to the detection's species fields (src/two_stage_pipeline_yolox.py:393-445)."""
+        p = self.pipeline
+        if not results:
+            self._set(det, None, 0.0, category, None)
+            return
+        tod = det.get("time_of_day")
+        if tod and self.activity_fn is not None:
+            for r in results:
+                r["confidence_original"] = r["confidence"]
+                r["activity_boosted"] = bool(self.activity_fn(r["species"], tod))
+                if not r["activity_boosted"]:
+                    r["confidence"] = r["confidence"] * p.time_of_day_penalty
+            results.sort(key=lambda r: r["confidence"], reverse=True)
+        top = results[0]
+        level = top.get("taxonomic_level", "species")
+        if level in p.rejected_taxonomic_levels:
+            self._set(det, None, 0.0, category, None)
+        else:
+            self._set(det, top["species"], top["confidence"], category, level)
+
+    def process_batch(self, frames, detections_per_frame):
+        """frames: device-resident HWC uint8 BGR tensors; detections_per_frame: Stage-1 dict lists (mutated in place and returned,
+        order kept).  One crop launch for every eligible detection of every frame, one forward per category."""
+        import torch
+
+        p = self.pipeline
+        if not p.enable_species_classification:
+            for dets in detections_per_frame:
+                for d in dets:
+                    d["species"] = None
+                    d["species_confidence"] = 0.0
+            return detections_per_frame
+        if getattr(p, "enhancer", None) is not None:
+            return [p.process_detections(f, dets) for f, dets in zip(frames, detections_per_frame)]
+        jobs = []                                                  # (frame index, detection, category, rect)
+        for fi, (f, dets) in enumerate(zip(frames, detections_per_frame)):
+            hw = (int(f.shape[0]), int(f.shape[1]))
+            for d in dets:
+                bbox = normalised_bbox(d.get("bbox", {}))
+                d["bbox"] = bbox
+                category = p.class_id_to_category.get(d.get("class_id"))
+                if category not in p.species_classifiers:          # :227-231
+                    d["species"] = None
+                    d["species_confidence"] = 0.0
+                    continue
+                rect = crop_rect(bbox, hw, p.min_crop_size, p.crop_padding_percent)
+                if rect is None:                                   # too small / empty crop (:256-259, :281-285)
+                    self._set(d, None, 0.0, category, None)
+                    continue
+                jobs.append((fi, d, category, rect))
+        if not jobs:
+            return detections_per_frame
+        rects_per_frame = [[] for _ in frames]
+        order = [[] for _ in frames]
+        for j, (fi, _, _, rect) in enumerate(jobs):
+            rects_per_frame[fi].append(rect)
+            order[fi].append(j)
+        batch = self.batcher.preprocess_batch(frames, rects_per_frame)          # [N,3,S,S], crops in frame-major order
+        row_of = {j: r for r, j in enumerate(j for per in order for j in per)}
+        by_cat: Dict[str, List[int]] = {}
+        for j, (_, _, category, _) in enumerate(jobs):
+            by_cat.setdefault(category, []).append(j)
+        for category, js in by_cat.items():
+            clf = p.species_classifiers[category]
+            try:
+                with torch.no_grad():
+                    x = batch[torch.tensor([row_of[j] for j in js], device=batch.device)]
+                    probs = torch.softmax(clf.model(x), dim=1).float().cpu()
+            except Exception:                                      # :447-451: a failing classifier leaves its detections unlabelled
+                for j in js:
+                    d = jobs[j][1]
+                    d["species"], d["species_confidence"], d["taxonomic_level"] = None, 0.0, None
+                continue
+            for row, j in enumerate(js):
+                d = jobs[j][1]
+                top_k = p.time_of_day_top_k if d.get("time_of_day") else 1
+                self._conclude(d, category, format_predictions(clf, probs[row], top_k))
+        return detections_per_frame
+
+    def process_detections(self, frame, detections):
+        """Drop-in for `TwoStageDetectionPipeline.process_detections(frame, detections)` (one frame)."""
+        import torch
+
+        if isinstance(frame, np.ndarray):
+            frame = torch.from_numpy(np.ascontiguousarray(frame)).cuda()
+        return self.process_batch([frame.contiguous()], [detections])[0]
+
+
+class StandInSpeciesClassifier:
+    """STAND-IN for the reference's `SpeciesClassifier` (timm EVA02-L/14@336 + iNat21 taxonomy, both unavailable offline): a small
+    seeded conv net over the same [N,3,S,S] input with the attributes `BatchedStage2` / `format_predictions` read.  It exists so that
+    the batched glue can be tested end to end and timed; it says nothing about the real classifier's accuracy or cost."""
+
+    def __init__(self, num_classes: int = 40, input_size: int = 336, device: str = "cuda:0", seed: int = 0, use_hierarchical: bool = True,
+                 confidence_threshold: float = 0.3):
+        import torch
+        import torch.nn as nn
+
+        g = torch.Generator().manual_seed(seed)
+        net = nn.Sequential(nn.Conv2d(3, 16, 7, 4, 3), nn.ReLU(), nn.Conv2d(16, 32, 3, 2, 1), nn.ReLU(), nn.AdaptiveAvgPool2d(4), nn.Flatten(),
+                            nn.Linear(512, num_classes))
+        with torch.no_grad():
+            for prm in net.parameters():
+                prm.copy_(torch.randn(prm.shape, generator=g) * (2.5 if prm.dim() == 2 else 0.15))
+        self.model = net.to(device).eval()
+        self.input_size = input_size
+        self.use_hierarchical = use_hierarchical
+        self.confidence_threshold = confidence_threshold
+        self.enable_geographic_filter = False
+        self.allowed_species = None
+        self.hierarchy_thresholds = {"species": 0.6, "genus": 0.4, "family": 0.3, "order": 0.2, "class": 0.1}
+        self.taxonomy = {str(i): {"common_name": f"species_{i}", "genus": f"genus_{i // 2}", "family": f"family_{i // 4}",
+                                  "order": f"order_{i // 8}", "class": "Aves" if i % 2 else "Mammalia"} for i in range(num_classes)}
+
+    def get_hierarchical_label(self, class_id: int, confidence: float):
+        """same contract as src/species_classifier.py:168-233: the most specific rank the confidence supports, or (None, None)"""
+        entry = self.taxonomy.get(str(class_id), {})
+        if not self.use_hierarchical:
+            return entry.get("common_name", f"species_{class_id}"), "species"
+        for level, key in (("species", "common_name"), ("genus", "genus"), ("family", "family"), ("order", "order"), ("class", "class")):
+            if confidence >= self.hierarchy_thresholds[level]:
+                label = entry.get(key)
+                return (label, level) if label else (None, None)
+        return None, None
+
+
+class StandInPipeline:
+    """The attributes of `TwoStageDetectionPipeline` (src/two_stage_pipeline_yolox.py:63-91) that `BatchedStage2` reads, with
+    stand-in classifiers for the reference's categories - for tests and bench.py only."""
+
+    def __init__(self, device: str = "cuda:0", categories=("bird", "mammal"), min_crop_size: int = 64, crop_padding_percent: int = 20):
+        from .coco_constants import CLASS_ID_TO_CATEGORY
+
+        self.enable_species_classification = True
+        self.class_id_to_category = CLASS_ID_TO_CATEGORY
+        self.species_classifiers = {c: StandInSpeciesClassifier(device=device, seed=10 + i) for i, c in enumerate(categories)}
+        self.min_crop_size = min_crop_size
+        self.crop_padding_percent = crop_padding_percent
+        self.rejected_taxonomic_levels = ["order", "class"]
+        self.time_of_day_top_k = 5
+        self.time_of_day_penalty = 0.3
+        self.enhancer = None
+
+
+def bench_crop_step(batch: int, size: int, seed: int = 5000, n_crops: int = 16):
+    """bench.py --workload two_stage (BASELINE config 5): after each detect step, the Stage-2 crop batch of `n_crops` mixed-size boxes
+    (sides drawn from rng.integers(64, 512)) spread over the step's frames -> [16,3,336,336] classifier input, enqueued on
+    the engine's stream.  The classifier forward is excluded (its network is out of scope) and the boxes are synthetic: Stage 1 on noise
+    frames with random weights finds nothing above threshold.  Returns (callable, description)."""
+    import torch
+
+    rng = np.random.default_rng(seed)
+    batcher = CropBatcher()
+    rects = [[] for _ in range(batch)]
+    for i in range(n_crops):
+        cw, ch = int(rng.integers(64, min(512, size))), int(rng.integers(64, min(512, size)))
+        x, y = int(rng.integers(0, size - cw + 1)), int(rng.integers(0, size - ch + 1))
+        rects[i % batch].append((x, y, x + cw, y + ch))
+
+    def run(engine, frames, stream):
+        with torch.cuda.stream(stream):
+            batcher.preprocess_batch(frames, rects)
+
+    info = {"crops_per_step": n_crops, "crop_sides": "rng.integers(64, 512)", "classifier_input": [n_crops, 3, batcher.input_size, batcher.input_size],
+            "timed": "detect + crop/resize/normalise batch (one launch); classifier forward EXCLUDED (EVA02 out of scope)"}
+    return run, info
