@@ -128,7 +128,7 @@ def test_make_coordinator_follows_reference_config_keys():
     assert isinstance(c, BatchCoordinator) and c.max_batch_size == 6 and abs(c.max_batch_wait_ms - 0.005) < 1e-9
     assert built["config_path"] == "x_r50vd.yml" and built["model_path"] == "w.pth" and built["max_batch"] == 6
     assert built["input_size"] == (640, 640) and built["conf_threshold"] == 0.3 and built["wildlife_only"] is False
-    assert "profile" not in built                                       # one batch in flight: the reference's own constructor arguments only
+    assert "profile" not in built and "precision" not in built         # one batch in flight: the reference's own constructor arguments only
 
     # pipeline_depth > 1: every detector of the pipeline is built with the throughput kernel profile
     profiles = []
@@ -275,13 +275,13 @@ def test_four_camera_threads_through_the_real_detector():
 def test_pipelined_coordinator_on_two_real_detectors_matches_detect():
     from telescope_cam_detection_amd.rtdetr_detector import RTDETRDetector
     from tests.util import load_case
-    arch, wseed, input_size, frames, g = load_case("t_tinyb_192x128")
+    arch, wseed, input_size, frames, g = load_case("t_tinyc_160x224")     # default engine (bf16x3): widths in whole 32-channel groups
     cfg = {"detection": {"detector_type": "rtdetr", "device": "cuda:0", "conf_threshold": 0.2, "input_size": list(input_size),
-                         "wildlife_only": False, "rtdetr": {"config_path": "tinyb", "weights": f"synthetic:tinyb:{wseed}"},
+                         "wildlife_only": False, "rtdetr": {"config_path": "tinyc", "weights": f"synthetic:tinyc:{wseed}"},
                          "batching": {"enabled": True, "max_batch_size": 2, "max_batch_wait_ms": 2.0, "pipeline_depth": 2}}}
     coord = make_rtdetr_coordinator(cfg)
     assert isinstance(coord, BatchCoordinator) and len(coord.detectors) == 2
-    ref = RTDETRDetector(config_path="tinyb", model_path=f"synthetic:tinyb:{wseed}", device="cuda:0", conf_threshold=0.2,
+    ref = RTDETRDetector(config_path="tinyc", model_path=f"synthetic:tinyc:{wseed}", device="cuda:0", conf_threshold=0.2,
                          input_size=input_size, wildlife_only=False, max_batch=2)
     assert ref.load_model()
     want = [ref.detect(f) for f in frames]

@@ -45,7 +45,7 @@ def nchw(t):
     return np.transpose(t, (0, 3, 1, 2))
 
 
-FP32_CASES = ["t_tiny_160", "t_tiny_160x224", "t_tinyb_192x128", "c1_r18_640_bs1", "c1_r18_640_scene", "c1_r18_640_resize",
+FP32_CASES = ["t_tiny_160", "t_tiny_160x224", "t_tinyb_192x128", "t_tinyc_160x224", "c1_r18_640_bs1", "c1_r18_640_scene", "c1_r18_640_resize",
               "c2_r50_640_scene_bs2"]
 
 
@@ -100,7 +100,7 @@ def test_fp32_engine_full_size_configs_against_hf_fixtures(name):
     eng.close()
 
 
-X3_CASES = ["c1_r18_640_bs1", "c1_r18_640_scene", "c1_r18_640_resize", "c2_r50_640_scene_bs2"]
+X3_CASES = ["t_tinyc_160x224", "c1_r18_640_bs1", "c1_r18_640_scene", "c1_r18_640_resize", "c2_r50_640_scene_bs2"]
 
 
 @pytest.mark.parametrize("name", X3_CASES)

@@ -6,7 +6,7 @@ import torch
 from oracle import rtdetr_oracle as orc
 from tests.util import load_case, match_detections, sample, weights_for
 
-FAST = ["t_tiny_160", "t_tiny_160x224", "t_tinyb_192x128", "c1_r18_640_bs1", "c1_r18_640_scene", "c1_r18_640_resize"]
+FAST = ["t_tiny_160", "t_tiny_160x224", "t_tinyb_192x128", "t_tinyc_160x224", "c1_r18_640_bs1", "c1_r18_640_scene", "c1_r18_640_resize"]
 SLOW = ["c2_r50_640_scene_bs2"]
 
 
