@@ -57,6 +57,7 @@ struct Error : std::runtime_error {
   do {                                                                                 \
     hipError_t _e = (expr);                                                            \
     if (_e != hipSuccess) {                                                            \
+      (void)hipGetLastError(); /* clear the runtime's sticky last-error: the next launch's hipGetLastError() must not see this one */ \
       int _c = (_e == hipErrorOutOfMemory) ? 2 : 3;                                    \
       throw ::rtd::Error(_c, std::string(#expr) + ": " + hipGetErrorString(_e) + " at " __FILE__ ":" + std::to_string(__LINE__)); \
     }                                                                                  \

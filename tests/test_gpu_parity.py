@@ -366,9 +366,10 @@ def test_bf16_engine_stagewise(name):
         m, n, ws, wb = match_detections(ol[b].numpy(), ob[b].numpy(), osc[b].numpy(), labels[b], boxes[b], scores[b], 2e-2, 2.0)
         print(f"{name}[{b}] bf16 (free-running) token overlap {ov:.3f}, matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
         tot_m += m; tot_n += n
-        assert ov >= 0.80, (b, ov)
-        assert m >= 0.70 * n, (b, m, n)
-    assert tot_m >= 0.75 * tot_n
+        # measured: overlap >= 0.96; misses <= 16 of 300 (R18 / R50), <= 6 of 50 (tiny archs); bounds = 1.5x the measured misses
+        assert ov >= 0.94, (b, ov)
+        assert n - m <= max(9, int(0.08 * n)), (b, m, n)
+    assert tot_m >= 0.90 * tot_n
     eng.close()
 
 
@@ -383,7 +384,7 @@ def test_bf16_engine_on_the_benchmark_frames_against_hf_fixture():
         labels, boxes, scores = eng.infer_raw(frames)
     mx = eng.debug_tensor("enc_cls_max")[:, :, 0, 0]
     print(f"bf16 c2_r50_640_bs8 enc score max abs err {np.abs(mx - g['enc_cls_max']).max():.2e}")
-    assert np.abs(mx - g["enc_cls_max"]).max() < 8e-2
+    assert np.abs(mx - g["enc_cls_max"]).max() < 4.2e-2                      # measured 2.7e-2
     tot_m = tot_n = 0
     Q = arch.num_queries
     for b in range(len(frames)):
@@ -391,8 +392,8 @@ def test_bf16_engine_on_the_benchmark_frames_against_hf_fixture():
         m, n, ws, wb = match_detections(g["labels"][b], g["boxes"][b], g["scores"][b], labels[b], boxes[b], scores[b], 2e-2, 2.0)
         print(f"bf16 c2_r50_640_bs8[{b}] token overlap {ov:.3f}, matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
         tot_m += m; tot_n += n
-        assert ov >= 0.80 and m >= 0.70 * n, (b, ov, m, n)
-    assert tot_m >= 0.75 * tot_n
+        assert ov >= 0.955 and n - m <= 29, (b, ov, m, n)                      # measured: overlap >= 0.970, <= 19 of 300 rows miss
+    assert tot_m >= 0.92 * tot_n
     eng.close()
 
 
@@ -407,13 +408,14 @@ def test_bf16_engine_r101_1280_bs4_against_hf_fixture():
     mx = eng.debug_tensor("enc_cls_max")[:, :, 0, 0]
     print(f"bf16 c3_r101_1280_bs4 enc score max abs err {np.abs(mx - g['enc_cls_max']).max():.2e}")
     assert np.isfinite(boxes).all() and (np.diff(scores, axis=1) <= 0).all()
-    assert np.abs(mx - g["enc_cls_max"]).max() < 0.15
+    assert np.abs(mx - g["enc_cls_max"]).max() < 6e-2                        # measured 3.9e-2
     tot_m = tot_n = 0
     for b in range(len(frames)):
         m, n, ws, wb = match_detections(g["labels"][b], g["boxes"][b], g["scores"][b], labels[b], boxes[b], scores[b], 2e-2, 4.0)
         print(f"bf16 c3_r101_1280_bs4[{b}] matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
         tot_m += m; tot_n += n
-    assert tot_m >= 0.6 * tot_n
+        assert n - m <= 32, (b, m, n)                                          # measured: <= 21 of 300 rows miss at 2e-2 / 4 px
+    assert tot_m >= 0.90 * tot_n
     eng.close()
 
 
@@ -512,7 +514,7 @@ def test_fused_uint8_stem_matches_the_generic_preprocess_plus_conv():
     for b in range(len(frames)):
         m, n, ws, wb = match_detections(out[0][0][b], out[0][1][b], out[0][2][b], out[1][0][b], out[1][1][b], out[1][2][b], 2e-2, 2.0)
         print(f"fused stem vs generic [{b}]: matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
-        assert m >= n - 30, (b, m, n, ws, wb)
+        assert m >= n - 8, (b, m, n, ws, wb)                                     # measured: <= 5 of 300 miss (the resized frame)
 
 
 def test_non_square_input_with_partial_tiles_bf16_and_fp32():
@@ -546,7 +548,7 @@ def test_non_square_input_with_partial_tiles_bf16_and_fp32():
         assert np.isfinite(bx2).all() and (np.diff(sc2) <= 0).all()
         m, n, ws, wb = match_detections(l, bx, sc, l2, bx2, sc2, 3e-2, 4.0)
         print(f"non-square bf16 vs fp32 [{b}]: matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
-        assert m >= n - 60, ("bf16", b, m, n, ws, wb)
+        assert m >= n - 18, ("bf16", b, m, n, ws, wb)                            # measured: 10-12 of 300 miss at 3e-2 / 4 px
 
 
 def test_detector_keeps_working_after_the_callers_degrade_writes():
