@@ -2079,6 +2079,144 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv3x3_reg_kernel(const Conv
   }
 }
 
+// BF16X2 form of the direct 3x3 kernel for 32 input channels (stem.1 32 -> 32, stem.2 32 -> 64 at 320^2): a pixel's 128 bytes are
+// [32 hi | 32 lo], so the patch, its LDS-DMA and its swizzle are the bf16 kernel's CIN = 64 case; each wave keeps the hi AND the lo filter
+// of its 32 output channels in registers (36 fragments = 144 VGPRs) and runs hi*hi + hi*lo + lo*hi per tap (6 MFMAs per tap and row).
+// 8 waves per block, one block per CU (two 43 KiB patch buffers): COG channel groups x (8 / COG) waves, each wave 8 / (8 / COG) rows.
+// The epilogue writes the row's BF16X2 pixels ([32 hi | 32 lo] per 32-channel group) through the wave's slab, 16-byte stores.
+template <int COG>   // output channel groups of 32 (1 or 2)
+__global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a, unsigned x_bytes, unsigned y_bytes, int tiles_x, int tiles_y, int ntiles) {
+  constexpr int NW = 8, NT_ = 512, WPG = NW / COG, RPW = 8 / WPG;    // waves per channel group, rows per wave
+  constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2, NPIX = PW * PH;
+  constexpr int ROWB = 128, CPP = 8, PPI = 8;
+  constexpr int NINSTR = (NPIX + PPI - 1) / PPI;
+  constexpr int PBUF = NINSTR * 1024;
+  constexpr int ROWO = 128 + 16;                  // slab row: one pixel's [32 hi | 32 lo] + 16 bytes (bank skew)
+  constexpr int WROW = 9 * 64 * 2 + 16;           // filter row in LDS: 9 taps x [32 hi | 32 lo] + 16 bytes
+  static_assert(32 * COG * WROW <= 2 * PBUF, "the filter is staged through the two patch buffers");
+  __shared__ __attribute__((aligned(16))) char patch[2 * PBUF];
+  __shared__ __attribute__((aligned(16))) char stage[NW][32 * ROWO];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wv / WPG, wq = wv % WPG;
+  const int nbase = grp * 32;
+  const int h = lane >> 5;
+
+  bf16x8 wf[9][4];                                  // [tap][kc]: kc 0, 1 = hi channels 0-15 / 16-31, kc 2, 3 = lo
+  {
+    const bf16* wg = (const bf16*)a.w;
+    constexpr int CPR = 9 * 64 / 8;
+    for (int e = tid; e < 32 * COG * CPR; e += NT_) {
+      const int row = e / CPR, ch = e - row * CPR;
+      *(bf16x8*)(patch + row * WROW + ch * 16) = *(const bf16x8*)(wg + (size_t)row * a.Kpad + ch * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc)
+        wf[tap][kc] = *(const bf16x8*)(patch + (nbase + (lane & 31)) * WROW + (tap * 64 + kc * 16 + 8 * h) * 2);
+    __syncthreads();
+  }
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
+  auto swz = [](int pi) { return (pi >> 1) & 7; };
+  auto issue_patch = [&](int tile, int buf) {
+    const int tx = tile % tiles_x;
+    const int t2 = tile / tiles_x;
+    const int ty = t2 % tiles_y;
+    const int b = t2 / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    for (int j = wv; j < NINSTR; j += NW) {
+      const int pi = j * PPI + lane / CPP;
+      const int py = pi / PW, px = pi - py * PW;
+      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+      const bool ok = pi < NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const int src_chunk = (lane % CPP) ^ swz(pi);
+      const unsigned vo = ok ? (unsigned)(((long long)b * a.x_bstride + ((long long)iy * a.W + ix) * a.ldx) * 2 + src_chunk * 16) : 0x80000000u;   // ldx: bf16 elements
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(patch + buf * PBUF + j * 1024), 16, vo, 0, 0, 0);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) issue_patch(tile, 0);
+  for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+    const int buf = it & 1;
+    // the 4 RPW stores of the previous tile were issued after this tile's DMA and may stay in flight (every row issues exactly 4)
+    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (RPW == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) issue_patch(tile + gridDim.x, buf ^ 1);
+    const int tx = tile % tiles_x;
+    const int t2 = tile / tiles_x;
+    const int ty = t2 % tiles_y;
+    const int b = t2 / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const char* pbuf = patch + buf * PBUF;
+
+#pragma unroll 1
+    for (int rr_ = 0; rr_ < RPW; ++rr_) {
+      const int r = wq * RPW + rr_;
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      bf16x8 xf[2][4];
+      auto read_tap = [&](bf16x8 (&dst)[4], int tap) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int pi = (r + kh) * PW + kw + (lane & 31);
+        const int sw = swz(pi);
+        const char* prow = pbuf + pi * ROWB;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) dst[kc] = *(const bf16x8*)(prow + (((2 * kc + h) ^ sw) << 4));
+      };
+      read_tap(xf[0], 0);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) read_tap(xf[(tap + 1) & 1], tap + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c], xf[tap & 1][c], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c], xf[tap & 1][c + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c + 2], xf[tap & 1][c], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- epilogue of this 32-pixel row: lane = pixel (lane & 31), channels 8 q + 4 h + (0..3) of the wave's group ----
+      const int oy = y0 + r;
+      char* sw_ = stage[wv];
+      dispatch_act(a.act, [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 bv = *(const f32x4*)(a.bias + nbase + 8 * q + 4 * h);
+          bf16x4 oh, ol;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { bf16 hi, lo; split2(act_c<ACT>(acc[4 * q + e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
+          *(bf16x4*)(sw_ + (lane & 31) * ROWO + (8 * q + 4 * h) * 2) = oh;
+          *(bf16x4*)(sw_ + (lane & 31) * ROWO + 64 + (8 * q + 4 * h) * 2) = ol;
+        }
+      });
+      __builtin_amdgcn_wave_barrier();
+      {
+        const long long yrow = 4 * ((long long)b * a.y_bstride + ((long long)oy * a.W + x0) * a.ldy + nbase);   // bytes; ldy: channels
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+          const int idx = i2 * 64 + lane;
+          const int p = idx >> 3, ch = idx & 7;
+          const bool ok = oy < a.H && x0 + p < a.W;
+          const unsigned vo = ok ? (unsigned)(yrow + 4 * (long long)p * a.ldy + ch * 16) : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_*)(sw_ + p * ROWO + ch * 16), ry, vo, 0, 0);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 static int g_conv_reg = 1;    // A/B hook (rtd_debug_option "conv_reg"): 0 = narrow 3x3 layers stay on the implicit-GEMM kernels
 void conv_set_reg(int v) { g_conv_reg = v; }
 
@@ -2711,6 +2849,20 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
   RTD_CHECK(x_bytes < (1ll << 31) && x2_bytes < (1ll << 31) && w_bytes < (1ll << 31), 1, "conv (bf16x3): operand larger than a buffer descriptor (2 GiB)");
   g.probe = 0; g.splitk = 1; g.slab = nullptr; g.cnt = nullptr; g.y_bytes = 0;
   g.x_bytes = (unsigned)x_bytes; g.w_bytes = (unsigned)w_bytes; g.x2_bytes = (unsigned)x2_bytes;
+  // narrow 3x3 layers on wide grids (stem.1, stem.2): the direct kernel stages every input pixel once instead of nine times
+  if (g_conv_reg && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !dual && a.res_mode == RES_NONE && x.c == 32 && (y.c == 32 || y.c == 64) &&
+      y.dt == BF16X2) {
+    const long long y_bytes = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * 4;
+    const int tiles_x = (x.w + 31) / 32, tiles_y = (x.h + 7) / 8;
+    const long long ntiles = (long long)x.n * tiles_x * tiles_y;
+    if (ntiles >= 256 && ntiles < (1ll << 30) && y_bytes < (1ll << 31)) {
+      const unsigned gx = (unsigned)std::min<long long>(ntiles, 256);        // persistent, one block per CU
+      if (y.c == 32) hipLaunchKernelGGL((conv3x3_reg_split_kernel<1>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles);
+      else hipLaunchKernelGGL((conv3x3_reg_split_kernel<2>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+  }
   const long long mt = (k.M + 127) / 128, ntn = (k.N + 127) / 128, ntn64 = (k.N + 63) / 64;
   if (k.N <= 64 || (mt * ntn < g_split_ws64_max_blocks && ntn64 > ntn)) {
     k.ntn = (int)ntn64;

@@ -40,6 +40,7 @@ struct PlanOpts {
   int up_fold = 1;      // read the FPN's upsampled lateral straight from the half-size tensor (ConvArgs::x_up2)
   int arena_reuse = 1;  // backbone stages recycle their activation buffers
   int stem_fused = 0;   // bf16 engine runs backbone.stem.0 straight from the uint8 frames (measured neutral -> off, kept tested)
+  int stem_fused_split = 1;   // the same for the bf16x3 engine (hi/lo pairs made on the fly from the bytes): on
   int sel_fused = 1;    // LayerNorm + score head + class max of the query selection in one launch
   int dec_fused = 1;    // 0 = one launch per decoder op
 };
@@ -542,7 +543,8 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   const int eh = c.embedding_size / 2;
   int h = down2(H), w = down2(W);
   Tensor s0 = B.act(P, n, h, w, eh);
-  plan->stem_fused = e->opts.stem_fused && P == BF16 && eh == 32;
+  // bf16x3: on by default - the generic form there is a 105 MB fp32 NHWC-8 image + an fp32-MFMA stem conv (30 + 180 us at R50 bs 8)
+  plan->stem_fused = ((e->opts.stem_fused && P == BF16) || (SP && e->opts.stem_fused_split)) && eh == 32;
   if (plan->stem_fused) {
     // straight from the uint8 frames (ops.hip stem0_u8_kernel); `x` is only materialised on demand for rtd_debug_tensor("input")
     const uint8_t** table = (const uint8_t**)B.alloc((size_t)c.max_batch * sizeof(void*));
@@ -1583,6 +1585,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "dec_fused") == 0) { g_opts.dec_fused = value; return RTD_OK; }
   if (strcmp(name, "sel_fused") == 0) { g_opts.sel_fused = value; return RTD_OK; }
   if (strcmp(name, "stem_fused") == 0) { g_opts.stem_fused = value; return RTD_OK; }
+  if (strcmp(name, "stem_fused_split") == 0) { g_opts.stem_fused_split = value; return RTD_OK; }
   if (strcmp(name, "sc_fold") == 0) { g_opts.sc_fold = value; return RTD_OK; }
   if (strcmp(name, "maxpool_v1") == 0) { maxpool_set_v1(value); return RTD_OK; }
   if (strcmp(name, "arena_reuse") == 0) { g_opts.arena_reuse = value; return RTD_OK; }

@@ -1041,13 +1041,18 @@ typedef __bf16 bf16x8_s __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_s __attribute__((ext_vector_type(4)));
 typedef float f32x16_s __attribute__((ext_vector_type(16)));
 typedef float f32x4_s __attribute__((ext_vector_type(4)));
+// SPLIT (bf16x3 engine): the normalised pixel v / 255.0f is kept as a hi / lo bf16 pair (two patches), the filter row `wq` is a BF16X2 row
+// (K = 72 real taps x channels in 32-element groups [32 hi | 32 lo]), every MFMA step runs hi*hi + hi*lo + lo*hi and the output rows are
+// BF16X2 pixels ([32 hi | 32 lo], y_bstride / ldy in channels).
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __restrict__ table, int H, int W, const bf16* __restrict__ wq, int Kpad,
                                                         const float* __restrict__ bias, bf16* __restrict__ y, long long y_bstride, long long ldy,
                                                         int OH, int OW, int tiles_x, int tiles_y, int act) {
   constexpr int TH = 8, TW = 32, PR = 2 * TH + 1, PC = 2 * TW + 1, ROWE = 200;        // 65 px * 3 = 195 elements per patch row -> 200
   constexpr int NDW = (PC * 3 + 3 + 3) / 4;                                            // aligned dwords that cover one patch row
-  constexpr int ROWO = 64 + 16;                                                        // store slab row: 32 bf16 + skew
+  constexpr int ROWO = (SPLIT ? 128 : 64) + 16;                                        // store slab row: 32 channels + skew
   __shared__ __attribute__((aligned(16))) bf16 patch[PR * ROWE];                        // already normalised: (bf16)(v / 255.0f)
+  __shared__ __attribute__((aligned(16))) bf16 patch_lo[SPLIT ? PR * ROWE : 8];         // SPLIT: bf16(v / 255.0f - hi)
   __shared__ __attribute__((aligned(16))) char stage[4][32 * ROWO];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5;
   int t = blockIdx.x;
@@ -1081,19 +1086,23 @@ __global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __r
       if (el < 0 || el >= PC * 3) continue;
       const int ix = 2 * x0 - 1 + el / 3;
       const float v = (row_ok && (unsigned)ix < (unsigned)W) ? (float)((dw >> (8 * q)) & 0xffu) : 0.f;
-      patch[r * ROWE + el] = (bf16)(v / 255.0f);
+      const float vn = v / 255.0f;
+      const bf16 hi = (bf16)vn;
+      patch[r * ROWE + el] = hi;
+      if (SPLIT) patch_lo[r * ROWE + el] = (bf16)(vn - (float)hi);
     }
   }
   for (int e = tid; e < PR * (ROWE - PC * 3); e += 256) {                               // row tails: read (times a zero filter tap) by the last pixels
     const int r = e / (ROWE - PC * 3), i = e - r * (ROWE - PC * 3);
     patch[r * ROWE + PC * 3 + i] = (bf16)0.f;
+    if (SPLIT) patch_lo[r * ROWE + PC * 3 + i] = (bf16)0.f;
   }
   // K layout chosen for the GATHER, not for the filter: k = 10 kh + e, e = 3 kw + (BGR byte) for e < 9, e = 9 and k = 30, 31 carry
   // zero filter taps.  A filter row of the patch is then 10 consecutive elements starting at an even offset, so the 8 k values of
   // a lane (k = 16 s + 8 (lane >> 5) + j) are at most two runs of whole dwords: 4 ds_read_b32 per MFMA operand instead of 8
   // ds_read_u16 (measured: no change, 44.8 us either way - the launch is bound by the per-block patch staging, not the gather).
   // Pixel p starts at element 6 p: consecutive lanes are 3 banks apart.
-  bf16x8_s wf[2];
+  bf16x8_s wf[2], wfl[2];
   int doff[2][4];                     // dword j of the operand: element offset relative to the pixel's (2 r, 2 p) corner
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -1102,7 +1111,15 @@ __global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __r
       const int k = 16 * s + 8 * h + j;
       const int kh = k / 10, e = k - kh * 10;
       const int kw = e / 3, cb = e - kw * 3;                                            // frame byte cb (BGR) = model channel 2 - cb (RGB)
-      wf[s][j] = (k < 30 && e < 9) ? wq[(size_t)(lane & 31) * Kpad + (kh * 3 + kw) * 8 + (2 - cb)] : (bf16)0.f;   // zero taps: the pixel operand may be anything finite
+      const int kr = (kh * 3 + kw) * 8 + (2 - cb);                                      // the filter's own K index (tap-major, 8 padded channels)
+      const bool real = k < 30 && e < 9;
+      if (SPLIT) {
+        const size_t pos = (size_t)(lane & 31) * Kpad + ((kr >> 5) << 6) + (kr & 31);   // BF16X2 row: group kr / 32, hi half
+        wf[s][j] = real ? wq[pos] : (bf16)0.f;
+        wfl[s][j] = real ? wq[pos + 32] : (bf16)0.f;
+      } else {
+        wf[s][j] = real ? wq[(size_t)(lane & 31) * Kpad + kr] : (bf16)0.f;              // zero taps: the pixel operand may be anything finite
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1115,42 +1132,54 @@ __global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __r
 #pragma unroll 1
   for (int rr = 0; rr < 2; ++rr) {
     const int r = wv * 2 + rr;
-    const bf16* base = patch + (2 * r) * ROWE + (2 * (lane & 31)) * 3;
+    const int eoff = (2 * r) * ROWE + (2 * (lane & 31)) * 3;
+    const bf16* base = patch + eoff;
     f32x16_s acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+      typedef unsigned u4_s __attribute__((ext_vector_type(4)));
       unsigned xd[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) xd[j] = *(const unsigned*)(base + doff[s][j]);
-      typedef unsigned u4_s __attribute__((ext_vector_type(4)));
       const u4_s xv = {xd[0], xd[1], xd[2], xd[3]};
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], __builtin_bit_cast(bf16x8_s, xv), acc, 0, 0, 0);
+      if (SPLIT) {
+        unsigned xl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xl[j] = *(const unsigned*)(patch_lo + eoff + doff[s][j]);
+        const u4_s xlv = {xl[0], xl[1], xl[2], xl[3]};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], __builtin_bit_cast(bf16x8_s, xlv), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfl[s], __builtin_bit_cast(bf16x8_s, xv), acc, 0, 0, 0);
+      }
     }
     const int oy = y0 + r;
     char* sw_ = stage[wv];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4_s bv = *(const f32x4_s*)(bias + 8 * q + 4 * h);
-      bf16x4_s o;
+      bf16x4_s o, ol;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float v = acc[4 * q + e] + bv[e];
         if (act == ACT_RELU) v = fmaxf(v, 0.f);
         else if (act == ACT_SILU) v = v / (1.f + __expf(-v));
         o[e] = (bf16)v;
+        if (SPLIT) ol[e] = (bf16)(v - (float)o[e]);
       }
       *(bf16x4_s*)(sw_ + (lane & 31) * ROWO + (8 * q + 4 * h) * 2) = o;
+      if (SPLIT) *(bf16x4_s*)(sw_ + (lane & 31) * ROWO + 64 + (8 * q + 4 * h) * 2) = ol;
     }
     __builtin_amdgcn_wave_barrier();
     if (oy < OH) {
-      bf16* yrow = y + (long long)b * y_bstride + ((long long)oy * OW + x0) * ldy;
+      constexpr int CPP = SPLIT ? 8 : 4;                                               // 16-byte chunks per output pixel
+      bf16* yrow = y + (SPLIT ? 2 : 1) * ((long long)b * y_bstride + ((long long)oy * OW + x0) * ldy);
 #pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2) {
+      for (int i2 = 0; i2 < CPP / 2; ++i2) {
         const int idx = i2 * 64 + lane;
-        const int p = idx >> 2, ch = idx & 3;
-        if (x0 + p < OW) *(bf16x8_s*)(yrow + (long long)p * ldy + ch * 8) = *(const bf16x8_s*)(sw_ + p * ROWO + ch * 16);
+        const int p = idx / CPP, ch = idx % CPP;
+        if (x0 + p < OW) *(bf16x8_s*)(yrow + (SPLIT ? 2 : 1) * (long long)p * ldy + ch * 8) = *(const bf16x8_s*)(sw_ + p * ROWO + ch * 16);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1159,11 +1188,15 @@ __global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __r
 void launch_stem0_u8(const uint8_t* const* table_dev, int n, int H, int W, const void* w, int Kpad, const float* bias, const Tensor& y, int act,
                      hipStream_t s) {
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  RTD_CHECK(y.dt == BF16 && y.c == 32 && y.h == OH && y.w == OW && y.n >= n && y.ld % 8 == 0 && (act == ACT_RELU || act == ACT_NONE || act == ACT_SILU), 1,
-            "stem0_u8: output must be bf16 [n, H/2, W/2, 32]");
+  RTD_CHECK((y.dt == BF16 || y.dt == BF16X2) && y.c == 32 && y.h == OH && y.w == OW && y.n >= n && y.ld % (y.dt == BF16X2 ? SPLIT_GROUP : 8) == 0 &&
+                (act == ACT_RELU || act == ACT_NONE || act == ACT_SILU), 1, "stem0_u8: output must be bf16 / BF16X2 [n, H/2, W/2, 32]");
   const int tiles_x = (OW + 31) / 32, tiles_y = (OH + 7) / 8;
-  hipLaunchKernelGGL(stem0_u8_kernel, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, table_dev, H, W, (const bf16*)w, Kpad, bias, (bf16*)y.p,
-                     (long long)y.bstride, (long long)y.ld, OH, OW, tiles_x, tiles_y, act);
+  if (y.dt == BF16X2)
+    hipLaunchKernelGGL(stem0_u8_kernel<true>, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, table_dev, H, W, (const bf16*)w, Kpad, bias, (bf16*)y.p,
+                       (long long)y.bstride, (long long)y.ld, OH, OW, tiles_x, tiles_y, act);
+  else
+    hipLaunchKernelGGL(stem0_u8_kernel<false>, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, table_dev, H, W, (const bf16*)w, Kpad, bias, (bf16*)y.p,
+                       (long long)y.bstride, (long long)y.ld, OH, OW, tiles_x, tiles_y, act);
   HIP_CHECK(hipGetLastError());
 }
 

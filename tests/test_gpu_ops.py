@@ -280,7 +280,9 @@ SPLIT_CONV_CASES = [
     (1, 33, 29, 32, 96, 3, 1, 1, "silu", 0, 0),         # one channel group per tap, ragged M, Cout not a tile multiple
     (2, 40, 40, 64, 128, 3, 2, 1, "relu", 1, 0),        # stride 2, pre-activation BF16X2 residual
     (1, 16, 16, 128, 256, 1, 1, 0, "none", 2, 0),       # post-activation residual
-    (4, 60, 264, 32, 32, 3, 1, 1, "relu", 0, 0),        # stem.1: half-empty 64-channel tile
+    (4, 60, 264, 32, 32, 3, 1, 1, "relu", 0, 0),        # stem.1: the direct (filter-in-registers) split kernel, ragged tiles both ways
+    (4, 68, 232, 32, 64, 3, 1, 1, "silu", 0, 0),        # stem.2: two channel groups per block
+    (2, 40, 40, 32, 32, 3, 1, 1, "relu", 0, 0),         # small map: stays on the tiled kernel (half-empty 64-channel tile)
     (4, 80, 80, 128, 128, 3, 1, 1, "silu", 1, 0),       # 2-stage kernel (>= 257 blocks)
     (4, 100, 97, 128, 192, 3, 1, 1, "silu", 2, 0),      # ragged M, partial last N tile, post residual
     (2, 160, 160, 64, 256, 1, 1, 0, "relu", 1, 0),      # stage-0 c3

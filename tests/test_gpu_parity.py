@@ -517,6 +517,37 @@ def test_fused_uint8_stem_matches_the_generic_preprocess_plus_conv():
         assert m >= n - 8, (b, m, n, ws, wb)                                     # measured: <= 5 of 300 miss (the resized frame)
 
 
+def test_bf16x3_fused_uint8_stem_matches_the_generic_stem():
+    """bf16x3: backbone.stem.0 straight from the uint8 frames (default, hi/lo pairs made on the fly) against the generic form (fp32
+    NHWC-8 image + exact fp32-MFMA conv): same detections at the north-star tolerance; the first stage output agrees to split rounding."""
+    from telescope_cam_detection_amd import _capi
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.synth import scene_frame
+    from telescope_cam_detection_amd.weights import fold_weights, pack_blob, synth_weights
+
+    arch = ARCHS["r18"]
+    w = synth_weights(arch, 3)
+    blob = pack_blob(fold_weights(arch, w))
+    frames = [scene_frame(70, 640, 640), scene_frame(71, 480, 600), scene_frame(72, 640, 640)]
+    out, stem = {}, {}
+    for fused in (0, 1):
+        _capi.debug_option("stem_fused_split", fused)
+        eng = _capi.Engine(arch, blob, 0, _capi.PREC_BF16X3, 3, (640, 640), True)
+        for _ in range(2):
+            out[fused] = eng.infer_raw(frames)
+        stem[fused] = eng.debug_tensor("stem").astype(np.float64)
+        out[("input", fused)] = eng.debug_tensor("input")[:, :, :, :3]
+        eng.close()
+    np.testing.assert_array_equal(out[("input", 0)], out[("input", 1)])
+    e = np.linalg.norm(stem[0] - stem[1]) / np.linalg.norm(stem[0])
+    print(f"bf16x3 fused stem vs generic: stem rel l2 {e:.2e}")
+    assert e < 1e-5
+    for b in range(len(frames)):
+        m, n, ws, wb = match_detections(out[0][0][b], out[0][1][b], out[0][2][b], out[1][0][b], out[1][1][b], out[1][2][b], 1e-3, 1e-2)
+        print(f"bf16x3 fused stem vs generic [{b}]: matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
+        assert m >= n - 2, (b, m, n, ws, wb)
+
+
 def test_non_square_input_with_partial_tiles_bf16_and_fp32():
     """416 x 736 (multiples of 32, but 208 x 368 and 104 x 184 are not multiples of the 8 x 32 / 128-pixel tiles): every conv
     kernel family meets ragged tiles.  fp32 engine vs oracle at the north-star tolerance, bf16 engine vs fp32 engine to bf16 noise."""
