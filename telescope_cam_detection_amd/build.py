@@ -59,6 +59,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    # -shared accepts undefined symbols: a kernel whose host stub was not emitted (seen with ROCm 7.2 on a kernel template holding a
+    # dependent-extent array captured by a lambda) only fails at dlopen on the GPU box.  Refuse to ship such a library.
+    nm = shutil.which("nm")
+    if nm:
+        u = subprocess.run([nm, "-C", "--undefined-only", tmp], capture_output=True, text=True).stdout
+        bad = [l.strip() for l in u.splitlines() if "rtd::" in l or "__device_stub__" in l]
+        if bad:
+            os.remove(tmp)
+            raise RuntimeError("libmi355rtdetr.so would have unresolved kernel symbols:\n" + "\n".join(bad[:10]))
     os.replace(tmp, LIB_PATH)
     if verbose:
         print(f"built {LIB_PATH}")

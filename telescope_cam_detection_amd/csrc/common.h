@@ -115,6 +115,12 @@ int conv_kpad_split(int K);           // BF16X2 filter row length in bf16 elemen
 bool conv_split_supported(const ConvArgs& a);   // BF16X2 input: does the split kernel take this launch?
 void conv_set_split_ws2_min_blocks(int v);
 void conv_set_split_ws64_max_blocks(int v);
+void conv_set_split_kernel(int v);
+void conv_set_split_flex(int v);
+void conv_set_split_flex_min_nk(int v);
+void conv_set_split_flex_force(int v);
+void conv_set_split_persist(int v);
+void conv_set_split_persist_min_tiles(int v);
 int conv_npad(int N);
 void conv_set_force_v1(int v);      // A/B hook: 1 = never take the large-tile (v2) path
 void conv_set_glds_min_blocks(int v);

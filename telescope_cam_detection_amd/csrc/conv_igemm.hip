@@ -836,9 +836,9 @@ __device__ __forceinline__ void ws_copy_out(const ConvK& a, const float* st, int
 
 // BF16X2 output, tile already final in LDS as split rows ([pixel][2 BN bf16]: the tile's BN / 32 channel groups, each [32 hi | 32 lo],
 // exactly the bytes of the pixel's slice in global memory): pure 16-byte moves, 4 BN bytes per pixel row.
-template <int BN>
+template <int BN, int ROWS = 128>
 __device__ __forceinline__ void ws_copy_out_split_rows(const ConvK& a, const bf16* sb, int SLB, int tid, int m0, int n0) {
-  constexpr int CH = 2 * BN / 8, RSTEP = 512 / CH, ITERS = 128 / RSTEP;
+  constexpr int CH = 2 * BN / 8, RSTEP = 512 / CH, ITERS = (ROWS + RSTEP - 1) / RSTEP;
   const int ch = tid % CH;
   if (n0 + (ch >> 3) * SPLIT_GROUP >= a.N) return;               // whole 32-channel groups (N % 32 == 0)
   int m = m0 + tid / CH;
@@ -846,17 +846,18 @@ __device__ __forceinline__ void ws_copy_out_split_rows(const ConvK& a, const bf1
   int p = m - b * a.OHW;
   long long yoff = 2 * ((long long)b * a.y_bstride + (long long)p * a.ldy + n0) + ch * 8;   // bf16 elements
   const bf16* srow = sb + (tid / CH) * SLB + ch * 8;
+  int row = tid / CH;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    if (m < a.M) *(bf16x8*)((bf16*)a.y + yoff) = *(const bf16x8*)srow;
-    m += RSTEP; p += RSTEP; yoff += 2 * RSTEP * a.ldy; srow += RSTEP * SLB;
+    if (m < a.M && (ROWS % RSTEP == 0 || row < ROWS)) *(bf16x8*)((bf16*)a.y + yoff) = *(const bf16x8*)srow;
+    m += RSTEP; p += RSTEP; row += RSTEP; yoff += 2 * RSTEP * a.ldy; srow += RSTEP * SLB;
     while (p >= a.OHW) { p -= a.OHW; yoff += 2 * (a.y_bstride - (long long)a.OHW * a.ldy); }
   }
 }
 
 // Copy-out of the split kernels' fp32 staging tile: bias (+ residual: BF16X2 or fp32) -> activation -> BF16X2 or fp32 output, 8 channels
 // per thread and iteration.  ldy / ldr count channels for either type (ConvK::y_split).
-template <int ITERS, int ACT, int BN>
+template <int ITERS, int ACT, int BN, int ROWS = 128>
 __device__ __forceinline__ void ws_copy_out_sp(const ConvK& a, const float* st, int SLD, int tid, int m0, int n0) {
   constexpr int CH8 = BN / 8, RSTEP = 512 / CH8;
   const int c8 = tid % CH8;
@@ -869,9 +870,10 @@ __device__ __forceinline__ void ws_copy_out_sp(const ConvK& a, const float* st, 
   long long ypix = (long long)b * a.y_bstride + (long long)p * a.ldy;
   long long rpix = (long long)b * a.r_bstride + (long long)p * a.ldr;
   const float* srow = st + (tid / CH8) * SLD + c8 * 8;
+  int row = tid / CH8;
 #pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    if (m < a.M) {
+  for (int it = 0; it < ITERS; ++it, row += RSTEP) {
+    if (m < a.M && (ROWS % RSTEP == 0 || row < ROWS)) {
       const f32x4 s0 = *(const f32x4*)(srow), s1 = *(const f32x4*)(srow + 4);
       float v[8] = {s0[0] + b0[0], s0[1] + b0[1], s0[2] + b0[2], s0[3] + b0[3],
                     s1[0] + b1[0], s1[1] + b1[1], s1[2] + b1[2], s1[3] + b1[3]};
@@ -1373,6 +1375,719 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamps[4] = (long long)__builtin_amdgcn_s_memtime() - t_base;
     stamps[7] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// v4x: the wave-specialised kernel for BF16X2 operands (the bf16x3 engine's convolution), its own function so that the MFMA
+// shape can be chosen: the loader role, the LDS image (128-byte rows = one [32 hi | 32 lo] channel group, source-side XOR swizzle) and
+// the barrier protocol are conv_igemm_ws_kernel's; the MFMA waves run hi*hi + hi*lo + lo*hi either on v_mfma_f32_32x32x16_bf16 (two
+// 16-deep halves of the group per K-step) or, M16, on v_mfma_f32_16x16x32_bf16 (one 32-deep step: lane l reads row l & 15, 16-byte
+// chunk l >> 4 of the hi half, chunk 4 + (l >> 4) of the lo half - conflict-free under the same swizzle).  Microbenchmarks with the DMA
+// switched off (tools/conv_bench.py --opt glds_drop --vals 0,4) show the MFMA-wave side, not the data movement, bounds this kernel
+// (3x3 256 -> 256 at 80^2: 133 us with, 113 us without any DMA), and on random data the chip's clock under MFMA load; the 16x16x32
+// shape holds a higher clock for the same flops (MI355X_MICROARCH.md, DVFS give-back item 7).
+template <int STAGES, int BN, bool M16>
+__global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_kernel(const ConvG g) {
+  const ConvK& a = g.k;
+  constexpr int BM = 128;
+  static_assert(BN == 128 || BN == 64, "tile widths");
+  constexpr int TJ = BN == 128 ? 2 : 1;          // 32-pixel tiles per MFMA wave; 64 channels per wave
+  constexpr int NBI = BN / 32;
+  constexpr int PPT = 4 + NBI;
+  constexpr int CH8 = BN / 8, RSTEP = 512 / CH8, CITERS = BM / RSTEP;
+  constexpr int BK = 64;                          // bf16 elements per K-step = 32 channels x (hi, lo)
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int SLD = BN + 4;
+  constexpr int SMEM = (STAGES * STAGE > BM * SLD * 4) ? STAGES * STAGE : BM * SLD * 4;
+  constexpr int AHEAD = STAGES - 1;
+  static_assert(STAGES >= 2 && STAGES <= 4, "counted waits below assume 1..3 tiles ahead");
+  __shared__ __attribute__((aligned(16))) char smem[SMEM + 256];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wv >= 4;
+  const int w4 = wv & 3;
+  const int wm = BN == 128 ? (w4 & 1) : w4, wn = BN == 128 ? (w4 >> 1) : 0;
+  int wg;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = wg % a.ntn, mt = wg / a.ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int nk = a.Kpad / BK;
+
+  // accumulators: 32x32 tiles [channel tile][pixel tile] x 16, or 16x16 tiles [4 channel tiles][2 TJ pixel tiles] x 4 - 32 TJ floats per lane either way
+  f32x16 acc[M16 ? 1 : 2][M16 ? 1 : TJ];
+  f32x4 acc16[M16 ? 4 : 1][M16 ? 2 * TJ : 1];
+  if constexpr (M16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * TJ; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  if (!loader) prefetch_share(a, blockIdx.x, gridDim.x, tid, 256, smem + SMEM);
+
+  if (loader) {
+    // ---- loader role (conv_igemm_ws_kernel's) ---------------------------------------------------------
+    const int lrow = w4 * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((w4 * 4 + (lane >> 4)) & 7);
+    int a_off[4], a_iy0[4], a_ix0[4], b_off[4], a2_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + i * 32 + lrow;
+      a2_off[i] = (int)0x80000000;
+      if (m < a.M) {
+        const int b = m / a.OHW;
+        const int r = m - b * a.OHW;
+        const int oy = r / a.OW;
+        const int ox = r - oy * a.OW;
+        a_iy0[i] = oy * a.stride - a.pad;
+        a_ix0[i] = ox * a.stride - a.pad;
+        a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)a_iy0[i] * a.W + a_ix0[i]) * a.ldx) * 2) + chunk * 16;
+        if (a.x_up2) a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)(oy >> 1) * (a.W >> 1) + (ox >> 1)) * a.ldx) * 2) + chunk * 16;
+        if (a.x2) a2_off[i] = (int)(((long long)b * a.x2_bstride + (long long)r * a.ldx2) * 2) + chunk * 16;
+      } else {
+        a_iy0[i] = -(1 << 28);
+        a_ix0[i] = -(1 << 28);
+        a_off[i] = 0;
+      }
+      b_off[i] = (n0 + i * 32 + lrow) * a.Kpad * 2 + chunk * 16;
+    }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x), 0, a.x2 ? g.x2_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
+    int k0 = 0, kh = 0, kw = 0, c0 = 0;
+    auto issue = [&](int buf) {
+      if (g.probe & 4) return;
+      char* sa = smem + buf * STAGE + w4 * 1024;
+      if (a.x2 && k0 >= a.k2_start) {
+        const int d2 = (k0 - a.k2_start) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, (lds_ptr_t)(sa + i * 4096), 16, (unsigned)a2_off[i] + (a2_off[i] < 0 ? 0u : (unsigned)d2), 0, 0, 0);
+      } else {
+        const int delta = ((kh * a.W + kw) * (int)a.ldx + c0) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+          const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+          const unsigned vo = ok ? (unsigned)(a_off[i] + delta) : 0x80000000u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 4096), 16, vo, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NBI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sa + BM * 128 + i * 4096), 16, (unsigned)(b_off[i] + k0 * 2), 0, 0, 0);
+      k0 += BK;
+      c0 += BK;
+      if (c0 >= a.Cin) {
+        c0 = 0;
+        if (++kw == a.KW) { kw = 0; ++kh; }
+      }
+    };
+    for (int t = 0; t < AHEAD && t < nk; ++t) issue(t);
+    for (int ks = 0; ks < nk; ++ks) {
+      const int younger = nk - 1 - ks;
+      if (STAGES == 4 && younger >= 2) wait_vmcnt<2 * PPT>();
+      else if (STAGES >= 3 && younger >= 1) wait_vmcnt<PPT>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (ks + AHEAD < nk) issue((ks + AHEAD) % STAGES);
+    }
+  } else if constexpr (M16) {
+    // ---- MFMA role, 16x16x32: one 32-deep step per K-step.  The wave's 8 filter fragments stay live; pixel fragments come tile by tile ----
+    const int r16 = lane & 15, c4 = lane >> 4;
+    const int sw = (r16 >> 1) & 7;
+    const int foh = r16 * 128 + ((c4 ^ sw) << 4), fol = r16 * 128 + (((c4 + 4) ^ sw) << 4);
+    for (int ks = 0; ks < nk; ++ks) {
+      __builtin_amdgcn_s_barrier();
+      const char* sa = smem + (ks % STAGES) * STAGE + wm * (32 * TJ) * 128;
+      const char* sb = smem + (ks % STAGES) * STAGE + (BM + wn * 64) * 128;
+      bf16x8 wh[4], wl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { wh[i] = *(const bf16x8*)(sb + i * 2048 + foh); wl[i] = *(const bf16x8*)(sb + i * 2048 + fol); }
+#pragma unroll
+      for (int j = 0; j < 2 * TJ; ++j) {
+        const bf16x8 xh = *(const bf16x8*)(sa + j * 2048 + foh), xl = *(const bf16x8*)(sa + j * 2048 + fol);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh, acc16[i][j], 0, 0, 0);
+          acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl, acc16[i][j], 0, 0, 0);
+          acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh, acc16[i][j], 0, 0, 0);
+        }
+      }
+    }
+  } else {
+    // ---- MFMA role, 32x32x16: fragment kk of a K-step = channels 16 (kk & 1) .. +15 of the group, hi (kk < 2) or lo ----
+    int foff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 128 + (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
+    for (int ks = 0; ks < nk; ++ks) {
+      __builtin_amdgcn_s_barrier();
+      const char* sa = smem + (ks % STAGES) * STAGE + wm * (32 * TJ) * 128;
+      const char* sb = smem + (ks % STAGES) * STAGE + (BM + wn * 64) * 128;
+#pragma unroll
+      for (int sh = 0; sh < 2; ++sh) {
+        bf16x8 xh[TJ], xl[TJ], wh[2], wl[2];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) { xh[j] = *(const bf16x8*)(sa + j * 4096 + foff[sh]); xl[j] = *(const bf16x8*)(sa + j * 4096 + foff[sh + 2]); }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { wh[i] = *(const bf16x8*)(sb + i * 4096 + foff[sh]); wl[i] = *(const bf16x8*)(sb + i * 4096 + foff[sh + 2]); }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+  }
+  __syncthreads();                                 // every MFMA operand read is done: smem becomes the staging tile
+
+  // every accumulator group = 4 consecutive channels (cl..cl+3 inside the tile) of one pixel (row pl of the tile)
+  auto for_each_group = [&](auto&& f) {
+    if constexpr (M16) {
+      const int r16 = lane & 15, c4 = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * TJ; ++j) f(wn * 64 + 16 * i + 4 * c4, wm * (32 * TJ) + 16 * j + r16, acc16[i][j]);
+    } else {
+      const int h = lane >> 5;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            f(wn * 64 + i * 32 + 8 * q + 4 * h, wm * (32 * TJ) + j * 32 + (lane & 31), f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]});
+    }
+  };
+  if (a.y_split && a.res_mode == RES_NONE) {
+    // bias + activation + hi/lo split on the accumulators, the tile's BF16X2 rows through LDS, plain copy-out
+    constexpr int SLB = 2 * BN + 8;
+    bf16* sb = (bf16*)smem;
+    if (!loader) {
+      dispatch_act(a.act, [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
+        for_each_group([&](int cl, int pl, const f32x4& v) {
+          const f32x4 bv = *(const f32x4*)(a.bias + n0 + cl);
+          bf16x4 oh, ol;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { bf16 hi, lo; split2(act_c<ACT>(v[e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
+          bf16* d = sb + pl * SLB + ((cl >> 5) << 6) + (cl & 31);
+          *(bf16x4*)d = oh;
+          *(bf16x4*)(d + SPLIT_GROUP) = ol;
+        });
+      });
+    }
+    __syncthreads();
+    ws_copy_out_split_rows<BN>(a, sb, SLB, tid, m0, n0);
+    return;
+  }
+  float* st = (float*)smem;
+  if (!loader) for_each_group([&](int cl, int pl, const f32x4& v) { *(f32x4*)(&st[pl * SLD + cl]) = v; });
+  __syncthreads();
+  dispatch_act(a.act, [&](auto actc) { ws_copy_out_sp<CITERS, decltype(actc)::value, BN>(a, st, SLD, tid, m0, n0); });
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// v4f: the BF16X2 kernel on a tile of FLEXIBLE height: MT pixel tiles of 16 rows (MT = 4 .. 13: 64 .. 208 pixels) x BN channels.
+// The MFMA-bound layers lose ~20 % to tile-count quantization with fixed 128 x 128 tiles (3x3 256 -> 256 at 80^2 = 800 tiles takes as long
+// as 1014 tiles would: tools/conv_bench.py --only quant; 40^2 maps give 200 tiles for 256 CUs, 20^2 maps 100).  Here the host picks the
+// tile height so that the grid is close to a whole number of rounds of the chip (launch_conv_split), e.g. 208 x 128 for 80^2 x 256
+// channels: 494 blocks = 2 rounds of one block per CU, 96 % full.
+// Wave layout 1 x 4: every MFMA wave owns ALL MT pixel tiles and BN / 4 channels (any MT balances), v_mfma_f32_16x16x32_bf16, its
+// 2 (BN = 128) or 1 (BN = 64) filter fragment pairs live for the K-step, pixel fragments tile by tile.  Loader role, LDS image, swizzle and
+// barrier protocol as conv_igemm_wsx_kernel; the A part of a stage holds AROWS = MT x 16 rounded up to 32 rows.
+template <int STAGES, int BN, int MT>
+__global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsf_kernel(const ConvG g) {
+  const ConvK& a = g.k;
+  constexpr int BM = MT * 16;
+  constexpr int AROWS = (BM + 31) / 32 * 32;
+  constexpr int NAI = AROWS / 32, NBI = BN / 32;
+  constexpr int PPT = NAI + NBI;
+  constexpr int CT = BN / 64;                     // 16-channel tiles per MFMA wave
+  constexpr int CH8 = BN / 8, RSTEP = 512 / CH8, CITERS = (BM + RSTEP - 1) / RSTEP;
+  constexpr int BK = 64;
+  constexpr int STAGE = (AROWS + BN) * 128;
+  constexpr int SLD = BN + 4, SLB = 2 * BN + 8;
+  constexpr int EPI = (BM * SLD * 4 > BM * SLB * 2) ? BM * SLD * 4 : BM * SLB * 2;
+  constexpr int SMEM = (STAGES * STAGE > EPI) ? STAGES * STAGE : EPI;
+  constexpr int AHEAD = STAGES - 1;
+  static_assert(STAGES >= 2 && STAGES <= 4 && MT >= 1 && MT <= 14 && (BN == 64 || BN == 128), "tile shape");
+  static_assert(SMEM + 256 <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) char smem[SMEM + 256];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wv >= 4;
+  const int w4 = wv & 3;
+  int wg;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = wg % a.ntn, mt = wg / a.ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int nk = a.Kpad / BK;
+
+  f32x4 acc[CT][MT];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!loader) prefetch_share(a, blockIdx.x, gridDim.x, tid, 256, smem + SMEM);
+
+  if (loader) {
+    const int lrow = w4 * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((w4 * 4 + (lane >> 4)) & 7);
+    int a_off[NAI], a_iy0[NAI], a_ix0[NAI], b_off[NBI];
+    unsigned a2_off[8];   // fixed extent (NAI <= 7): with a dependent extent hipcc (ROCm 7.2) silently drops the HOST stub of every instantiation
+    static_assert(NAI <= 8, "a2_off");
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) {
+      const int row = i * 32 + lrow;
+      const int m = m0 + row;
+      a2_off[i] = 0x80000000u;
+      if (m < a.M && row < BM) {
+        const int b = m / a.OHW;
+        const int r = m - b * a.OHW;
+        const int oy = r / a.OW;
+        const int ox = r - oy * a.OW;
+        a_iy0[i] = oy * a.stride - a.pad;
+        a_ix0[i] = ox * a.stride - a.pad;
+        a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)a_iy0[i] * a.W + a_ix0[i]) * a.ldx) * 2) + chunk * 16;
+        if (a.x_up2) a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)(oy >> 1) * (a.W >> 1) + (ox >> 1)) * a.ldx) * 2) + chunk * 16;
+        if (a.x2) a2_off[i] = (unsigned)(((long long)b * a.x2_bstride + (long long)r * a.ldx2) * 2) + chunk * 16;
+      } else {
+        a_iy0[i] = -(1 << 28);
+        a_ix0[i] = -(1 << 28);
+        a_off[i] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) b_off[i] = (n0 + i * 32 + lrow) * a.Kpad * 2 + chunk * 16;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x), 0, a.x2 ? g.x2_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
+    int k0 = 0, kh = 0, kw = 0, c0 = 0;
+    auto issue = [&](int buf) {
+      if (g.probe & 4) return;
+      char* sa = smem + buf * STAGE + w4 * 1024;
+      if (a.x2 && k0 >= a.k2_start) {
+        const int d2 = (k0 - a.k2_start) * 2;
+#pragma unroll
+        for (int i = 0; i < NAI; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, (lds_ptr_t)(sa + i * 4096), 16, a2_off[i] + ((a2_off[i] >> 31) ? 0u : (unsigned)d2), 0, 0, 0);
+      } else {
+        const int delta = ((kh * a.W + kw) * (int)a.ldx + c0) * 2;
+#pragma unroll
+        for (int i = 0; i < NAI; ++i) {
+          const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+          const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+          const unsigned vo = ok ? (unsigned)(a_off[i] + delta) : 0x80000000u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 4096), 16, vo, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NBI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sa + AROWS * 128 + i * 4096), 16, (unsigned)(b_off[i] + k0 * 2), 0, 0, 0);
+      k0 += BK;
+      c0 += BK;
+      if (c0 >= a.Cin) {
+        c0 = 0;
+        if (++kw == a.KW) { kw = 0; ++kh; }
+      }
+    };
+    for (int t = 0; t < AHEAD && t < nk; ++t) issue(t);
+    for (int ks = 0; ks < nk; ++ks) {
+      const int younger = nk - 1 - ks;
+      if (STAGES == 4 && younger >= 2) wait_vmcnt<2 * PPT>();
+      else if (STAGES >= 3 && younger >= 1) wait_vmcnt<PPT>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (ks + AHEAD < nk) issue((ks + AHEAD) % STAGES);
+    }
+  } else {
+    const int r16 = lane & 15, c4 = lane >> 4;
+    const int sw = (r16 >> 1) & 7;
+    const int foh = r16 * 128 + ((c4 ^ sw) << 4), fol = r16 * 128 + (((c4 + 4) ^ sw) << 4);
+    for (int ks = 0; ks < nk; ++ks) {
+      __builtin_amdgcn_s_barrier();
+      const char* sa = smem + (ks % STAGES) * STAGE;
+      const char* sb = sa + (AROWS + w4 * (BN / 4)) * 128;
+      bf16x8 wh[CT], wl[CT];
+#pragma unroll
+      for (int i = 0; i < CT; ++i) { wh[i] = *(const bf16x8*)(sb + i * 2048 + foh); wl[i] = *(const bf16x8*)(sb + i * 2048 + fol); }
+      // pixel fragments of tile j + 1 are read while the MFMAs of tile j issue (pinned: with one MFMA wave per SIMD an LDS round trip in
+      // front of every tile's MFMAs idles the matrix pipe)
+      bf16x8 xh[2], xl[2];
+      xh[0] = *(const bf16x8*)(sa + foh); xl[0] = *(const bf16x8*)(sa + fol);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        if (j + 1 < MT) { xh[(j + 1) & 1] = *(const bf16x8*)(sa + (j + 1) * 2048 + foh); xl[(j + 1) & 1] = *(const bf16x8*)(sa + (j + 1) * 2048 + fol); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh[j & 1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl[j & 1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh[j & 1], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  __syncthreads();
+
+  auto for_each_group = [&](auto&& f) {
+    const int r16 = lane & 15, c4 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) f(w4 * (BN / 4) + 16 * i + 4 * c4, 16 * j + r16, acc[i][j]);
+  };
+  if (a.y_split && a.res_mode == RES_NONE) {
+    bf16* sb = (bf16*)smem;
+    if (!loader) {
+      dispatch_act(a.act, [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
+        for_each_group([&](int cl, int pl, const f32x4& v) {
+          const f32x4 bv = *(const f32x4*)(a.bias + n0 + cl);
+          bf16x4 oh, ol;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { bf16 hi, lo; split2(act_c<ACT>(v[e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
+          bf16* d = sb + pl * SLB + ((cl >> 5) << 6) + (cl & 31);
+          *(bf16x4*)d = oh;
+          *(bf16x4*)(d + SPLIT_GROUP) = ol;
+        });
+      });
+    }
+    __syncthreads();
+    ws_copy_out_split_rows<BN, BM>(a, sb, SLB, tid, m0, n0);
+    return;
+  }
+  float* st = (float*)smem;
+  if (!loader) for_each_group([&](int cl, int pl, const f32x4& v) { *(f32x4*)(&st[pl * SLD + cl]) = v; });
+  __syncthreads();
+  dispatch_act(a.act, [&](auto actc) { ws_copy_out_sp<CITERS, decltype(actc)::value, BN, BM>(a, st, SLD, tid, m0, n0); });
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// v4p: PERSISTENT BF16X2 kernel with three wave roles.  A block of the fixed-tile kernels lives ~16 us for a short K loop (1x1 convs
+// with K = 256: 8 K-steps = 2.4 us of matrix-pipe time): the first DMA's round trip, the accumulator staging, the copy-out and the
+// block turnover are serial per block, and two co-resident blocks only overlap part of it (tools/conv_bench.py --only kfix: 800 tiles
+// cost 15 us + 1.6 us per K-step; the value projection, 6300 tiles, ran at 30 % matrix-pipe duty).  Here ONE block per CU walks a
+// contiguous range of tiles (112 pixels x 128 channels, the grid's tiles divided evenly over 256 blocks) and nothing is serial:
+//   loader waves (4)  run the flattened (tile, K-step) sequence through a 3-stage ring, two stages ahead, straight across tile
+//                     boundaries - the next tile's first stages are in flight while the current tile finishes;
+//   MFMA waves (4)    1 x 4 layout (all 7 pixel tiles x 32 channels each, v_mfma_f32_16x16x32_bf16, hi*hi + hi*lo + lo*hi); after a tile's
+//                     last K-step they drop the RAW fp32 accumulators into a staging tile (56 ds_write_b128 each) and start the next tile;
+//   store waves (4)   turn the previous tile's staging into output - bias, residual, activation, hi/lo split, 16-byte stores - in
+//                     slices between the K-step barriers of the tile the MFMA waves are computing (VALU and memory work beside MFMA work).
+// One s_barrier per K-step orders all three roles.  The store waves finish reading a staging tile before they arrive at the barrier of
+// the following tile's LAST K-step; the MFMA waves overwrite it only after that barrier.  K loops need >= 2 steps.
+template <int MT>
+__global__ __launch_bounds__(768, 3) void conv_igemm_wsp_kernel(const ConvG g, int total_tiles) {
+  const ConvK& a = g.k;
+  constexpr int BN = 128, STAGES = 3, AHEAD = 2, BK = 64;
+  constexpr int BM = MT * 16;
+  constexpr int AROWS = (BM + 31) / 32 * 32;
+  constexpr int NAI = AROWS / 32, NBI = BN / 32, PPT = NAI + NBI, CT = BN / 64;
+  constexpr int STAGE = (AROWS + BN) * 128;
+  constexpr int SLD = BN + 4;
+  constexpr int RING = STAGES * STAGE;
+  constexpr int SMEM = RING + BM * SLD * 4;
+  static_assert(SMEM + 256 <= 160 * 1024 && NAI <= 8, "LDS");
+  __shared__ __attribute__((aligned(16))) char smem[SMEM + 256];
+  float* const st = (float*)(smem + RING);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wv >> 2, w4 = wv & 3;            // 0 MFMA, 1 loader, 2 store
+  const int nk = a.Kpad / BK;
+  const int t0 = (int)((long long)blockIdx.x * total_tiles / gridDim.x), t1 = (int)((long long)(blockIdx.x + 1) * total_tiles / gridDim.x);
+  const int nloc = t1 - t0;
+  const int total = nloc * nk;                      // flattened (tile, K-step) sequence of this block
+
+  if (role == 1) {
+    // ---- loader waves ---------------------------------------------------------------------------------
+    const int lrow = w4 * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((w4 * 4 + (lane >> 4)) & 7);
+    int a_off[NAI], a_iy0[NAI], a_ix0[NAI], b_off[NBI];
+    unsigned a2_off[8];
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x), 0, a.x2 ? g.x2_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
+    int k0 = 0, kh = 0, kw = 0, c0 = 0, iks = 0, itile = t0, istep = 0, cur_mt = -1;
+    auto setup = [&](int tile) {
+      const int nt = tile % a.ntn, mt = tile / a.ntn;
+      const int n0 = nt * BN;
+#pragma unroll
+      for (int i = 0; i < NBI; ++i) b_off[i] = (n0 + i * 32 + lrow) * a.Kpad * 2 + chunk * 16;
+      if (mt == cur_mt) return;                     // same pixels as the previous tile: only the filter rows move
+      cur_mt = mt;
+      const int m0 = mt * BM;
+#pragma unroll
+      for (int i = 0; i < NAI; ++i) {
+        const int row = i * 32 + lrow;
+        const int m = m0 + row;
+        a2_off[i] = 0x80000000u;
+        if (m < a.M && row < BM) {
+          const int b = m / a.OHW;
+          const int r = m - b * a.OHW;
+          const int oy = r / a.OW;
+          const int ox = r - oy * a.OW;
+          a_iy0[i] = oy * a.stride - a.pad;
+          a_ix0[i] = ox * a.stride - a.pad;
+          a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)a_iy0[i] * a.W + a_ix0[i]) * a.ldx) * 2) + chunk * 16;
+          if (a.x_up2) a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)(oy >> 1) * (a.W >> 1) + (ox >> 1)) * a.ldx) * 2) + chunk * 16;
+          if (a.x2) a2_off[i] = (unsigned)(((long long)b * a.x2_bstride + (long long)r * a.ldx2) * 2) + chunk * 16;
+        } else {
+          a_iy0[i] = -(1 << 28);
+          a_ix0[i] = -(1 << 28);
+          a_off[i] = 0;
+        }
+      }
+    };
+    auto issue_next = [&]() {
+      if (iks == 0) { setup(itile); k0 = 0; kh = 0; kw = 0; c0 = 0; }
+      if (!(g.probe & 4)) {
+        char* sa = smem + (istep % STAGES) * STAGE + w4 * 1024;
+        if (a.x2 && k0 >= a.k2_start) {
+          const int d2 = (k0 - a.k2_start) * 2;
+#pragma unroll
+          for (int i = 0; i < NAI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, (lds_ptr_t)(sa + i * 4096), 16, a2_off[i] + ((a2_off[i] >> 31) ? 0u : (unsigned)d2), 0, 0, 0);
+        } else {
+          const int delta = ((kh * a.W + kw) * (int)a.ldx + c0) * 2;
+#pragma unroll
+          for (int i = 0; i < NAI; ++i) {
+            const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned vo = ok ? (unsigned)(a_off[i] + delta) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 4096), 16, vo, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NBI; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sa + AROWS * 128 + i * 4096), 16, (unsigned)(b_off[i] + k0 * 2), 0, 0, 0);
+      }
+      k0 += BK;
+      c0 += BK;
+      if (c0 >= a.Cin) {
+        c0 = 0;
+        if (++kw == a.KW) { kw = 0; ++kh; }
+      }
+      ++istep;
+      if (++iks == nk) { iks = 0; ++itile; }
+    };
+    for (int t = 0; t < AHEAD && t < total; ++t) issue_next();
+    for (int sidx = 0; sidx < total; ++sidx) {
+      // two stages ahead: when step sidx is needed, only step sidx + 1 (if it exists) may still be in flight
+      if (total - 1 - sidx >= 1) wait_vmcnt<PPT>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (sidx + AHEAD < total) issue_next();
+    }
+    __builtin_amdgcn_s_barrier();                   // F: the last tile is staged
+  } else if (role == 0) {
+    // ---- MFMA waves -----------------------------------------------------------------------------------
+    prefetch_share(a, blockIdx.x, gridDim.x, tid, 256, smem + SMEM);
+    const int r16 = lane & 15, c4 = lane >> 4;
+    const int sw = (r16 >> 1) & 7;
+    const int foh = r16 * 128 + ((c4 ^ sw) << 4), fol = r16 * 128 + (((c4 + 4) ^ sw) << 4);
+    int sidx = 0;
+    for (int i = 0; i < nloc; ++i) {
+      f32x4 acc[CT][MT];
+#pragma unroll
+      for (int ci = 0; ci < CT; ++ci)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[ci][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < nk; ++ks, ++sidx) {
+        __builtin_amdgcn_s_barrier();
+        if (g.probe & 128) continue;                                // probe: barriers only
+        const char* sa = smem + (sidx % STAGES) * STAGE;
+        const char* sb = sa + (AROWS + w4 * (BN / 4)) * 128;
+        bf16x8 wh[CT], wl[CT];
+#pragma unroll
+        for (int ci = 0; ci < CT; ++ci) { wh[ci] = *(const bf16x8*)(sb + ci * 2048 + foh); wl[ci] = *(const bf16x8*)(sb + ci * 2048 + fol); }
+        bf16x8 xh[2], xl[2];
+        xh[0] = *(const bf16x8*)(sa + foh); xl[0] = *(const bf16x8*)(sa + fol);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          if (j + 1 < MT) { xh[(j + 1) & 1] = *(const bf16x8*)(sa + (j + 1) * 2048 + foh); xl[(j + 1) & 1] = *(const bf16x8*)(sa + (j + 1) * 2048 + fol); }
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(g.probe & 16)) {
+#pragma unroll
+          for (int ci = 0; ci < CT; ++ci) {
+            acc[ci][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ci], xh[j & 1], acc[ci][j], 0, 0, 0);
+            acc[ci][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ci], xl[j & 1], acc[ci][j], 0, 0, 0);
+            acc[ci][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ci], xh[j & 1], acc[ci][j], 0, 0, 0);
+          }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // raw accumulators -> staging (the previous tile's staging was read out before the barrier of this tile's last K-step)
+#pragma unroll
+      for (int ci = 0; ci < CT; ++ci)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) *(f32x4*)(&st[(16 * j + r16) * SLD + w4 * (BN / 4) + 16 * ci + 4 * c4]) = acc[ci][j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                   // F
+  } else {
+    // ---- store waves ----------------------------------------------------------------------------------
+    // Tile T is turned into output while the MFMA waves compute tile T + 1: pass q (16 rows; a thread owns 8 channels of one row per pass)
+    // runs in barrier interval q of that tile (several passes per interval when the K loop has fewer than MT + 1 steps).  Nothing in an
+    // interval waits for global memory: the tile's bias slice and the first pass' residual are requested one tile / one interval ahead.
+    const int ts = tid - 512;                       // 0..255: row ts / 16 (+ 16 per pass), 8-channel chunk ts % 16
+    const int c8 = ts & 15, r0 = ts >> 4;
+    dispatch_act(a.act, [&](auto actc) {
+      constexpr int ACT = decltype(actc)::value;
+      f32x4 bc0 = {0.f, 0.f, 0.f, 0.f}, bc1 = bc0, bn0 = bc0, bn1 = bc0;      // bias of the tile being copied / of the tile being computed
+      float rpre[8];                                 // residual of the next pass to run
+      bool rpre_ok = false;
+      long long rpre_y = 0;
+      // Tile geometry is CARRIED, not divided out per pass (an integer division is ~50 VALU instructions; four per pass cost more than the
+      // pass itself): `cp` describes the tile being copied, `nx` the tile being computed; advancing to the next tile of the block's
+      // contiguous range is an increment of the channel tile, or a step of BM pixels with the (image, pixel) pair wrapped.
+      struct TileGeo { int nt, mt, b, p; };          // p: pixel index (inside image b) of this thread's row r0 of pass 0
+      auto geo_init = [&](int tile) {
+        TileGeo t;
+        t.nt = tile % a.ntn; t.mt = tile / a.ntn;
+        const int m = min(t.mt * BM + r0, a.M - 1);
+        t.b = m / a.OHW; t.p = m - t.b * a.OHW;
+        return t;
+      };
+      auto geo_next = [&](TileGeo& t) {
+        if (++t.nt == a.ntn) {
+          t.nt = 0; ++t.mt; t.p += BM;
+          while (t.p >= a.OHW) { t.p -= a.OHW; ++t.b; }
+        }
+      };
+      TileGeo nx = geo_init(t0), cp = nx;
+      auto geom = [&](const TileGeo& t, int pass, long long& ypix, long long& rpix) -> bool {
+        const int m = t.mt * BM + pass * 16 + r0;
+        const bool ok = m < a.M && t.nt * BN + c8 * 8 < a.N;
+        int b = t.b, p = t.p + pass * 16;
+        while (p >= a.OHW) { p -= a.OHW; ++b; }
+        ypix = (long long)b * a.y_bstride + (long long)p * a.ldy;
+        rpix = (long long)b * a.r_bstride + (long long)p * a.ldr;
+        return ok;
+      };
+      auto res_load = [&](const TileGeo& t, int pass, float (&rv)[8], bool& ok, long long& ypix) {
+        long long rpix;
+        ok = geom(t, pass, ypix, rpix);
+        const int c = t.nt * BN + c8 * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rv[e] = 0.f;
+        if (a.res_mode != RES_NONE && ok) {
+          if (a.res_split) {
+            split_load8((const bf16*)a.res, rpix, c, rv);
+          } else {
+            const f32x4 q0 = *(const f32x4*)((const float*)a.res + rpix + c), q1 = *(const f32x4*)((const float*)a.res + rpix + c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { rv[e] = q0[e]; rv[4 + e] = q1[e]; }
+          }
+        }
+      };
+      auto finish = [&](const TileGeo& t, int pass, const float (&rv)[8], bool ok, long long ypix) {       // staging row + bias (+ residual) -> activation -> store
+        if (!ok || (g.probe & 8)) return;
+        const int c = t.nt * BN + c8 * 8;
+        const float* srow = st + (pass * 16 + r0) * SLD + c8 * 8;
+        const f32x4 s0 = *(const f32x4*)(srow), s1 = *(const f32x4*)(srow + 4);
+        float v[8] = {s0[0] + bc0[0], s0[1] + bc0[1], s0[2] + bc0[2], s0[3] + bc0[3], s1[0] + bc1[0], s1[1] + bc1[1], s1[2] + bc1[2], s1[3] + bc1[3]};
+        if (a.res_mode == RES_PRE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = act_c<ACT>(v[e]);
+        if (a.res_mode == RES_POST) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+        if (a.y_split) {
+          split_store8((bf16*)a.y, ypix, c, v);
+        } else {
+          *(f32x4*)((float*)a.y + ypix + c) = f32x4{v[0], v[1], v[2], v[3]};
+          *(f32x4*)((float*)a.y + ypix + c + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+      };
+      auto bias_load = [&](const TileGeo& t, f32x4& d0, f32x4& d1) {
+        const int c = t.nt * BN + c8 * 8;
+        if (c < a.N) { d0 = *(const f32x4*)(a.bias + c); d1 = *(const f32x4*)(a.bias + c + 4); }
+      };
+      // passes of interval ks: [pb(ks), pb(ks + 1)) with pb(k) = min(MT, k * ppi), ppi = passes per interval
+      const int slots = nk - 1;
+      const int ppi = (MT + slots - 1) / slots;
+      for (int i = 0; i < nloc; ++i) {
+        for (int ks = 0; ks < nk; ++ks) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's staging reads are in registers before anyone may overwrite the tile
+          __builtin_amdgcn_s_barrier();
+          if (g.probe & 64) continue;                               // probe: barriers only
+          if (ks == 0) bias_load(nx, bn0, bn1);                      // tile t0 + i: used one tile later
+          if (i > 0 && ks < slots) {                                 // tile t0 + i - 1 = cp
+            const int p0 = min(MT, ks * ppi), p1 = min(MT, p0 + ppi);
+            for (int ps = p0; ps < p1; ++ps) {
+              float rv[8];
+              bool ok;
+              long long ypix;
+              if (ps == p0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rv[e] = rpre[e];
+                ok = rpre_ok; ypix = rpre_y;
+              } else {
+                res_load(cp, ps, rv, ok, ypix);
+              }
+              if (ps + 1 == p1 && p1 < MT) res_load(cp, p1, rpre, rpre_ok, rpre_y);      // first pass of the next interval
+              finish(cp, ps, rv, ok, ypix);
+            }
+          }
+          if (ks == nk - 1) {                                        // tile t0 + i is staged after this interval: it becomes the tile to copy
+            bc0 = bn0; bc1 = bn1;
+            cp = nx;
+            geo_next(nx);
+            res_load(cp, 0, rpre, rpre_ok, rpre_y);
+          }
+        }
+      }
+      __builtin_amdgcn_s_barrier();                 // F
+      for (int ps = 0; ps < MT; ++ps) {
+        float rv[8];
+        bool ok;
+        long long ypix;
+        if (ps == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rv[e] = rpre[e];
+          ok = rpre_ok; ypix = rpre_y;
+        } else {
+          res_load(cp, ps, rv, ok, ypix);
+        }
+        finish(cp, ps, rv, ok, ypix);
+      }
+    });
   }
 }
 
@@ -2785,6 +3500,25 @@ int conv_kpad_split(int K) { return 2 * ((K + SPLIT_GROUP - 1) / SPLIT_GROUP * S
 static int g_split_ws2_min_blocks = 257;   // A/B hook (rtd_debug_option "split_ws2_min_blocks")
 void conv_set_split_ws2_min_blocks(int v) { g_split_ws2_min_blocks = v; }
 static int g_split_ws64_max_blocks = 160;  // A/B hook (rtd_debug_option "split_ws64_max_blocks")
+// rtd_debug_option "split_kernel": 0 conv_igemm_ws_kernel<SPLIT>, 1 conv_igemm_wsx_kernel on 32x32x16 MFMAs, 2 on 16x16x32 (default: same-box A/B on
+// R50 bs 8, random frames: 1530 / 1550 / 1584 frames/s - the MFMA-bound layers run 5-8 % faster on the 16x16x32 shape, whose loop holds a higher clock)
+static int g_split_kernel = 2;
+void conv_set_split_kernel(int v) { g_split_kernel = v; }
+static int g_split_flex = 0;               // rtd_debug_option "split_flex": 1 = flexible tile heights (conv_igemm_wsf_kernel) on long K loops
+// Measured on R50 bs 8 with random frames inside the network (same box, tools/gpu_chain ab_p*): fixed 128 x 128 / 128 x 64 tiles 5529 us of
+// kernels per step, + flexible tile heights 5578, + persistent kernel 5740.  On zero-filled microbenchmarks the flexible tiles win 10-15 % on
+// the 80^2 maps (quantization) - inside the network, at the clocks random data allows and with cold operands, they do not; the persistent
+// kernel's store waves compete with the MFMA waves for the SIMDs' vector issue slots (a 16x16x32 MFMA blocks 8 of its 16 cycles) and the
+// epilogue's VALU work is as large as a K = 256 tile's MFMA work.  Both stay available (and tested) behind these switches, off by default.
+static int g_split_persist = 0;            // rtd_debug_option "split_persist": 1 = persistent three-role kernel on wide grids (2: also short K loops with a residual)
+static int g_split_persist_min_tiles = 384;   // persistent kernel from this many 112 x 128 tiles on ("split_persist_min_tiles")
+void conv_set_split_persist(int v) { g_split_persist = v; }
+void conv_set_split_persist_min_tiles(int v) { g_split_persist_min_tiles = v; }
+static int g_split_flex_force = 0;
+void conv_set_split_flex_force(int v) { g_split_flex_force = v; }
+static int g_split_flex_min_nk = 16;       // flexible tiles from this many K-steps on (shorter K loops are not MFMA-bound); "split_flex_min_nk"
+void conv_set_split_flex(int v) { g_split_flex = v; }
+void conv_set_split_flex_min_nk(int v) { g_split_flex_min_nk = v; }
 void conv_set_split_ws64_max_blocks(int v) { g_split_ws64_max_blocks = v; }
 bool conv_split_supported(const ConvArgs& a) {
   const Tensor& x = a.x;
@@ -2847,8 +3581,8 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
   const long long x_bytes = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * 4;
   const long long w_bytes = (long long)a.Npad * a.Kpad * 2;
   RTD_CHECK(x_bytes < (1ll << 31) && x2_bytes < (1ll << 31) && w_bytes < (1ll << 31), 1, "conv (bf16x3): operand larger than a buffer descriptor (2 GiB)");
-  g.probe = 0; g.splitk = 1; g.slab = nullptr; g.cnt = nullptr; g.y_bytes = 0;
-  g.x_bytes = (unsigned)x_bytes; g.w_bytes = (unsigned)w_bytes; g.x2_bytes = (unsigned)x2_bytes;
+  g.probe = g_glds_drop & ~32; g.splitk = 1; g.slab = nullptr; g.cnt = nullptr; g.y_bytes = 0;      // timing-only probes (rtd_debug_option "glds_drop")
+  g.x_bytes = (g_glds_drop & 1) ? 0u : (unsigned)x_bytes; g.w_bytes = (g_glds_drop & 2) ? 0u : (unsigned)w_bytes; g.x2_bytes = (unsigned)x2_bytes;
   // narrow 3x3 layers on wide grids (stem.1, stem.2): the direct kernel stages every input pixel once instead of nine times
   if (g_conv_reg && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !dual && a.res_mode == RES_NONE && x.c == 32 && (y.c == 32 || y.c == 64) &&
       y.dt == BF16X2) {
@@ -2864,9 +3598,83 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
     }
   }
   const long long mt = (k.M + 127) / 128, ntn = (k.N + 127) / 128, ntn64 = (k.N + 63) / 64;
+  // ---- persistent three-role kernel (conv_igemm_wsp_kernel): grids with several tiles per CU
+  if (g_split_persist && g_split_kernel == 2 && k.N >= 128 && k.Kpad / 64 >= 2 && (k.Kpad / 64 >= 8 || k.res_mode == RES_NONE || g_split_persist == 2)) {
+    constexpr int PMT = 7;
+    const long long mtl = (k.M + 16 * PMT - 1) / (16 * PMT), ntb = (k.N + 127) / 128;
+    const long long tiles = mtl * ntb;
+    if (tiles >= g_split_persist_min_tiles && tiles < (1ll << 30)) {
+      k.ntn = (int)ntb;
+      const unsigned gx = (unsigned)std::min<long long>(tiles, 256);
+      hipLaunchKernelGGL((conv_igemm_wsp_kernel<PMT>), dim3(gx), dim3(768), 0, s, g, (int)tiles);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+  }
+  // ---- flexible tile height (conv_igemm_wsf_kernel): MFMA-bound layers (>= 16 K-steps) pick the tile whose grid fills whole rounds of the chip
+  if (g_split_flex && g_split_kernel == 2 && k.Kpad / 64 >= g_split_flex_min_nk && k.N >= 64) {
+    int best_mt = 0, best_bn = 0, best_st = 0;
+    double best = 1e30;
+    if (g_split_flex_force) {                      // sweeps (tools/conv_bench.py --opt split_flex_force): mt + 100 * (bn == 64) + 1000 * stages
+      best_mt = g_split_flex_force % 100; best_bn = (g_split_flex_force / 100) % 10 ? 64 : 128; best_st = g_split_flex_force / 1000; best = 0.0;
+    }
+    for (int bn = (k.N > 64 ? 128 : 64); bn >= 64; bn -= 64) {
+      const long long ntb = (k.N + bn - 1) / bn;
+      for (int mtc = 4; mtc <= 13; ++mtc) {
+        const long long blocks = ((k.M + 16 * mtc - 1) / (16 * mtc)) * ntb;
+        const long long rounds = (blocks + 255) / 256;
+        const bool two = blocks > 256 && mtc <= 8;                 // 2 stages, two blocks per CU share the MFMA pipes; else 3 stages, one block per CU
+        double eff = (bn == 128 ? 1.0 : 0.78) * (1.0 - 0.6 / mtc);  // small tiles: more LDS reads and barriers per MFMA
+        if (!two && blocks > 256) eff *= 0.93;                     // nothing hides a lone block's barrier bubbles
+        const double cost = (double)rounds * mtc * bn / eff;
+        if (cost < best) { best = cost; best_mt = mtc; best_bn = bn; best_st = two ? 2 : 3; }
+      }
+    }
+    k.ntn = (int)((k.N + best_bn - 1) / best_bn);
+    const long long blocks = ((k.M + 16 * best_mt - 1) / (16 * best_mt)) * k.ntn;
+    const dim3 grid((unsigned)blocks), blk(512);
+    bool launched = true;
+#define RTD_WSF(ST, BNN, MTT) hipLaunchKernelGGL((conv_igemm_wsf_kernel<ST, BNN, MTT>), grid, blk, 0, s, g)
+#define RTD_WSF_MT(ST, BNN)                                                                                     \
+    switch (best_mt) {                                                                                         \
+      case 4: RTD_WSF(ST, BNN, 4); break; case 5: RTD_WSF(ST, BNN, 5); break; case 6: RTD_WSF(ST, BNN, 6); break;   \
+      case 7: RTD_WSF(ST, BNN, 7); break; case 8: RTD_WSF(ST, BNN, 8); break; default: launched = false; break; }
+    if (best_st == 2) {
+      if (best_bn == 128) { RTD_WSF_MT(2, 128) } else launched = false;
+    } else if (best_bn == 64) {
+      RTD_WSF_MT(3, 64)
+    } else {
+      switch (best_mt) {
+        case 4: RTD_WSF(3, 128, 4); break; case 5: RTD_WSF(3, 128, 5); break; case 6: RTD_WSF(3, 128, 6); break; case 7: RTD_WSF(3, 128, 7); break;
+        case 8: RTD_WSF(3, 128, 8); break; case 9: RTD_WSF(3, 128, 9); break; case 10: RTD_WSF(3, 128, 10); break; case 11: RTD_WSF(3, 128, 11); break;
+        case 12: RTD_WSF(3, 128, 12); break; case 13: RTD_WSF(3, 128, 13); break; default: launched = false; break;
+      }
+    }
+#undef RTD_WSF_MT
+#undef RTD_WSF
+    if (launched) { HIP_CHECK(hipGetLastError()); return; }
+    k.ntn = 1;
+  }
+  if (g_split_kernel != 0) {                      // the dedicated split kernel: 1 = 32x32x16 MFMAs, 2 = 16x16x32
+    const bool n64 = k.N <= 64 || (mt * ntn < g_split_ws64_max_blocks && ntn64 > ntn);
+    k.ntn = (int)(n64 ? ntn64 : ntn);
+    const long long blocks = mt * k.ntn;
+    const bool four = blocks < g_split_ws2_min_blocks;
+    const dim3 grid((unsigned)blocks), blk(512);
+#define RTD_WSX(ST, BNN) do { if (g_split_kernel == 2) hipLaunchKernelGGL((conv_igemm_wsx_kernel<ST, BNN, true>), grid, blk, 0, s, g); \
+                              else hipLaunchKernelGGL((conv_igemm_wsx_kernel<ST, BNN, false>), grid, blk, 0, s, g); } while (0)
+    if (n64) { if (four) RTD_WSX(4, 64); else RTD_WSX(2, 64); }
+    else { if (four) RTD_WSX(4, 128); else RTD_WSX(2, 128); }
+#undef RTD_WSX
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (k.N <= 64 || (mt * ntn < g_split_ws64_max_blocks && ntn64 > ntn)) {
     k.ntn = (int)ntn64;
-    hipLaunchKernelGGL((conv_igemm_ws_kernel<bf16, 4, false, 64, true>), dim3((unsigned)(mt * ntn64)), dim3(512), 0, s, g);
+    // wide grids (stage-0 c1 / c2 at 160^2: 1600 tiles): 2 stages, two blocks per CU - one block's prologue and copy-out run under the other's
+    // K loop (with 4 stages and one block per CU the 64-channel layers took 7 serial rounds of ~11 us: 80 us for 30 us of traffic)
+    if (mt * ntn64 < g_split_ws2_min_blocks) hipLaunchKernelGGL((conv_igemm_ws_kernel<bf16, 4, false, 64, true>), dim3((unsigned)(mt * ntn64)), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((conv_igemm_ws_kernel<bf16, 2, false, 64, true>), dim3((unsigned)(mt * ntn64)), dim3(512), 0, s, g);
   } else {
     k.ntn = (int)ntn;
     if (mt * ntn < g_split_ws2_min_blocks) hipLaunchKernelGGL((conv_igemm_ws_kernel<bf16, 4, false, 128, true>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
@@ -2878,7 +3686,7 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
 void conv_reset_options() {
   g_glds_min_blocks = 4; g_splitk_enable = 0; g_glds_drop = 0; g_conv_mode = 0; g_force_v1 = 0; g_ws256_min_blocks = 0; g_glds_min_n = 128;
   g_wsa_min_ntn = 8; g_ws2_min_blocks = 257; g_reg_epilogue = 1; g_ws64_max_blocks = 160; g_prefetch = 1; g_conv_reg = 1; g_conv_stream = 1;
-  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160;
+  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160; g_split_kernel = 2; g_split_flex = 0; g_split_flex_min_nk = 16; g_split_flex_force = 0; g_split_persist = 0; g_split_persist_min_tiles = 384;
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t s) {

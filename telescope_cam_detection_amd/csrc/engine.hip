@@ -1613,6 +1613,12 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "splitk") == 0) { conv_set_splitk(value); return RTD_OK; }
   if (strcmp(name, "split_ws2_min_blocks") == 0) { conv_set_split_ws2_min_blocks(value); return RTD_OK; }
   if (strcmp(name, "split_ws64_max_blocks") == 0) { conv_set_split_ws64_max_blocks(value); return RTD_OK; }
+  if (strcmp(name, "split_kernel") == 0) { conv_set_split_kernel(value); return RTD_OK; }
+  if (strcmp(name, "split_flex") == 0) { conv_set_split_flex(value); return RTD_OK; }
+  if (strcmp(name, "split_flex_min_nk") == 0) { conv_set_split_flex_min_nk(value); return RTD_OK; }
+  if (strcmp(name, "split_flex_force") == 0) { conv_set_split_flex_force(value); return RTD_OK; }
+  if (strcmp(name, "split_persist") == 0) { conv_set_split_persist(value); return RTD_OK; }
+  if (strcmp(name, "split_persist_min_tiles") == 0) { conv_set_split_persist_min_tiles(value); return RTD_OK; }
   if (strcmp(name, "glds_drop") == 0) { conv_set_glds_drop(value); return RTD_OK; }
   if (strcmp(name, "glds_min_blocks") == 0) { conv_set_glds_min_blocks(value); return RTD_OK; }
   return RTD_E_INVALID;
@@ -1678,10 +1684,10 @@ int rtd_op_conv_dual(int dtype, const void* x, const void* x2, const void* w_f32
 int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int stride, int pad, int with_res, int reps,
                    int flush_mb, float* us_out) {
   return op_guard([&] {
-    const int K = KH * KH * Cin, Kpad = conv_kpad(K), Npad = conv_npad(Cout);
+    const int K = KH * KH * Cin, Kpad = dtype == BF16X2 ? conv_kpad_split(K) : conv_kpad(K), Npad = conv_npad(Cout);
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const size_t es = dtype == BF16 ? 2 : 4;
-    const size_t xb = (size_t)B * H * W * Cin * es, yb = (size_t)B * OH * OW * Cout * es, wb = (size_t)Npad * Kpad * es;
+    const size_t xb = (size_t)B * H * W * Cin * es, yb = (size_t)B * OH * OW * Cout * es, wb = (size_t)Npad * Kpad * (dtype == F32 ? 4 : 2);
     void *x = nullptr, *y = nullptr, *r = nullptr, *w = nullptr, *flush = nullptr; float* bias = nullptr;
     HIP_CHECK(hipMalloc(&x, xb)); HIP_CHECK(hipMalloc(&y, yb)); HIP_CHECK(hipMalloc(&w, wb)); HIP_CHECK(hipMalloc((void**)&bias, Npad * 4));
     HIP_CHECK(hipMemset(x, 0, xb)); HIP_CHECK(hipMemset(w, 0, wb)); HIP_CHECK(hipMemset(bias, 0, Npad * 4));

@@ -291,6 +291,10 @@ SPLIT_CONV_CASES = [
     (2, 20, 20, 512, 512, 3, 1, 1, "relu", 0, 0),       # stage-3 c2: K = 4608 real channels x taps
     (1, 70, 50, 256, 64, 1, 1, 0, "gelu", 0, 0),
     (2, 40, 41, 256, 1024, 1, 1, 0, "relu", 1, 1),      # fp32 output with a BF16X2 residual
+    (8, 40, 40, 256, 256, 3, 1, 1, "silu", 2, 0),       # 40^2 x 8 maps: flexible tile height (112 px -> 230 blocks), post residual
+    (8, 80, 80, 64, 256, 3, 1, 1, "relu", 0, 0),        # 80^2 x 8 maps: 208-pixel tiles, 3 stages, one block per CU
+    (8, 20, 20, 256, 512, 3, 1, 1, "relu", 1, 0),       # 20^2 x 8 maps: 64-pixel tiles
+    (3, 37, 29, 512, 192, 1, 1, 0, "none", 0, 1),       # ragged M and N, fp32 output, K = 512 (16 K-steps: flexible tiles)
 ]
 
 
@@ -326,9 +330,27 @@ def test_conv_split_bf16x3(L, case):
         yd = torch.full((B, OH, OW, Cout), float("nan"), dtype=torch.float32, device="cuda")
     else:
         yd = torch.full((B, OH, OW, 2 * Cout), -1, dtype=torch.int16, device="cuda")
-    for ws2, ws64 in ((257, 160), (1, 0), (1 << 30, 1 << 30)):      # auto | 2-stage 128-wide tiles everywhere | 4-stage, 64-wide tiles everywhere
+    # tile dispatch: auto | 2-stage 128-wide tiles everywhere | 4-stage, 64-wide tiles everywhere; kernel: the default, and the dedicated split
+    # kernel on either MFMA shape (rtd_debug_option "split_kernel" 1 = 32x32x16, 2 = 16x16x32)
+    # kern -1: the default dispatch; -2: flexible-height tiles (conv_igemm_wsf_kernel) on EVERY K length; -3: the persistent three-role kernel
+    # (conv_igemm_wsp_kernel) wherever it is eligible (N >= 128, >= 2 K-steps), whatever the grid size; -4: both at their own thresholds
+    for ws2, ws64, kern in ((257, 160, -1), (257, 160, -3), (257, 160, -2), (257, 160, -4), (1, 0, 2), (1 << 30, 1 << 30, 2), (257, 160, 0), (257, 160, 1), (1, 0, 1), (1 << 30, 1 << 30, 0)):
+        _capi.debug_option("reset", 0)
         _capi.debug_option("split_ws2_min_blocks", ws2)
         _capi.debug_option("split_ws64_max_blocks", ws64)
+        if kern >= 0:
+            _capi.debug_option("split_kernel", kern)
+            _capi.debug_option("split_flex", 0)
+            _capi.debug_option("split_persist", 0)
+        if kern == -2:
+            _capi.debug_option("split_flex", 1)
+            _capi.debug_option("split_flex_min_nk", 1)
+        if kern == -3:
+            _capi.debug_option("split_persist", 2)
+            _capi.debug_option("split_persist_min_tiles", 1)
+        if kern == -4:
+            _capi.debug_option("split_flex", 1)
+            _capi.debug_option("split_persist", 1)
         ck(L, L.rtd_op_conv(_capi.DT_BF16X2, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None,
                             yd.data_ptr(), B, H, W, Cin, Cout, k, k, stride, pad, {"none": 0, "relu": 1, "silu": 2, "gelu": 3}[act],
                             res_mode, out_f32))
@@ -338,9 +360,8 @@ def test_conv_split_bf16x3(L, case):
         err = (got - y).abs().max().item() / y.abs().max().item()
         rel = (torch.linalg.norm(got - y) / torch.linalg.norm(y)).item()
         print(f"split conv {case}: max err / max |y| {err:.2e}, rel l2 {rel:.2e}")
-        assert err < 2e-5 and rel < 1e-5, (case, ws2, ws64, err, rel)
-    _capi.debug_option("split_ws2_min_blocks", 257)
-    _capi.debug_option("split_ws64_max_blocks", 160)
+        assert err < 2e-5 and rel < 1e-5, (case, ws2, ws64, kern, err, rel)
+    _capi.debug_option("reset", 0)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
