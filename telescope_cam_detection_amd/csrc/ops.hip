@@ -572,9 +572,12 @@ template <bool REG>
 __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ keys, int N, int K, int32_t* __restrict__ idx_out,
                                                 float* __restrict__ val_out) {
   constexpr int MAXPT = 32;
+  // one histogram per wave: scores of one image share their high key bits, so a block-wide histogram serialises ~N LDS atomics on a
+  // handful of addresses per pass (24000 keys: ~10 us per pass); per wave the same-address adds of one instruction cost ~64 cycles
+  __shared__ unsigned whist[16][256];
   __shared__ unsigned hist[256];
   __shared__ unsigned long long sel[1024];
-  __shared__ unsigned s_prefix, s_krem, s_cnt_gt, s_cnt_eq;
+  __shared__ unsigned s_prefix, s_krem, s_cnt_gt, s_cnt_eq, s_cnt_T;
   __shared__ unsigned wave_cnt[16];
   const int tid = threadIdx.x;
   const float* kb = keys + (int64_t)blockIdx.x * N;
@@ -594,21 +597,29 @@ __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ keys, i
   // ---- radix select: after the loop s_prefix is the key of the K-th largest element ------------
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
+    unsigned* mine = whist[tid >> 6];
+    for (int b = tid & 63; b < 256; b += 64) mine[b] = 0;
+    __builtin_amdgcn_wave_barrier();
     const unsigned prefix = s_prefix;
     const unsigned mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
     if (REG) {
 #pragma unroll
       for (int j = 0; j < MAXPT; ++j) {
         const int i = tid + j * 1024;
-        if (j < npt && i < N && (kreg[j] & mask) == prefix) atomicAdd(&hist[(kreg[j] >> shift) & 255u], 1u);
+        if (j < npt && i < N && (kreg[j] & mask) == prefix) atomicAdd(&mine[(kreg[j] >> shift) & 255u], 1u);
       }
     } else {
       for (int i = tid; i < N; i += 1024) {
         const unsigned k = f2key(kb[i]);
-        if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        if ((k & mask) == prefix) atomicAdd(&mine[(k >> shift) & 255u], 1u);
       }
+    }
+    __syncthreads();
+    if (tid < 256) {
+      unsigned t = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) t += whist[w][tid];
+      hist[tid] = t;
     }
     __syncthreads();
     if (tid < 64) {
@@ -632,6 +643,7 @@ __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ keys, i
         else { r -= c2; d = 252 - 4 * l; }
         s_krem = r;
         s_prefix = prefix | (d << shift);
+        if (pass == 3) s_cnt_T = hist[d];                          // how many keys equal the K-th largest exactly
       }
     }
     __syncthreads();
@@ -660,6 +672,26 @@ __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ keys, i
   __syncthreads();
   const unsigned n_gt = s_cnt_gt;       // == K - need_eq
   const int lane = tid & 63, wv = tid >> 6;
+  if (s_cnt_T == need_eq) {
+    // the usual case - no tie straddles the cut: every key equal to T is taken, in any order (the sort below orders by (key, index))
+    if (REG) {
+#pragma unroll
+      for (int j = 0; j < MAXPT; ++j) {
+        const int i = tid + j * 1024;
+        if (j < npt && i < N && kreg[j] == T) {
+          const unsigned pos = n_gt + atomicAdd(&s_cnt_eq, 1u);
+          if (pos < 1024) sel[pos] = ((unsigned long long)T << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+        }
+      }
+    } else {
+      for (int i = tid; i < N; i += 1024) {
+        if (f2key(kb[i]) == T) {
+          const unsigned pos = n_gt + atomicAdd(&s_cnt_eq, 1u);
+          if (pos < 1024) sel[pos] = ((unsigned long long)T << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+        }
+      }
+    }
+  } else
   for (int base = 0, j = 0; base < N; base += 1024, ++j) {
     const int i = base + tid;
     bool eq = false;
@@ -691,18 +723,24 @@ __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ keys, i
     if (s_cnt_eq >= need_eq) break;
   }
   __syncthreads();
-  // ---- bitonic sort, descending, 1024 slots (unused slots are 0 and sink to the end) -----------
-  for (int k = 2; k <= 1024; k <<= 1) {
+  // ---- bitonic sort, descending (unused slots are 0 and sink to the end): 512 slots when K fits, else 1024.  Exchanges at distance
+  // j < 64 stay inside one wave's 64 slots (LDS executes a wave's accesses in order): only the j >= 64 steps need the block barrier -
+  // 6 (512 slots) or 10 (1024) instead of 45 / 55
+  const int SN = K <= 512 ? 512 : 1024;
+  for (int k = 2; k <= SN; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64) __syncthreads();                                // the partner slot was last written by another wave
       const int ixj = tid ^ j;
-      if (ixj > tid) {
+      if (tid < SN && ixj > tid) {
         const unsigned long long a = sel[tid], b = sel[ixj];
         const bool desc = (tid & k) == 0;
         if (desc ? (a < b) : (a > b)) { sel[tid] = b; sel[ixj] = a; }
       }
-      __syncthreads();
+      if (j >= 64) __syncthreads();
+      else __builtin_amdgcn_wave_barrier();
     }
   }
+  __syncthreads();
   if (tid < K) {
     const unsigned long long e = sel[tid];
     idx_out[(int64_t)blockIdx.x * K + tid] = (int32_t)(0xffffffffu - (unsigned)(e & 0xffffffffu));
