@@ -43,6 +43,7 @@ struct PlanOpts {
   int stem_fused_split = 1;   // the same for the bf16x3 engine (hi/lo pairs made on the fly from the bytes): on
   int sel_fused = 1;    // LayerNorm + score head + class max of the query selection in one launch
   int dec_fused = 1;    // 0 = one launch per decoder op
+  int side_stream = 1;  // the query-selection chain runs on a second stream beside the value projection (0: one stream)
 };
 PlanOpts g_opts;
 
@@ -68,6 +69,10 @@ struct Op {
   double flops, bytes;
   std::function<void(hipStream_t)> run;
   bool debug_only = false;   // runs (and is captured) only on handles that asked for it (rtd_debug_force_topk)
+  // lane 1 = the engine's side stream: independent work that runs BESIDE the main stream's (the query-selection chain - enc_output,
+  // scoring, top-k, gather: narrow grids, 150 us - next to the value projection of all decoder layers: 210 us).  kind: 0 launch,
+  // 1 fork (side waits for everything enqueued on main so far), 2 join (main waits for the side stream)
+  int lane = 0, kind = 0;
 };
 
 struct Plan {
@@ -100,6 +105,8 @@ struct rtd_engine {
   std::mutex mu;
   std::string err;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;                      // Op::lane 1
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool loaded = false;
   int P = BF16;  // storage / MFMA type of the conv trunk
   std::vector<char> blob;
@@ -454,9 +461,14 @@ struct Builder {
     if (!name.empty()) plan->named[name] = t;
     return t;
   }
+  int lane = 0;              // lane of the ops being pushed
   void push(const std::string& name, const char* kernel, double flops, double bytes, std::function<void(hipStream_t)> f) {
     if (dry) return;
-    plan->ops.push_back(Op{name, kernel, flops, bytes, std::move(f), false});
+    plan->ops.push_back(Op{name, kernel, flops, bytes, std::move(f), false, lane, 0});
+  }
+  void marker(int kind) {
+    if (dry) return;
+    plan->ops.push_back(Op{kind == 1 ? "fork" : "join", "sync", 0.0, 0.0, nullptr, false, 0, kind});
   }
   static double tbytes(const Tensor& t) { return (double)t.pixels() * t.c * dtype_size(t.dt); }
 
@@ -822,8 +834,10 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     v.h = lh[l]; v.w = lw[l];
     B.conv(nm("dec.proj.%d", l), pan[l], v, 1, 1, 0, ACT_NONE);
   }
-  // value_proj of every decoder layer in ONE GEMM (they all read `mem`, HF:v2.py:177)
-  Tensor vall = B.linear("dec.vp_all", mem, NL * dm, SP ? F32 : P, ACT_NONE, nullptr, "value_all");   // the samplers read bf16 or fp32 values
+  // The query-selection chain (enc_output -> scores -> top-k -> gather: narrow grids, latency-bound) and the value projection both start
+  // from `mem` and meet again in the decoder prologue: the chain runs on the side stream beside the projection (e->opts.side_stream).
+  const bool side = e->opts.side_stream != 0;
+  if (side) { B.marker(1); B.lane = 1; }
   // enc_output on masked memory, fp32 from here on (selection + decoder are exact fp32)
   Tensor eo = B.linear("dec.enc_out.fc", mem, dm, F32, ACT_NONE);
   if (!B.dry && e->n_invalid > 0) {
@@ -880,6 +894,10 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   } else {
     B.push("dec.gather_target", "gather", 0.0, 2.0 * n * Q * dm * 4, [om, tk, S, target](hipStream_t s) { launch_gather_rows(om, tk, S, target, s); });
   }
+  B.lane = 0;
+  // value_proj of every decoder layer in ONE GEMM (they all read `mem`, HF:v2.py:177)
+  Tensor vall = B.linear("dec.vp_all", mem, NL * dm, SP ? F32 : P, ACT_NONE, nullptr, "value_all");   // the samplers read bf16 or fp32 values
+  if (side) B.marker(2);
   const int npts = c.dec_heads * c.n_levels * c.n_points;
   float* ref_unact8 = (float*)B.alloc((size_t)n * Q * 8 * 4);
   float* ref8 = (float*)B.alloc((size_t)n * Q * 8 * 4);
@@ -1052,6 +1070,20 @@ Plan* get_plan(rtd_engine* e, int n) {
   return p;
 }
 
+// one op of the plan on its lane's stream; fork / join markers become event edges (inside a capture: graph dependencies)
+void run_op(rtd_engine* e, Op& op) {
+  if (op.debug_only && !e->force_used) return;
+  if (op.kind == 1) {
+    HIP_CHECK(hipEventRecord(e->ev_fork, e->stream));
+    HIP_CHECK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+  } else if (op.kind == 2) {
+    HIP_CHECK(hipEventRecord(e->ev_join, e->side));
+    HIP_CHECK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+  } else {
+    op.run(op.lane == 1 ? e->side : e->stream);
+  }
+}
+
 void run_plan(rtd_engine* e, Plan* p) {
   if (e->cfg.use_graph) {
     if (!p->exec) {
@@ -1060,14 +1092,13 @@ void run_plan(rtd_engine* e, Plan* p) {
       for (auto& op : p->ops) {
         if (op.debug_only && !e->force_used) continue;
         if (trace) { fprintf(stderr, "[rtd] %s (%s)\n", op.name.c_str(), op.kernel); fflush(stderr); }
-        op.run(e->stream);
-        if (trace) HIP_CHECK(hipStreamSynchronize(e->stream));
+        run_op(e, op);
+        if (trace) { HIP_CHECK(hipStreamSynchronize(e->side)); HIP_CHECK(hipStreamSynchronize(e->stream)); }
       }
       HIP_CHECK(hipStreamSynchronize(e->stream));
       HIP_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
       try {
-        for (auto& op : p->ops)
-          if (!op.debug_only || e->force_used) op.run(e->stream);
+        for (auto& op : p->ops) run_op(e, op);
       } catch (...) {
         hipGraph_t g = nullptr;
         (void)hipStreamEndCapture(e->stream, &g);
@@ -1079,8 +1110,7 @@ void run_plan(rtd_engine* e, Plan* p) {
     }
     HIP_CHECK(hipGraphLaunch(p->exec, e->stream));
   } else {
-    for (auto& op : p->ops)
-      if (!op.debug_only || e->force_used) op.run(e->stream);
+    for (auto& op : p->ops) run_op(e, op);
   }
 }
 
@@ -1278,6 +1308,9 @@ int rtd_load_weights(rtd_handle h, const void* blob, size_t nbytes) {
     RTD_CHECK(e->cfg.device >= 0 && e->cfg.device < ndev, RTD_E_INVALID, "device ordinal out of range");
     HIP_CHECK(hipSetDevice(e->cfg.device));
     if (!e->stream) HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    if (!e->side) HIP_CHECK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    if (!e->ev_fork) HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    if (!e->ev_join) HIP_CHECK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     e->blob.assign((const char*)blob, (const char*)blob + nbytes);
     parse_blob(e);
     const rtd_config& c = e->cfg;
@@ -1418,6 +1451,9 @@ void rtd_destroy(rtd_handle h) {
     if (h->resize_tmp) (void)hipFree(h->resize_tmp);
     if (h->u8_stage) (void)hipFree(h->u8_stage);
     if (h->block_host) (void)hipHostFree(h->block_host);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side) (void)hipStreamDestroy(h->side);
     if (h->stream) (void)hipStreamDestroy(h->stream);
   }
   delete h;
@@ -1494,7 +1530,7 @@ int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int3
     Plan* p = get_plan(h, n);
     std::vector<Op*> ops;                                     // what a forward of this handle launches
     for (auto& op : p->ops)
-      if (!op.debug_only || h->force_used) ops.push_back(&op);
+      if (op.kind == 0 && (!op.debug_only || h->force_used)) ops.push_back(&op);     // every launch, in plan order, on the main stream (no overlap while timing)
     const int nops = (int)ops.size();
     *count = nops;
     if (!out) return;
@@ -1583,6 +1619,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "conv_v1") == 0) { conv_set_force_v1(value); return RTD_OK; }
   if (strcmp(name, "dec_stamps") == 0) { g_opts.dec_stamps = value; return RTD_OK; }
   if (strcmp(name, "dec_fused") == 0) { g_opts.dec_fused = value; return RTD_OK; }
+  if (strcmp(name, "side_stream") == 0) { g_opts.side_stream = value; return RTD_OK; }
   if (strcmp(name, "sel_fused") == 0) { g_opts.sel_fused = value; return RTD_OK; }
   if (strcmp(name, "stem_fused") == 0) { g_opts.stem_fused = value; return RTD_OK; }
   if (strcmp(name, "stem_fused_split") == 0) { g_opts.stem_fused_split = value; return RTD_OK; }

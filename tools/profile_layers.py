@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--arch", default="r50")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--precision", default="bf16x3")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--ab", default="", help="debug option to A/B")
     ap.add_argument("--vals", default="1,0", help="two values of the option: baseline,candidate")
@@ -43,7 +43,7 @@ def main():
     from telescope_cam_detection_amd.weights import fold_weights, pack_blob, synth_weights
     arch = ARCHS[args.arch]
     blob = pack_blob(fold_weights(arch, synth_weights(arch, 0)))
-    prec = _capi.PREC_FP32 if args.precision == "fp32" else _capi.PREC_BF16
+    prec = _capi.precision_code(args.precision)
     for o in args.opt:
         k, v = o.split("=")
         _capi.debug_option(k, int(v))

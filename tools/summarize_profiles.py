@@ -8,14 +8,34 @@ committed under profiles/.
 """
 import collections
 import csv
+import hashlib
 import json
+import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha() -> str:
+    """hash of the kernel sources the profile was measured on (bench.py attaches a profile's figures only when it matches)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "telescope_cam_detection_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+CONFIG = os.environ.get("RTD_PROFILE_CONFIG", "r50_bs8_bf16x3")   # <arch>_bs<B>_<precision> of the profiled bench.py command
 
 
 def family(name: str) -> str:
     if "conv3x3_reg" in name:
         return "conv3x3_direct"
+    if "stem0_u8" in name:
+        return "conv_stem0_u8"
     if "conv_igemm_ws" in name or "conv_igemm_glds" in name:
         return "conv_igemm_lds_dma"
     if "conv_igemm" in name:
@@ -28,7 +48,9 @@ def family(name: str) -> str:
 
 
 def steady_steps(rows):
-    idx = [i for i, r in enumerate(rows) if "k_preprocess_identity" in r["Kernel_Name"]]
+    # a step starts with the per-call preprocess launch (outside the hipGraph): the frame-table setter of the fused uint8 stem, else the
+    # stand-alone preprocess
+    idx = [i for i, r in enumerate(rows) if "k_set_frame_table" in r["Kernel_Name"] or "k_preprocess_identity" in r["Kernel_Name"]]
     steps = [rows[idx[i]:idx[i + 1]] for i in range(len(idx) - 1)]
     modal = collections.Counter(len(s) for s in steps).most_common(1)[0][0]
     good = [s for s in steps if len(s) == modal]
@@ -41,7 +63,7 @@ def do_trace(path, out):
     fam = collections.defaultdict(lambda: [0, 0])
     span = []
     for st in steps:
-        span.append((int(st[-1]["End_Timestamp"]) - int(st[0]["Start_Timestamp"])) / 1e6)
+        span.append((max(int(r["End_Timestamp"]) for r in st) - int(st[0]["Start_Timestamp"])) / 1e6)
         for r in st:
             f = fam[family(r["Kernel_Name"])]
             f[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
@@ -50,7 +72,8 @@ def do_trace(path, out):
     ks = [dict(kernel=k, us_per_step=round(d / len(steps) / 1e3, 2), launches_per_step=c / len(steps), avg_us=round(d / c / 1e3, 3),
                pct=round(100 * d / tot, 2)) for k, (d, c) in sorted(fam.items(), key=lambda kv: -kv[1][0])]
     conv = [k for k in ks if k["kernel"].startswith("conv")]
-    res = dict(command="rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --streams 1 --no-cpu-baseline --no-latency",
+    res = dict(csrc_sha=csrc_sha(), config=CONFIG,
+               command="rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --streams 1 --multi-streams 0 --no-bf16-line --no-cpu-baseline --no-latency",
                steady_graph_steps_used=len(steps), kernels_per_step=modal, step_span_ms_median=sorted(span)[len(span) // 2],
                conv_igemm_all=dict(us_per_step=round(sum(k["us_per_step"] for k in conv), 2), launches_per_step=sum(k["launches_per_step"] for k in conv),
                                    avg_us=round(sum(k["us_per_step"] for k in conv) / sum(k["launches_per_step"] for k in conv), 3)),
@@ -72,7 +95,8 @@ def do_pmc(fetch, write, out):
             f[1] += 1
         return fam
     f, w = load(fetch), load(write)
-    res = {"note": "one steady graph step; FETCH_SIZE / WRITE_SIZE in KiB from separate rocprofv3 --pmc passes; FETCH_SIZE doubled "
+    res = {"csrc_sha": csrc_sha(), "config": CONFIG,
+           "note": "one steady graph step; FETCH_SIZE / WRITE_SIZE in KiB from separate rocprofv3 --pmc passes; FETCH_SIZE doubled "
                    "(gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md HBM section)"}
     for k in f:
         fk, c = f[k]
@@ -105,7 +129,8 @@ def do_mfma(path, out):
         f[1] += float(ra["Counter_Value"]) / 8.0
         f[2] += 1
         f[3] += (int(rb["End_Timestamp"]) - int(rb["Start_Timestamp"])) / 1e3
-    res = {"note": "one steady graph step of `bench.py --streams 1` under rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; "
+    res = {"csrc_sha": csrc_sha(), "config": CONFIG,
+           "note": "one steady graph step of `bench.py --streams 1` under rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; "
                    "util = busy / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs); clock = GRBM_GUI_ACTIVE / 8 / duration (reads high on short dispatches)"}
     tb = ta = 0.0
     for k, (b, a, c, us) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
