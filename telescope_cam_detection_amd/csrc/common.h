@@ -119,6 +119,7 @@ void conv_set_split_kernel(int v);
 void conv_set_split_flex(int v);
 void conv_set_split_flex_min_nk(int v);
 void conv_set_split_flex_force(int v);
+void conv_set_split_flex_small_max(int v);
 void conv_set_split_persist(int v);
 void conv_set_split_persist_min_tiles(int v);
 int conv_npad(int N);

@@ -3504,7 +3504,9 @@ static int g_split_ws64_max_blocks = 160;  // A/B hook (rtd_debug_option "split_
 // R50 bs 8, random frames: 1530 / 1550 / 1584 frames/s - the MFMA-bound layers run 5-8 % faster on the 16x16x32 shape, whose loop holds a higher clock)
 static int g_split_kernel = 2;
 void conv_set_split_kernel(int v) { g_split_kernel = v; }
-static int g_split_flex = 0;               // rtd_debug_option "split_flex": 1 = flexible tile heights (conv_igemm_wsf_kernel) on long K loops
+// rtd_debug_option "split_flex": flexible tile heights (conv_igemm_wsf_kernel) on long K loops - 0 never, 1 every grid, 2 (default) only grids
+// of <= split_flex_small_max 128 x 128 tiles (20^2 maps at batch 8, most layers at batch 1: R50 bs-1 latency 2.49 -> 2.36 ms, bs 8 unchanged)
+static int g_split_flex = 2;
 // Measured on R50 bs 8 with random frames inside the network (same box, tools/gpu_chain ab_p*): fixed 128 x 128 / 128 x 64 tiles 5529 us of
 // kernels per step, + flexible tile heights 5578, + persistent kernel 5740.  On zero-filled microbenchmarks the flexible tiles win 10-15 % on
 // the 80^2 maps (quantization) - inside the network, at the clocks random data allows and with cold operands, they do not; the persistent
@@ -3514,6 +3516,8 @@ static int g_split_persist = 0;            // rtd_debug_option "split_persist": 
 static int g_split_persist_min_tiles = 384;   // persistent kernel from this many 112 x 128 tiles on ("split_persist_min_tiles")
 void conv_set_split_persist(int v) { g_split_persist = v; }
 void conv_set_split_persist_min_tiles(int v) { g_split_persist_min_tiles = v; }
+static int g_split_flex_small_max = 128;   // "split_flex_small_max"
+void conv_set_split_flex_small_max(int v) { g_split_flex_small_max = v; }
 static int g_split_flex_force = 0;
 void conv_set_split_flex_force(int v) { g_split_flex_force = v; }
 static int g_split_flex_min_nk = 16;       // flexible tiles from this many K-steps on (shorter K loops are not MFMA-bound); "split_flex_min_nk"
@@ -3612,7 +3616,9 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
     }
   }
   // ---- flexible tile height (conv_igemm_wsf_kernel): MFMA-bound layers (>= 16 K-steps) pick the tile whose grid fills whole rounds of the chip
-  if (g_split_flex && g_split_kernel == 2 && k.Kpad / 64 >= g_split_flex_min_nk && k.N >= 64) {
+  // split_flex 2: only grids that leave CUs idle with 128-pixel tiles (20^2 maps at batch 8, most layers at batch 1)
+  if (g_split_flex && g_split_kernel == 2 && k.Kpad / 64 >= g_split_flex_min_nk && k.N >= 64 &&
+      (g_split_flex != 2 || ((k.M + 127) / 128) * ((k.N + 127) / 128) <= g_split_flex_small_max)) {
     int best_mt = 0, best_bn = 0, best_st = 0;
     double best = 1e30;
     if (g_split_flex_force) {                      // sweeps (tools/conv_bench.py --opt split_flex_force): mt + 100 * (bn == 64) + 1000 * stages
@@ -3686,7 +3692,7 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
 void conv_reset_options() {
   g_glds_min_blocks = 4; g_splitk_enable = 0; g_glds_drop = 0; g_conv_mode = 0; g_force_v1 = 0; g_ws256_min_blocks = 0; g_glds_min_n = 128;
   g_wsa_min_ntn = 8; g_ws2_min_blocks = 257; g_reg_epilogue = 1; g_ws64_max_blocks = 160; g_prefetch = 1; g_conv_reg = 1; g_conv_stream = 1;
-  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160; g_split_kernel = 2; g_split_flex = 0; g_split_flex_min_nk = 16; g_split_flex_force = 0; g_split_persist = 0; g_split_persist_min_tiles = 384;
+  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160; g_split_kernel = 2; g_split_flex = 2; g_split_flex_min_nk = 16; g_split_flex_force = 0; g_split_persist = 0; g_split_persist_min_tiles = 384; g_split_flex_small_max = 128;
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t s) {

@@ -1654,6 +1654,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "split_flex") == 0) { conv_set_split_flex(value); return RTD_OK; }
   if (strcmp(name, "split_flex_min_nk") == 0) { conv_set_split_flex_min_nk(value); return RTD_OK; }
   if (strcmp(name, "split_flex_force") == 0) { conv_set_split_flex_force(value); return RTD_OK; }
+  if (strcmp(name, "split_flex_small_max") == 0) { conv_set_split_flex_small_max(value); return RTD_OK; }
   if (strcmp(name, "split_persist") == 0) { conv_set_split_persist(value); return RTD_OK; }
   if (strcmp(name, "split_persist_min_tiles") == 0) { conv_set_split_persist_min_tiles(value); return RTD_OK; }
   if (strcmp(name, "glds_drop") == 0) { conv_set_glds_drop(value); return RTD_OK; }

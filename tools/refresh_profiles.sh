@@ -9,11 +9,13 @@ O=gpurun_out/$R
 mkdir -p $O
 # 1. the bench line (default: bf16x3 engine, one batch in flight = `value`; + multi_stream, bf16_engine, cpu_baseline side lines)
 timeout -k 10 600 python bench.py > $O/bench_r50.json 2> $O/bench_r50.err
-# 2. kernel trace + stats of ONE handle (what roofline.avg_launch_us must agree with), then the two PMC passes
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o runc -- python3 bench.py --steps 20 --warmup 3 --streams 1 --multi-streams 0 --no-bf16-line --no-cpu-baseline --no-latency > $O/trace.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o runc -- python3 bench.py --steps 3 --warmup 1 --streams 1 --multi-streams 0 --no-bf16-line --no-cpu-baseline --no-latency > $O/pmc_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o runc -- python3 bench.py --steps 3 --warmup 1 --streams 1 --multi-streams 0 --no-bf16-line --no-cpu-baseline --no-latency > $O/pmc_write.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o runc -- python3 bench.py --steps 3 --warmup 1 --streams 1 --multi-streams 0 --no-bf16-line --no-cpu-baseline --no-latency > $O/pmc_mfma.log 2>&1
+# 2. kernel trace + stats of ONE handle (what roofline.avg_launch_us must agree with), then the PMC passes.  side_stream=0: every kernel of the
+#    step on one stream, so that durations and counters belong to one kernel at a time (the product overlaps the query-selection chain with the
+#    value projection on a second stream: -40 us per step, but overlapped kernels' durations would be counted twice)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o runc -- python3 bench.py --steps 20 --warmup 3 --streams 1 --multi-streams 0 --no-bf16-line --no-cpu-baseline --no-latency --opt side_stream=0 > $O/trace.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o runc -- python3 bench.py --steps 3 --warmup 1 --streams 1 --multi-streams 0 --no-bf16-line --no-cpu-baseline --no-latency --opt side_stream=0 > $O/pmc_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o runc -- python3 bench.py --steps 3 --warmup 1 --streams 1 --multi-streams 0 --no-bf16-line --no-cpu-baseline --no-latency --opt side_stream=0 > $O/pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o runc -- python3 bench.py --steps 3 --warmup 1 --streams 1 --multi-streams 0 --no-bf16-line --no-cpu-baseline --no-latency --opt side_stream=0 > $O/pmc_mfma.log 2>&1
 # 3. the other configurations: R18 (the reference's default model), the exact fp32 engine, BASELINE config 3 (R101 1280^2 bs 4)
 timeout -k 10 300 python bench.py --arch r18 --no-cpu-baseline > $O/bench_r18.json 2>/dev/null
 timeout -k 10 300 python bench.py --precision bf16 --no-cpu-baseline > $O/bench_bf16.json 2>/dev/null
