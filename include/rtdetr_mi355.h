@@ -172,6 +172,12 @@ int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* b
 int rtd_op_conv_dual(int dtype, const void* x, const void* x2, const void* w_f32, const float* bias, const void* res,
                      void* y, int B, int H, int W, int Cin, int C2, int Cout, int KH, int stride, int pad,
                      int act, int res_mode, int out_f32, int x_up2);
+/* 1x1 conv (optionally with a second input, as rtd_op_conv_dual) with the FOLLOWING 1x1 conv Cout -> Cnext fused into the launch
+ * (how the plan runs a bottleneck's reduce conv inside the previous block's expand conv): y = act(W [x | x2] + b (+ res)),
+ * y1 = next_act(W1 y + b1), both written.  dtype 1 (bf16) / 4 (bf16x2); RTD_E_INVALID for shapes the streaming kernels do not take. */
+int rtd_op_conv_next(int dtype, const void* x, const void* x2, const void* w_f32, const float* bias, const void* res, void* y,
+                     const void* w1_f32, const float* bias1, void* y1, int B, int H, int W, int Cin, int C2, int Cout, int Cnext,
+                     int act, int res_mode, int next_act);
 int rtd_op_layernorm(int dtype, const void* x, const void* res, const float* g, const float* b,
                      void* y, int rows, int dim, int out_f32);
 int rtd_op_attention(int dtype, const void* qk, const void* v, void* o, int B, int L, int heads, int hd);

@@ -94,7 +94,7 @@ _lib: Optional[C.CDLL] = None
 EXPORTS = [
     "rtd_version", "rtd_create", "rtd_load_weights", "rtd_infer", "rtd_infer_raw", "rtd_infer_async",
     "rtd_result_block", "rtd_sync", "rtd_stream", "rtd_destroy", "rtd_last_error", "rtd_debug_tensor",
-    "rtd_debug_force_topk", "rtd_profile", "rtd_arena_bytes", "rtd_debug_option", "rtd_op_conv", "rtd_op_conv_dual", "rtd_op_layernorm",
+    "rtd_debug_force_topk", "rtd_profile", "rtd_arena_bytes", "rtd_debug_option", "rtd_op_conv", "rtd_op_conv_dual", "rtd_op_conv_next", "rtd_op_layernorm",
     "rtd_op_attention", "rtd_op_msdeform", "rtd_op_topk", "rtd_op_resize", "rtd_crop_resize_batch", "rtd_bench_conv", "rtd_bench_conv_pair",
 ]
 
@@ -142,6 +142,7 @@ def lib() -> C.CDLL:
     L.rtd_debug_option.argtypes = [C.c_char_p, i32]
     L.rtd_op_conv.argtypes = [i32, vp, vp, vp, vp, vp] + [i32] * 12
     L.rtd_op_conv_dual.argtypes = [i32, vp, vp, vp, vp, vp, vp] + [i32] * 13
+    L.rtd_op_conv_next.argtypes = [i32] + [vp] * 9 + [i32] * 10
     L.rtd_op_layernorm.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32]
     L.rtd_op_attention.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32]
     L.rtd_op_msdeform.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(i32), i32, f32]

@@ -121,6 +121,7 @@ void conv_set_split_flex_min_nk(int v);
 void conv_set_split_flex_force(int v);
 void conv_set_split_flex_small_max(int v);
 void conv_set_split_persist(int v);
+void conv_set_split_sx(int v);
 void conv_set_split_persist_min_tiles(int v);
 int conv_npad(int N);
 void conv_set_force_v1(int v);      // A/B hook: 1 = never take the large-tile (v2) path
@@ -241,6 +242,7 @@ struct DecArgs {
   float* logits;            // mode 2: [B*Q, C]
   void* out_bf16;           // mode 4: write the output tokens as bf16 here instead of fp32 hs_out (nullptr = fp32)
   float* stamps;            // diagnostic: [blocks][16] phase end times (10 ns units) or nullptr
+  int probe;                // timing probes (wrong results): bit 0 = every filter fragment read comes from one 64 KiB window (L2-hot filter)
   // weights
   DecLin o, offaw, op, fc1, fc2, bb0, bb1, bb2, qp0, qp1, qk, v, cls;
   DecLN ln1, ln2, ln3;

@@ -3481,10 +3481,13 @@ bool conv_dual_supported(const ConvArgs& a) {
 // The fused following conv exists in the streaming kernel for N = 256 (K = 64, or 64 + 64 with a second input) -> 64 channels and
 // N = 512 (K = 128) -> 128 channels.  Asked per plan (batch size): the fused and the separate form use the same filter tensors and
 // give bit-identical outputs, so plans of different batch sizes may differ.
+static bool sx_shape_ok(const ConvArgs& a);
 bool conv_next_supported(const ConvArgs& a) {
   const Tensor& x = a.x;
   const Tensor& y = a.y;
   const bool dual = a.x2.p != nullptr;
+  if (x.dt == BF16X2)
+    return sx_shape_ok(a) && y.c == 256 && (a.next_y.c == 64 || a.next_y.c == 128) && a.next_y.dt == BF16X2 && a.next_y.ld % SPLIT_GROUP == 0 && y.ld % SPLIT_GROUP == 0;
   if (!g_conv_stream || !g_stream_slab || x.dt != BF16 || y.dt != BF16 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.x_up2) return false;
   if (a.res_mode != RES_NONE && (a.res.dt != BF16 || a.res.ld % 8)) return false;
   if (dual && !(x.c == 64 && a.x2.c == 64 && y.c == 256)) return false;
@@ -3524,6 +3527,268 @@ static int g_split_flex_min_nk = 16;       // flexible tiles from this many K-st
 void conv_set_split_flex(int v) { g_split_flex = v; }
 void conv_set_split_flex_min_nk(int v) { g_split_flex_min_nk = v; }
 void conv_set_split_ws64_max_blocks(int v) { g_split_ws64_max_blocks = v; }
+
+// ------------------------------------------------------------------------------------------------
+// Streaming 1x1 convolution on BF16X2 operands for the thin, very wide-grid expand convs of the first backbone stages
+// (stage-0 c3: 64 [+ 64 shortcut] -> 256 channels at 160^2, stage-1 c3: 128 -> 512 at 80^2): 0.3-0.5 GB per launch and 7-13 GFLOP, i.e.
+// HBM-bound, and the tiled kernels pay a prologue, an LDS staging round trip and a barrier-separated epilogue per 128-pixel
+// block for ONE or two K-steps.  Same scheme as conv1x1_stream_kernel (no LDS tile, no role split), on hi/lo pairs:
+//   * a WAVE owns one 32-channel group of the output ( = one [32 hi | 32 lo] 128-byte run per pixel) and keeps that group's
+//     filter, hi and lo, in registers (4 x K/16 fragments); the block's 8 waves cover 256 channels of a 32-pixel tile, wider
+//     layers put 256-channel blocks in gridDim.y; persistent grid, tiles block-cyclic;
+//   * pixel fragments come straight from global memory in MFMA B-operand shape (lane = pixel, 16 bytes of K; the 8 waves' copies
+//     hit in L1); three v_mfma_f32_32x32x16_bf16 per 16-deep chunk (w_hi x_lo, w_lo x_hi, w_hi x_hi);
+//   * filter rows are permuted at load time (MFMA row 8b+4h+r <- channel 16h+4b+r): a lane's 16 accumulators are 16 CONSECUTIVE
+//     channels of its pixel; residual and output cross a wave-private slab (32 rows x 128 bytes + skew) so that their global
+//     accesses are row-shaped (8 lanes x 16 bytes = one pixel's 128-byte run);
+//   * NEXTN (N == 256): the following 256 -> NEXTN reduce conv (the next block's c1) runs on the tile while the eight slabs
+//     hold y as hi/lo bf16 = exactly what that conv would read back from HBM: wave w takes 16 output channels (NEXTN = 64: of one
+//     16-pixel half) with 8 x 3 v_mfma_f32_16x16x32_bf16, its 16 x 256 filter slice (hi and lo) in registers, between two block
+//     barriers.  The c1 launch and its read of the 4-bytes-per-channel y tensor (R50 bs 8 stage 0: 210 MB) disappear.
+// Arithmetic per output: K chunks in order into a zero accumulator (lo-terms first inside a chunk), + bias, + residual (hi + lo),
+// activation, one hi/lo rounding.  Kernel choice depends on the per-IMAGE extents only, so every batch size runs the same arithmetic.
+// ------------------------------------------------------------------------------------------------
+template <int NGX, int NG2, bool RES, int NEXTN>   // NGX / NG2: 32-channel K groups read from x / from ConvK::x2
+__global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsigned x_bytes, unsigned r_bytes, unsigned y_bytes, unsigned x2_bytes, int ntiles,
+                                                            unsigned yn_bytes) {
+  constexpr int NKX = 2 * NGX, NK2 = 2 * NG2, NKK = NKX + NK2;   // 16-deep MFMA chunks
+  constexpr int NG_ = NGX + NG2;
+  constexpr int SROW = 144;
+  __shared__ __attribute__((aligned(16))) char slabs[8][32 * SROW];
+  __shared__ __attribute__((aligned(16))) char xs[2][32 * (NG_ * 128 + 16)];
+  constexpr int YROW = NEXTN * 4 + 16;
+  __shared__ __attribute__((aligned(16))) char y1s[NEXTN ? 32 * YROW : 16];   // the follower's output tile: accumulator-shaped writes, row-shaped stores
+  __shared__ __attribute__((aligned(16))) float sbias[256];
+  __shared__ __attribute__((aligned(16))) char pf_dummy[256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, pl = lane & 31;
+  const int cb = (blockIdx.y * 8 + wv) * 32;                     // this wave's output channel group
+  if (tid < 256) sbias[tid] = a.bias[blockIdx.y * 256 + tid];
+
+  bf16x8 wfh[NKK], wfl[NKK];
+  {
+    const int ch = cb + 16 * ((pl >> 2) & 1) + 4 * (pl >> 3) + (pl & 3);
+    const bf16* wr = (const bf16*)a.w + (size_t)ch * a.Kpad + 8 * h;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      wfh[kk] = *(const bf16x8*)(wr + (kk >> 1) * 64 + 16 * (kk & 1));
+      wfl[kk] = *(const bf16x8*)(wr + (kk >> 1) * 64 + 16 * (kk & 1) + 32);
+    }
+  }
+  // NEXTN: this wave's 16 x 256 slice of the following filter as 16x16x32 A operands (row lane & 15, k 32 s + 8 (lane >> 4) ..)
+  constexpr int NS = NEXTN ? 8 : 1;
+  bf16x8 w1h[NS], w1l[NS];
+  f32x4 b1v = {0.f, 0.f, 0.f, 0.f};
+  const int slice = NEXTN == 64 ? (wv & 3) : wv;
+  if (NEXTN) {
+    const bf16* w1 = (const bf16*)a.next_w + (size_t)(16 * slice + (lane & 15)) * a.next_kpad + 8 * (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { w1h[s] = *(const bf16x8*)(w1 + 64 * s); w1l[s] = *(const bf16x8*)(w1 + 64 * s + 32); }
+    b1v = *(const f32x4*)(a.next_bias + 16 * slice + 4 * (lane >> 4));
+  }
+  __syncthreads();
+  prefetch_share(a, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, tid, 512, pf_dummy);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(NG2 ? a.x2 : a.x), 0, NG2 ? x2_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res : a.x), 0, RES ? r_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ryn = __builtin_amdgcn_make_buffer_rsrc((void*)(NEXTN ? a.next_y : a.y), 0, NEXTN ? yn_bytes : 0u, 0x00020000);
+  const float* bl = sbias + wv * 32 + 16 * h;
+  char* sl = slabs[wv];
+  char* sl_acc = sl + pl * SROW + 32 * h;                         // this lane's 16 channels in accumulator shape: hi here, lo at + 64
+  char* sl_row = sl + (lane >> 3) * SROW + (lane & 7) * 16;       // ... in row shape (pixel lane / 8 + 8 j, 16-byte chunk lane % 8)
+
+  // The pixel tile (32 rows x NG x 128 bytes) is staged ONCE per block through LDS, double buffered: thread -> (pixel tid / CPR, 16-byte chunk
+  // tid % CPR) so that a pixel's run is read by consecutive lanes (fragment-shaped global reads - 64 lanes on 64 different lines, issued by
+  // all 8 waves - cost 4x the address cycles: 76 us instead of 51 for the stage-1 layers).  The loads of tile i + 1 (and its residual rows)
+  // are in flight while tile i is computed; one block barrier per tile.
+  constexpr int XROW = NG_ * 128 + 16;                            // + 16: consecutive rows shift by 4 banks (conflict-free ds_read_b128)
+  constexpr int CPRX = NGX * 8, CPR2 = NG2 ? NG2 * 8 : 1;         // 16-byte chunks per pixel and source
+  constexpr int LX = (32 * CPRX + 511) / 512, L2 = NG2 ? (32 * CPR2 + 511) / 512 : 0;
+  static_assert(LX <= 2 && L2 <= 1, "staging registers");       // (fixed extents below: hipcc drops the host stub of a kernel template whose lambdas see dependent-extent arrays)
+  auto issue = [&](int t, u32x4_ (&gx)[2], u32x4_ (&g2)[1], u32x4_ (&rv)[4], unsigned (&yrow)[4]) {
+    // one division per tile: the tile's first pixel (uniform); a tile crosses at most one image boundary (OHW >= 32)
+    const int m0 = t * 32;
+    const int b0 = m0 / a.OHW, p0 = m0 - b0 * a.OHW;
+#pragma unroll
+    for (int i = 0; i < LX; ++i) {
+      const int e = tid + 512 * i, px = e / CPRX, ck = e - px * CPRX;
+      int b = b0, p = p0 + px;
+      if (p >= a.OHW) { p -= a.OHW; ++b; }
+      const bool ok = m0 + px < a.M && px < 32;
+      gx[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(((long long)b * a.x_bstride + (long long)p * a.ldx) * 2 + ck * 16) : 0x80000000u, 0, 0);
+    }
+    if (NG2) {
+      const int px = tid / CPR2, ck = tid - px * CPR2;
+      int b = b0, p = p0 + px;
+      if (p >= a.OHW) { p -= a.OHW; ++b; }
+      const bool ok = m0 + px < a.M && px < 32;
+      g2[0] = __builtin_amdgcn_raw_buffer_load_b128(rx2, ok ? (unsigned)(((long long)b * a.x2_bstride + (long long)p * a.ldx2) * 2 + ck * 16) : 0x80000000u, 0, 0);
+    }
+    // row-shaped offsets of this lane's 4 output chunks (rows 8 apart); residual chunks requested now
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int px = (lane >> 3) + 8 * j;
+      int b = b0, p = p0 + px;
+      if (p >= a.OHW) { p -= a.OHW; ++b; }
+      const bool ok2 = m0 + px < a.M;
+      yrow[j] = ok2 ? (unsigned)(((long long)b * a.y_bstride + (long long)p * a.ldy + cb) * 4 + (lane & 7) * 16) : 0x80000000u;   // channels: 4 bytes each in a BF16X2 row
+      if (RES) rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rr, ok2 ? (unsigned)(((long long)b * a.r_bstride + (long long)p * a.ldr + cb) * 4 + (lane & 7) * 16) : 0x80000000u, 0, 0);
+    }
+  };
+
+  dispatch_act(a.act, [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+    u32x4_ gx[2], g2[1], rvn[4];
+    unsigned yrown[4];
+    int t = blockIdx.x;
+    if (t < ntiles) issue(t, gx, g2, rvn, yrown);
+    for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
+      char* xb = xs[it & 1];
+#pragma unroll
+      for (int i = 0; i < LX; ++i) {
+        const int e = tid + 512 * i, px = e / CPRX, ck = e - px * CPRX;
+        if (px < 32) *(u32x4_*)(xb + px * XROW + ck * 16) = gx[i];
+      }
+      if (NG2) {
+        const int px = tid / CPR2, ck = tid - px * CPR2;
+        if (px < 32) *(u32x4_*)(xb + px * XROW + NGX * 128 + ck * 16) = g2[0];
+      }
+      u32x4_ rv[4];
+      unsigned yrow[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { rv[j] = rvn[j]; yrow[j] = yrown[j]; }
+      __syncthreads();                                           // the tile is in xs[it & 1]; every wave has left tile it - 1 (whose buffer the NEXT write takes)
+      if (t + (int)gridDim.x < ntiles) issue(t + gridDim.x, gx, g2, rvn, yrown);
+      const char* xf = xb + pl * XROW + 16 * h;
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const bf16x8 fh = *(const bf16x8*)(xf + (kk >> 1) * 128 + 32 * (kk & 1)), fl = *(const bf16x8*)(xf + (kk >> 1) * 128 + 32 * (kk & 1) + 64);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfh[kk], fl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfl[kk], fh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfh[kk], fh, acc, 0, 0, 0);
+      }
+      float r[16];
+      if (RES) {                                                 // residual: row shape -> slab -> accumulator shape
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(u32x4_*)(sl_row + j * 8 * SROW) = rv[j];
+        __builtin_amdgcn_wave_barrier();
+        const bf16x8 h0 = *(const bf16x8*)sl_acc, h1 = *(const bf16x8*)(sl_acc + 16), l0 = *(const bf16x8*)(sl_acc + 64), l1 = *(const bf16x8*)(sl_acc + 80);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { r[e] = (float)h0[e] + (float)l0[e]; r[8 + e] = (float)h1[e] + (float)l1[e]; }
+      }
+      bf16x8 oh[2], ol[2];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = acc[e] + bl[e];
+        if (RES && a.res_mode == RES_PRE) v += r[e];
+        v = act_c<ACT>(v);
+        if (RES && a.res_mode == RES_POST) v += r[e];
+        bf16 hi, lo;
+        split2(v, hi, lo);
+        oh[e >> 3][e & 7] = hi; ol[e >> 3][e & 7] = lo;
+      }
+      *(bf16x8*)sl_acc = oh[0]; *(bf16x8*)(sl_acc + 16) = oh[1]; *(bf16x8*)(sl_acc + 64) = ol[0]; *(bf16x8*)(sl_acc + 80) = ol[1];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_*)(sl_row + j * 8 * SROW), ry, yrow[j], 0, 0);
+      if (NEXTN) {
+        __syncthreads();                                         // the eight slabs hold the tile's 256 output channels (hi | lo, activated)
+        const int r16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int hf = 0; hf < (NEXTN == 64 ? 1 : 2); ++hf) {
+          const int half = NEXTN == 64 ? (wv >> 2) : hf;
+          f32x4 c = {0.f, 0.f, 0.f, 0.f};                        // pixel 16 half + (lane & 15), channels 16 slice + 4 (lane >> 4) + e
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            const char* sb = slabs[s] + (16 * half + r16) * SROW + kq * 16;
+            const bf16x8 ph = *(const bf16x8*)sb, pq = *(const bf16x8*)(sb + 64);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h[s], pq, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1l[s], ph, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h[s], ph, c, 0, 0, 0);
+          }
+          bf16x4 vh, vl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = c[e] + b1v[e];
+            if (a.next_act == ACT_RELU) v = fmaxf(v, 0.f);
+            bf16 hi, lo;
+            split2(v, hi, lo);
+            vh[e] = hi; vl[e] = lo;
+          }
+          char* yq = y1s + (16 * half + r16) * YROW + (slice >> 1) * 128 + (16 * (slice & 1) + 4 * kq) * 2;
+          *(bf16x4*)yq = vh;
+          *(bf16x4*)(yq + 64) = vl;
+        }
+        __syncthreads();                                         // every wave has read the slabs: the next tile may overwrite them; y1s is complete
+        {
+          constexpr int CPN = NEXTN / 4;                         // 16-byte chunks per pixel of the follower's output
+          const int m0 = t * 32;
+          const int b0 = m0 / a.OHW, p0 = m0 - b0 * a.OHW;
+#pragma unroll
+          for (int i = 0; i < (32 * CPN) / 512; ++i) {
+            const int e = tid + 512 * i, px = e / CPN, ck = e - px * CPN;
+            int b = b0, p = p0 + px;
+            if (p >= a.OHW) { p -= a.OHW; ++b; }
+            const unsigned off = m0 + px < a.M ? (unsigned)(((long long)b * a.next_y_bstride + (long long)p * a.next_ldy) * 4 + ck * 16) : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_*)(y1s + px * YROW + ck * 16), ryn, off, 0, 0);
+          }
+        }
+      } else {
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  });
+}
+
+static int g_split_sx = 2;   // rtd_debug_option "split_sx": 0 = off, 1 = only K = 64 (+ 64) -> 256 (stage 0), 2 = also K = 128 -> N % 256 == 0 (stage 1)
+void conv_set_split_sx(int v) { g_split_sx = v; }
+// shapes the streaming split kernel takes; per-IMAGE extents only (see the kernel comment)
+static bool sx_shape_ok(const ConvArgs& a) {
+  const Tensor& x = a.x;
+  const Tensor& y = a.y;
+  const bool dual = a.x2.p != nullptr;
+  if (!g_split_sx || x.dt != BF16X2 || y.dt != BF16X2 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.x_up2) return false;
+  if (a.res_mode != RES_NONE && (a.res.dt != BF16X2 || dual)) return false;
+  if (y.c % 256 || (long long)y.h * y.w < 6400) return false;
+  if (dual) return x.c == 64 && a.x2.c == 64 && y.c == 256;
+  if (x.c == 64) return true;
+  return x.c == 128 && g_split_sx >= 2 && a.next_y.p == nullptr;
+}
+static bool dispatch_sx(const ConvK& k, const ConvArgs& a, long long x_bytes, long long x2_bytes, hipStream_t s) {
+  if (!sx_shape_ok(a)) return false;
+  const Tensor& y = a.y;
+  const bool dual = a.x2.p != nullptr, res = a.res_mode != RES_NONE, next = a.next_y.p != nullptr;
+  const long long y_bytes = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * 4;
+  long long r_bytes = 0, yn_bytes = 0;
+  if (res) r_bytes = ((long long)(a.res.n - 1) * a.res.bstride + ((long long)a.res.h * a.res.w - 1) * a.res.ld + a.res.c) * 4;
+  if (next) {
+    if (!(y.c == 256 && (a.next_y.c == 64 || a.next_y.c == 128) && a.next_y.dt == BF16X2 && a.next_y.ld % SPLIT_GROUP == 0 && ((uintptr_t)a.next_y.p & 15) == 0 &&
+          a.next_kpad == conv_kpad_split(256) && a.next_w && a.next_bias && (a.next_act == ACT_RELU || a.next_act == ACT_NONE))) return false;
+    yn_bytes = ((long long)(a.next_y.n - 1) * a.next_y.bstride + ((long long)a.next_y.h * a.next_y.w - 1) * a.next_y.ld + a.next_y.c) * 4;
+  }
+  if (y_bytes >= (1ll << 31) || r_bytes >= (1ll << 31) || yn_bytes >= (1ll << 31)) return false;
+  const long long ntiles = ((long long)k.M + 31) / 32;
+  if (ntiles >= (1ll << 30)) return false;
+  const int ny = y.c / 256;
+  const dim3 grid((unsigned)std::min<long long>(ntiles, std::max(1, 512 / ny)), ny), blk(512);     // persistent: two 8-wave blocks per CU
+#define RTD_SX(NGX, NG2, RES_, NX) hipLaunchKernelGGL((conv1x1_sx_kernel<NGX, NG2, RES_, NX>), grid, blk, 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, \
+                                                     (unsigned)y_bytes, (unsigned)x2_bytes, (int)ntiles, (unsigned)yn_bytes)
+  const int nx = next ? a.next_y.c : 0;
+  if (dual) { if (nx == 64) RTD_SX(2, 2, false, 64); else if (nx == 128) RTD_SX(2, 2, false, 128); else RTD_SX(2, 2, false, 0); }
+  else if (a.x.c == 64 && res) { if (nx == 64) RTD_SX(2, 0, true, 64); else if (nx == 128) RTD_SX(2, 0, true, 128); else RTD_SX(2, 0, true, 0); }
+  else if (a.x.c == 64) { if (nx == 64) RTD_SX(2, 0, false, 64); else if (nx == 128) RTD_SX(2, 0, false, 128); else RTD_SX(2, 0, false, 0); }
+  else if (res) RTD_SX(4, 0, true, 0);
+  else RTD_SX(4, 0, false, 0);
+#undef RTD_SX
+  return true;
+}
+
 bool conv_split_supported(const ConvArgs& a) {
   const Tensor& x = a.x;
   const Tensor& y = a.y;
@@ -3538,7 +3803,7 @@ bool conv_split_supported(const ConvArgs& a) {
     if (!(r.dt == BF16X2 || r.dt == F32) || !r.p || ((uintptr_t)r.p & 15) || r.ld % 4) return false;
     if (r.dt == BF16X2 && r.ld % SPLIT_GROUP) return false;
   }
-  return a.next_y.p == nullptr;
+  return a.next_y.p == nullptr || sx_shape_ok(a);
 }
 static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
   const Tensor& x = a.x;
@@ -3560,7 +3825,8 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
   k.M = x.n * OH * OW; k.H = x.h * up; k.W = x.w * up;
   k.Cin = 2 * x.c; k.ldx = 2 * x.ld; k.x_bstride = 2 * x.bstride;                    // bf16 elements
   k.x_up2 = a.x_up2;
-  k.next_w = nullptr; k.next_bias = nullptr; k.next_y = nullptr; k.next_ldy = 0; k.next_y_bstride = 0; k.next_kpad = 0; k.next_act = 0;
+  k.next_w = a.next_w; k.next_bias = a.next_bias; k.next_y = a.next_y.p; k.next_ldy = a.next_y.ld; k.next_y_bstride = a.next_y.bstride;   // channels
+  k.next_kpad = a.next_kpad; k.next_act = a.next_act;
   k.OH = OH; k.OW = OW; k.OHW = OH * OW;
   k.N = y.c; k.Kreal = 2 * K; k.Kpad = a.Kpad;
   k.KH = a.KH; k.KW = a.KW; k.stride = a.stride; k.pad = a.pad;
@@ -3587,6 +3853,9 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
   RTD_CHECK(x_bytes < (1ll << 31) && x2_bytes < (1ll << 31) && w_bytes < (1ll << 31), 1, "conv (bf16x3): operand larger than a buffer descriptor (2 GiB)");
   g.probe = g_glds_drop & ~32; g.splitk = 1; g.slab = nullptr; g.cnt = nullptr; g.y_bytes = 0;      // timing-only probes (rtd_debug_option "glds_drop")
   g.x_bytes = (g_glds_drop & 1) ? 0u : (unsigned)x_bytes; g.w_bytes = (g_glds_drop & 2) ? 0u : (unsigned)w_bytes; g.x2_bytes = (unsigned)x2_bytes;
+  // thin 1x1 expand convs on wide grids (stage-0 / stage-1 c3): the streaming kernel, with the next block's reduce conv riding on it
+  if (dispatch_sx(k, a, x_bytes, x2_bytes, s)) { HIP_CHECK(hipGetLastError()); return; }
+  RTD_CHECK(a.next_y.p == nullptr, 1, "conv (bf16x3): a fused following conv exists in the streaming kernel only");
   // narrow 3x3 layers on wide grids (stem.1, stem.2): the direct kernel stages every input pixel once instead of nine times
   if (g_conv_reg && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !dual && a.res_mode == RES_NONE && x.c == 32 && (y.c == 32 || y.c == 64) &&
       y.dt == BF16X2) {
@@ -3692,7 +3961,7 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
 void conv_reset_options() {
   g_glds_min_blocks = 4; g_splitk_enable = 0; g_glds_drop = 0; g_conv_mode = 0; g_force_v1 = 0; g_ws256_min_blocks = 0; g_glds_min_n = 128;
   g_wsa_min_ntn = 8; g_ws2_min_blocks = 257; g_reg_epilogue = 1; g_ws64_max_blocks = 160; g_prefetch = 1; g_conv_reg = 1; g_conv_stream = 1;
-  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160; g_split_kernel = 2; g_split_flex = 2; g_split_flex_min_nk = 16; g_split_flex_force = 0; g_split_persist = 0; g_split_persist_min_tiles = 384; g_split_flex_small_max = 128;
+  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160; g_split_kernel = 2; g_split_flex = 2; g_split_flex_min_nk = 16; g_split_flex_force = 0; g_split_persist = 0; g_split_persist_min_tiles = 384; g_split_flex_small_max = 128; g_split_sx = 2;
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t s) {

@@ -138,7 +138,7 @@ __device__ __forceinline__ void split_rows(const float* Xs, int ldx, int K, bf16
 // W[n0 + (lane & 15)][same k].  Output: fp32 Ys and / or a hi/lo split (Yh, Yl) for a following GEMM.
 template <int ACT, bool WLO = true, int PF = 2>   // WLO = false: the filter's lo half is neither loaded nor multiplied (bf16 filter, split activations)
 __device__ void row_gemm_split(const bf16* Ah, const bf16* Al, int lda, const DecLin& L, float* Ys, int ldy, const float* Rs, int ldr,
-                               bf16* Yh, bf16* Yl, int ldyb, int wave, int lane, int rot) {
+                               bf16* Yh, bf16* Yl, int ldyb, int wave, int lane, int rot, size_t wmask = ~(size_t)0) {
   const int ntiles = (L.N + 15) >> 4;
   const int r16 = lane & 15, q = lane >> 4;
   const bf16* ah = Ah + r16 * lda + 8 * q;
@@ -150,8 +150,8 @@ __device__ void row_gemm_split(const bf16* Ah, const bf16* Al, int lda, const De
     const int t = wave + 2 * NW * ((ps + rot) % npass);
     const bool has2 = t + NW < ntiles;                          // wave-uniform
     const int n0 = t << 4, n1 = has2 ? (t + NW) << 4 : n0;
-    const char* w0 = (const char*)L.w + (size_t)t * kc * 2048 + lane * 16;
-    const char* w1 = (const char*)L.w + (size_t)(has2 ? t + NW : t) * kc * 2048 + lane * 16;
+    const char* w0 = (const char*)L.w + (((size_t)t * kc * 2048) & wmask) + lane * 16;
+    const char* w1 = (const char*)L.w + (((size_t)(has2 ? t + NW : t) * kc * 2048) & wmask) + lane * 16;
     f32x4_ acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     // PF register sets, each one 64-deep K step of both tiles (8 x 16-byte loads per lane); a set is reloaded with the step PF
     // ahead right after its MFMAs were issued, so 8 PF loads per wave stay in flight (the loop is L2-latency bound: one step in
@@ -550,6 +550,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
   __shared__ __attribute__((aligned(16))) float sR[DR * LDR];   // ref boxes (cols 0..3), zero padded to 64 (K of qpos.0)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t wmask = (a.probe & 1) ? (size_t)0xFFFF : ~(size_t)0;
   // Y[16][N] = act(X[16][K] W^T + b (+ R)); X fp32 rows in LDS.  SPLIT: X is first split into sXh/sXl (all waves must have
   // left the previous GEMM: every call site below sits behind a __syncthreads()).
 #define DEC_TOUCH(LW) touch_weights(LW, rot, tiles, tid, sDummy)
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (SPLIT) {                                                                                             \
       split_rows(X, LDXS, (LW).K, sXh, sXl, LDX, tid);                                                       \
       __syncthreads();                                                                                       \
-      row_gemm_split<ACT, (SPLIT != 2), DPF>(sXh, sXl, LDX, LW, Y, LDY, R, LDRS, nullptr, nullptr, 0, wave, lane, rot);         \
+      row_gemm_split<ACT, (SPLIT != 2), DPF>(sXh, sXl, LDX, LW, Y, LDY, R, LDRS, nullptr, nullptr, 0, wave, lane, rot, wmask);         \
     } else {                                                                                                 \
       row_gemm<ACT>(X, LDXS, LW, Y, LDY, R, LDRS, wave, lane, rot);                                          \
     }                                                                                                        \
@@ -655,8 +656,8 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (SPLIT) {
       split_rows(sH, LDH, a.fc1.K, sXh, sXl, LDX, tid);
       __syncthreads();
-      if (a.mode == 4) row_gemm_split<ACT_GELU, (SPLIT != 2), DPF>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
-      else row_gemm_split<ACT_RELU, (SPLIT != 2), DPF>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
+      if (a.mode == 4) row_gemm_split<ACT_GELU, (SPLIT != 2), DPF>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot, wmask);
+      else row_gemm_split<ACT_RELU, (SPLIT != 2), DPF>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot, wmask);
     } else {
       if (a.mode == 4) row_gemm<ACT_GELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane, rot);
       else row_gemm<ACT_RELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane, rot);
@@ -664,7 +665,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     DEC_TOUCH(a.bb0);
     __syncthreads();
     DEC_STAMP(6);   // fc1
-    if (SPLIT) row_gemm_split<ACT_NONE, (SPLIT != 2), DPF>(sFh, sFl, LDFB, a.fc2, sH, LDH, sH, LDH, nullptr, nullptr, 0, wave, lane, rot);
+    if (SPLIT) row_gemm_split<ACT_NONE, (SPLIT != 2), DPF>(sFh, sFl, LDFB, a.fc2, sH, LDH, sH, LDH, nullptr, nullptr, 0, wave, lane, rot, wmask);
     else row_gemm<ACT_NONE>(sF, LDF, a.fc2, sH, LDH, sH, LDH, wave, lane, rot);
     DEC_TOUCH(a.bb1);
     __syncthreads();
@@ -740,10 +741,10 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (SPLIT) {
       split_rows(sR, LDR, a.qp0.K, sXh, sXl, LDX, tid);
       __syncthreads();
-      row_gemm_split<ACT_RELU, (SPLIT != 2), DPF>(sXh, sXl, LDX, a.qp0, nullptr, 0, nullptr, 0, sQh, sQl, LDQB, wave, lane, rot);
+      row_gemm_split<ACT_RELU, (SPLIT != 2), DPF>(sXh, sXl, LDX, a.qp0, nullptr, 0, nullptr, 0, sQh, sQl, LDQB, wave, lane, rot, wmask);
       DEC_TOUCH(a.v);
       __syncthreads();
-      row_gemm_split<ACT_NONE, (SPLIT != 2), DPF>(sQh, sQl, LDQB, a.qp1, sP, LDH, nullptr, 0, nullptr, nullptr, 0, wave, lane, rot);
+      row_gemm_split<ACT_NONE, (SPLIT != 2), DPF>(sQh, sQl, LDQB, a.qp1, sP, LDH, nullptr, 0, nullptr, nullptr, 0, wave, lane, rot, wmask);
     } else {
       row_gemm<ACT_RELU>(sR, LDR, a.qp0, sT, LDQ, nullptr, 0, wave, lane, rot);
       DEC_TOUCH(a.v);
@@ -941,9 +942,12 @@ void launch_gather_ln(const float* x, int64_t ldx, int rows_per_image, const int
   HIP_CHECK(hipGetLastError());
 }
 
+static int g_dec_probe = 0; // dec_pf += 16: DecArgs::probe bit 0
 static int g_dec_pf = 2;    // A/B hook (rtd_debug_option "dec_pf"): filter K steps in flight per wave in the split GEMMs (2 or 3)
-void dec_set_pf(int v) { g_dec_pf = v; }
-void launch_dec_layer(const DecArgs& a, hipStream_t s) {
+void dec_set_pf(int v) { g_dec_pf = v & 15; g_dec_probe = v >> 4; }
+void launch_dec_layer(const DecArgs& a_in, hipStream_t s) {
+  DecArgs a = a_in;
+  a.probe = g_dec_probe;
   RTD_CHECK(a.D == 256 && a.D / a.heads == 32 && a.ffn <= 1024 && a.C <= 512, 1, "fused decoder: d_model 256, head dim 32, ffn <= 1024");
   RTD_CHECK(a.n_levels == 3 && a.n_points == 4 && a.heads == NW, 1, "fused decoder: 3 levels x 4 points, 8 heads");
   const int tiles = (a.Q + DR - 1) / DR;

@@ -493,7 +493,7 @@ struct Builder {
     if (next_y) {                                              // the following 1x1 conv rides on this launch (ConvArgs::next_*)
       DevWeight wn;
       if (!dry) wn = get_weight(e, next_name, x.dt, next_y->c, y.c);
-      else { wn.Kpad = conv_kpad(y.c); wn.Npad = conv_npad(next_y->c); }
+      else { wn.Kpad = x.dt == BF16X2 ? conv_kpad_split(y.c) : conv_kpad(y.c); wn.Npad = conv_npad(next_y->c); }
       a.next_w = wn.w; a.next_bias = wn.bias; a.next_y = *next_y; a.next_kpad = wn.Kpad; a.next_act = next_act;
     }
     a.ws = e->conv_ws;
@@ -582,6 +582,8 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   // ---- residual stages (HF:rt_detr_resnet.py:135-310) ------------------------------------------
   Tensor feats[3];
   int cin = c.embedding_size;
+  bool c1_done = false;                                         // this block's c1 already ran inside the previous block's last conv
+  Tensor t1_next;
   for (int si = 0; si < 4; ++si) {
     const int cout = c.hidden_sizes[si];
     // Buffers are recycled inside a stage (rtd_debug_option "arena_reuse"): the blocks' outputs ping-pong between two buffers
@@ -604,8 +606,6 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       if (!name.empty()) B.plan->named[name] = t;
       return t;
     };
-    bool c1_done = false;                                       // this block's c1 already ran inside the previous block's last conv
-    Tensor t1_next;
     for (int bi = 0; bi < c.depths[si]; ++bi) {
       const int stride = (si > 0 && bi == 0) ? 2 : 1;
       const std::string pfx = nm("backbone.s%d.b%d", si, bi);
@@ -652,16 +652,20 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       if (c.layer_type == RTD_LAYER_BOTTLENECK) {
         // the c1 output of this block: with recycled buffers it is the stage's shared temporary, which the PREVIOUS block's last conv
         // may already have filled (ConvArgs::next_*: the reduce conv fused into the expand conv that produced its input)
-        Tensor t1 = e->opts.arena_reuse ? view(tb1, h, w, mid, "") : (c1_done ? t1_next : B.act(P, n, h, w, mid));
+        Tensor t1 = c1_done ? t1_next : (e->opts.arena_reuse ? view(tb1, h, w, mid, "") : B.act(P, n, h, w, mid));
         if (!c1_done) B.conv(pfx + ".c1", cur, t1, 1, 1, 0, ACT_RELU);
         c1_done = false;
         Tensor t2 = e->opts.arena_reuse ? view(tb2, oh, ow, mid, "") : B.act(P, n, oh, ow, mid);
         B.conv(pfx + ".c2", t1, t2, 3, stride, 1, ACT_RELU);
-        // fuse the NEXT block's c1 (same stage: stride 1, same extents, reads `out`) when the streaming kernel takes this conv
+        // fuse the NEXT block's c1 (1x1, stride 1, reads `out` at these extents) when the streaming kernel takes this conv: the next block of
+        // this stage, or (bf16x3 plans) block 0 of the next stage, whose c1 runs before that block's stride
         const Tensor* nx = nullptr;
         std::string nx_name;
-        if (P == BF16 && e->opts.c1_fuse && bi + 1 < c.depths[si]) {
-          Tensor t1_shape = out; t1_shape.c = t1_shape.ld = mid; t1_shape.bstride = (int64_t)oh * ow * mid;
+        const bool same_stage = bi + 1 < c.depths[si];
+        const bool cross_stage = !same_stage && SP && si + 1 < 4;
+        if ((P == BF16 || SP) && e->opts.c1_fuse && (same_stage || cross_stage)) {
+          const int mid_n = same_stage ? mid : c.hidden_sizes[si + 1] / 4;
+          Tensor t1_shape = out; t1_shape.c = t1_shape.ld = mid_n; t1_shape.bstride = (int64_t)oh * ow * mid_n;
           ConvArgs probe;                                        // this plan's shapes (fused and separate launches are bit-identical)
           probe.x = t2; probe.x.p = (void*)16;
           probe.y = out; probe.y.p = (void*)16;
@@ -669,8 +673,8 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
           else { probe.res = res; probe.res.p = (void*)16; probe.res_mode = RES_PRE; }
           probe.next_y = t1_shape; probe.next_y.p = (void*)16;
           if (conv_next_supported(probe)) {
-            t1_next = e->opts.arena_reuse ? view(tb1, oh, ow, mid, "") : B.act(P, n, oh, ow, mid);
-            nx = &t1_next; nx_name = nm("backbone.s%d.b%d", si, bi + 1) + ".c1"; c1_done = true;
+            t1_next = (same_stage && e->opts.arena_reuse) ? view(tb1, oh, ow, mid_n, "") : B.act(P, n, oh, ow, mid_n);
+            nx = &t1_next; nx_name = (same_stage ? nm("backbone.s%d.b%d", si, bi + 1) : nm("backbone.s%d.b0", si + 1)) + ".c1"; c1_done = true;
           }
         }
         if (fold_sc) B.conv(pfx + ".c3", t2, out, 1, 1, 0, ACT_RELU, nullptr, RES_NONE, 0, &sc_in, pfx + ".sc", 0, nx, nx_name, ACT_RELU);
@@ -1656,6 +1660,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "split_flex_force") == 0) { conv_set_split_flex_force(value); return RTD_OK; }
   if (strcmp(name, "split_flex_small_max") == 0) { conv_set_split_flex_small_max(value); return RTD_OK; }
   if (strcmp(name, "split_persist") == 0) { conv_set_split_persist(value); return RTD_OK; }
+  if (strcmp(name, "split_sx") == 0) { conv_set_split_sx(value); return RTD_OK; }
   if (strcmp(name, "split_persist_min_tiles") == 0) { conv_set_split_persist_min_tiles(value); return RTD_OK; }
   if (strcmp(name, "glds_drop") == 0) { conv_set_glds_drop(value); return RTD_OK; }
   if (strcmp(name, "glds_min_blocks") == 0) { conv_set_glds_min_blocks(value); return RTD_OK; }
@@ -1663,7 +1668,8 @@ int rtd_debug_option(const char* name, int value) {
 }
 
 static int op_conv_impl(int dtype, const void* x, const void* x2, int C2, const void* w_ohwi_f32, const float* bias, const void* res, void* y,
-                        int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int act, int res_mode, int out_f32, int x_up2 = 0) {
+                        int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int act, int res_mode, int out_f32, int x_up2 = 0,
+                        const void* w1_f32 = nullptr, const float* bias1 = nullptr, void* y1 = nullptr, int Cnext = 0, int next_act = 0) {
   return op_guard([&] {
     RTD_CHECK(KH == KW, RTD_E_INVALID, "square filters only");
     const int K = KH * KW * Cin + (x2 ? C2 : 0), Npad = conv_npad(Cout);
@@ -1692,6 +1698,22 @@ static int op_conv_impl(int dtype, const void* x, const void* x2, int C2, const 
     a.act = act; a.res_mode = res ? res_mode : RES_NONE;
     if (res) a.res = mk(res, dtype, B, OH, OW, Cout);
     if (x2) a.x2 = mk(x2, dtype, B, OH, OW, C2);
+    float* w1pad = nullptr; void* w1dev = nullptr; float* b1pad = nullptr;
+    if (y1) {                                                    // a following 1x1 conv Cout -> Cnext fused into this launch (ConvArgs::next_*)
+      RTD_CHECK(dtype == BF16 || dtype == BF16X2, RTD_E_INVALID, "fused following conv: bf16 / bf16x2 only");
+      const int N1 = conv_npad(Cnext), K1 = dtype == BF16X2 ? conv_kpad_split(Cout) : conv_kpad(Cout), k1cols = dtype == BF16X2 ? K1 / 2 : K1;
+      HIP_CHECK(hipMalloc((void**)&w1pad, (size_t)N1 * k1cols * 4));
+      HIP_CHECK(hipMemset(w1pad, 0, (size_t)N1 * k1cols * 4));
+      HIP_CHECK(hipMemcpy2D(w1pad, (size_t)k1cols * 4, w1_f32, (size_t)Cout * 4, (size_t)Cout * 4, Cnext, hipMemcpyDeviceToDevice));
+      HIP_CHECK(hipMalloc((void**)&b1pad, (size_t)N1 * 4));
+      HIP_CHECK(hipMemset(b1pad, 0, (size_t)N1 * 4));
+      HIP_CHECK(hipMemcpy(b1pad, bias1, (size_t)Cnext * 4, hipMemcpyDeviceToDevice));
+      HIP_CHECK(hipMalloc(&w1dev, (size_t)N1 * K1 * 2));
+      if (dtype == BF16) launch_f32_to(w1pad, w1dev, BF16, (int64_t)N1 * K1, nullptr);
+      else launch_f32_to_split(w1pad, k1cols, w1dev, k1cols, N1, k1cols, nullptr);
+      a.next_w = w1dev; a.next_bias = b1pad; a.next_y = mk(y1, dtype, B, OH, OW, Cnext); a.next_kpad = K1; a.next_act = next_act;
+      RTD_CHECK(conv_next_supported(a), RTD_E_INVALID, "fused following conv: shape not taken by the streaming kernels");
+    }
     ConvWorkspace ws;
     ws.slab_bytes = (size_t)640 * 128 * 128 * 4; ws.cnt_entries = 1024;
     HIP_CHECK(hipMalloc((void**)&ws.slab, ws.slab_bytes));
@@ -1705,6 +1727,7 @@ static int op_conv_impl(int dtype, const void* x, const void* x2, int C2, const 
     HIP_CHECK(hipDeviceSynchronize());
     if (wdev != wpad) (void)hipFree(wdev);
     (void)hipFree(wpad); (void)hipFree(bpad);
+    if (w1pad) { (void)hipFree(w1pad); (void)hipFree(w1dev); (void)hipFree(b1pad); }
   });
 }
 
@@ -1717,6 +1740,12 @@ int rtd_op_conv_dual(int dtype, const void* x, const void* x2, const void* w_f32
                      int H, int W, int Cin, int C2, int Cout, int KH, int stride, int pad, int act, int res_mode, int out_f32, int x_up2) {
   if (!x2 || (x_up2 && ((H | W) & 1))) return RTD_E_INVALID;
   return op_conv_impl(dtype, x, x2, C2, w_f32, bias, res, y, B, H, W, Cin, Cout, KH, KH, stride, pad, act, res_mode, out_f32, x_up2);
+}
+
+int rtd_op_conv_next(int dtype, const void* x, const void* x2, const void* w_f32, const float* bias, const void* res, void* y, const void* w1_f32,
+                     const float* bias1, void* y1, int B, int H, int W, int Cin, int C2, int Cout, int Cnext, int act, int res_mode, int next_act) {
+  if (!y1 || !w1_f32 || !bias1) return RTD_E_INVALID;
+  return op_conv_impl(dtype, x, x2, x2 ? C2 : 0, w_f32, bias, res, y, B, H, W, Cin, Cout, 1, 1, 1, 0, act, res_mode, 0, 0, w1_f32, bias1, y1, Cnext, next_act);
 }
 
 int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int stride, int pad, int with_res, int reps,

@@ -295,6 +295,9 @@ SPLIT_CONV_CASES = [
     (8, 80, 80, 64, 256, 3, 1, 1, "relu", 0, 0),        # 80^2 x 8 maps: 208-pixel tiles, 3 stages, one block per CU
     (8, 20, 20, 256, 512, 3, 1, 1, "relu", 1, 0),       # 20^2 x 8 maps: 64-pixel tiles
     (3, 37, 29, 512, 192, 1, 1, 0, "none", 0, 1),       # ragged M and N, fp32 output, K = 512 (16 K-steps: flexible tiles)
+    (1, 81, 80, 64, 256, 1, 1, 0, "silu", 2, 0),        # streaming split kernel (>= 6400 pixels per image): ragged last 32-pixel tile, post residual
+    (2, 80, 80, 128, 512, 1, 1, 0, "relu", 1, 0),       # stage-1 c3: K = 128, two 256-channel blocks in gridDim.y
+    (1, 100, 70, 64, 512, 1, 1, 0, "none", 0, 0),       # no residual, linear
 ]
 
 
@@ -342,6 +345,7 @@ def test_conv_split_bf16x3(L, case):
             _capi.debug_option("split_kernel", kern)
             _capi.debug_option("split_flex", 0)
             _capi.debug_option("split_persist", 0)
+            _capi.debug_option("split_sx", 0)        # the tiled kernels on the streaming kernel's shapes too
         if kern == -2:
             _capi.debug_option("split_flex", 1)
             _capi.debug_option("split_flex_min_nk", 1)
@@ -362,6 +366,81 @@ def test_conv_split_bf16x3(L, case):
         print(f"split conv {case}: max err / max |y| {err:.2e}, rel l2 {rel:.2e}")
         assert err < 2e-5 and rel < 1e-5, (case, ws2, ws64, kern, err, rel)
     _capi.debug_option("reset", 0)
+
+
+SX_NEXT_CASES = [
+    # B, H, W, Cin, C2 (0 = no second input), Cnext, act, res_mode, next_act
+    (2, 160, 160, 64, 64, 64, "relu", 0, "relu"),    # stage-0 block 0: c3 + folded shortcut, next block's c1 fused
+    (1, 160, 160, 64, 0, 64, "relu", 1, "relu"),     # stage-0 blocks 1..: residual
+    (1, 81, 80, 64, 0, 128, "relu", 1, "relu"),      # last block of stage 0 -> stage-1 block 0 c1 (128 channels), ragged last tile
+    (3, 90, 90, 64, 0, 64, "silu", 2, "none"),       # tiles straddling images, post residual, linear follower
+]
+
+
+@pytest.mark.parametrize("case", SX_NEXT_CASES)
+def test_conv_split_streaming_with_fused_next(L, case):
+    """conv1x1_sx_kernel with ConvArgs::next_*: y = act(W [x | x2] + b (+ res)) and y1 = next_act(W1 y + b1) from one launch, both against
+    fp64 on the values the kernel sees (y1 from the hi/lo-rounded y the kernel keeps in LDS = what a separate launch would read back)."""
+    from telescope_cam_detection_amd import _capi
+    B, H, W, Cin, C2, Cnext, act, res_mode, next_act = case
+    Cout = 256
+    g = torch.Generator().manual_seed(5200 + SX_NEXT_CASES.index(case))
+    rq = lambda t: torch.from_numpy(_capi.from_split(_capi.to_split(t.numpy())))      # round to hi + lo
+    x = torch.randn(B, H, W, Cin, generator=g)
+    x2 = torch.randn(B, H, W, C2, generator=g) if C2 else None
+    w = torch.randn(Cout, Cin + C2, generator=g) * (1.0 / (Cin + C2)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(B, H, W, Cout, generator=g) if res_mode else None
+    w1 = torch.randn(Cnext, Cout, generator=g) * (1.0 / Cout) ** 0.5
+    b1 = torch.randn(Cnext, generator=g) * 0.1
+    xin = rq(x) if x2 is None else torch.cat([rq(x), rq(x2)], -1)
+    y = xin.double() @ rq(w).double().t() + b.double()
+    if res_mode == 1:
+        y = y + rq(res).double()
+    y = {"none": lambda t: t, "relu": F.relu, "silu": F.silu}[act](y)
+    if res_mode == 2:
+        y = y + rq(res).double()
+    dev = lambda t: torch.from_numpy(_capi.to_split(t.numpy()).view(np.int16)).cuda()
+    xd, x2d, rd = dev(x), (dev(x2) if x2 is not None else None), (dev(res) if res is not None else None)
+    wd, bd, w1d, b1d = w.contiguous().cuda(), b.cuda(), w1.contiguous().cuda(), b1.cuda()
+    yd = torch.full((B, H, W, 2 * Cout), -1, dtype=torch.int16, device="cuda")
+    y1d = torch.full((B, H, W, 2 * Cnext), -1, dtype=torch.int16, device="cuda")
+    A = {"none": 0, "relu": 1, "silu": 2}
+    ck(L, L.rtd_op_conv_next(_capi.DT_BF16X2, xd.data_ptr(), x2d.data_ptr() if x2d is not None else None, wd.data_ptr(), bd.data_ptr(),
+                             rd.data_ptr() if rd is not None else None, yd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), y1d.data_ptr(),
+                             B, H, W, Cin, C2, Cout, Cnext, A[act], res_mode, A[next_act]))
+    got = torch.from_numpy(_capi.from_split(yd.cpu().numpy().view(np.uint16))).double()
+    got1 = torch.from_numpy(_capi.from_split(y1d.cpu().numpy().view(np.uint16))).double()
+    assert torch.isfinite(got).all() and torch.isfinite(got1).all()
+    err = (got - y).abs().max().item() / y.abs().max().item()
+    y1 = got @ rq(w1).double().t() + b1.double()                    # the follower reads the kernel's own (rounded) y
+    y1 = {"none": lambda t: t, "relu": F.relu}[next_act](y1)
+    err1 = (got1 - y1).abs().max().item() / y1.abs().max().item()
+    print(f"sx + next {case}: y {err:.2e}, y1 {err1:.2e}")
+    assert err < 2e-5 and err1 < 2e-5, (case, err, err1)
+    # the same conv without the follower gives the same y bits (kernel choice is per-image; the follower only reads the tile)
+    yd2 = torch.full((B, H, W, 2 * Cout), -1, dtype=torch.int16, device="cuda")
+    if x2d is None:
+        ck(L, L.rtd_op_conv(_capi.DT_BF16X2, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None, yd2.data_ptr(),
+                            B, H, W, Cin, Cout, 1, 1, 1, 0, A[act], res_mode, 0))
+    else:
+        ck(L, L.rtd_op_conv_dual(_capi.DT_BF16X2, xd.data_ptr(), x2d.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, yd2.data_ptr(),
+                                 B, H, W, Cin, C2, Cout, 1, 1, 0, A[act], 0, 0, 0))
+    assert torch.equal(yd, yd2)
+    # and the separate follower launch (tiled split kernel) agrees with the fused one to rounding
+    y1d2 = torch.full((B, H, W, 2 * Cnext), -1, dtype=torch.int16, device="cuda")
+    ck(L, L.rtd_op_conv(_capi.DT_BF16X2, yd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), None, y1d2.data_ptr(), B, H, W, Cout, Cnext, 1, 1, 1, 0, A[next_act], 0, 0))
+    sep = torch.from_numpy(_capi.from_split(y1d2.cpu().numpy().view(np.uint16))).double()
+    assert (sep - got1).abs().max().item() / y1.abs().max().item() < 2e-5
+    # split_sx 0: the tiled kernels take the expand conv; a fused follower is then refused, not silently dropped
+    _capi.debug_option("split_sx", 0)
+    try:
+        rc = L.rtd_op_conv_next(_capi.DT_BF16X2, xd.data_ptr(), x2d.data_ptr() if x2d is not None else None, wd.data_ptr(), bd.data_ptr(),
+                                rd.data_ptr() if rd is not None else None, yd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), y1d.data_ptr(),
+                                B, H, W, Cin, C2, Cout, Cnext, A[act], res_mode, A[next_act])
+        assert rc != 0
+    finally:
+        _capi.debug_option("reset", 0)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
