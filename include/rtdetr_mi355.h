@@ -144,12 +144,21 @@ int64_t rtd_arena_bytes(rtd_handle h);
  *                   kernel wherever eligible | 9 streaming 1x1 kernels whatever the grid size | 10 128 x 64 tile everywhere
  *   conv_reg [1], conv_stream [1], stream2 [1], stream2_max_n [2048], stream_slab [1], stream_min_tiles [2048], wsa_min_ntn [8], ws2_min_blocks [257], ws64_max_blocks [160],
  *   ws256_min_blocks [0], glds_min_blocks [4], glds_min_n [128], splitk [0], reg_epilogue [1], prefetch [1], maxpool_v1 [0],
- *   dec_pf [2], glds_drop [0: timing-only probes, results wrong when set]
- * Plan-build switches, read when an engine builds a plan (set them before rtd_load_weights):
+ *   dec_pf [2; + 16: L2-hot filter probe, results wrong], glds_drop [0: timing-only probes, results wrong when set]
+ *   conv_reg is a bit set: 1 = direct 3x3 kernels for the narrow stem / stage-0 layers, 2 = the 64-channel BF16X2 one [3]
+ * RTD_PREC_BF16X3 kernels: split_kernel [2: 0 round-1 tile, 1 dedicated kernel on 32x32x16 MFMAs, 2 on 16x16x32] | split_ws2_min_blocks [257] |
+ *   split_ws64_max_blocks [160] | split_flex [2: flexible tile heights 0 never, 1 every grid, 2 grids of <= split_flex_small_max [128] tiles],
+ *   split_flex_min_nk [16], split_flex_force [0] | split_persist [0] persistent three-role kernel, split_persist_min_tiles [384] |
+ *   split_sx [2: streaming 1x1 kernel 0 off, 1 stage-0 shapes, 2 + K = 128]
+ * "reset" (any value): every dispatch switch and every plan-build default back to the values in brackets.
+ * Plan-build switches are process-wide DEFAULTS that a handle snapshots at rtd_create: all plans of a handle agree with each other and a later
+ * call cannot change a live handle (set them before rtd_create):
  *   sc_fold [1] projection shortcut folded into the block's last conv | up_fold [1] FPN upsample folded into the CSP's first conv |
- *   c1_fuse [1] stage-0 reduce conv computed inside the previous block's expand conv | attn_split [2] bf16 engine: self-attention on
- *   split-bf16 MFMAs (bit 0 AIFI, bit 1 decoder) |
- *   arena_reuse [1] | stem_fused [0] | dec_fused [1], dec_split [1: 0 fp32 MFMA, 2 bf16 filters], sel_fused [1] | dec_stamps [0] */
+ *   c1_fuse [1] a block's reduce conv computed inside the previous block's expand conv (bf16: stage 0/1; bf16x3: stage 0 and the first block
+ *   of stage 1) | attn_split [2] self-attention on split-bf16 MFMAs (bit 0 AIFI, bit 1 decoder) |
+ *   arena_reuse [1] | stem_fused [0] (bf16) / stem_fused_split [1] (bf16x3): stem.0 straight from the uint8 frames | side_stream [1] query
+ *   selection on a second stream beside the value projection | dec_fused [1], dec_split [1: 0 fp32 MFMA, 2 bf16 filters], sel_fused [1] |
+ *   dec_stamps [0] */
 int rtd_debug_option(const char* name, int value);
 
 /* ---- Stage 2: crop + classifier pre-processing for a whole batch of detections ------------------

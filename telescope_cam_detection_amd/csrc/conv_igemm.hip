@@ -2932,7 +2932,141 @@ __global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a
   }
 }
 
-static int g_conv_reg = 1;    // A/B hook (rtd_debug_option "conv_reg"): 0 = narrow 3x3 layers stay on the implicit-GEMM kernels
+
+// The same direct scheme for the 64 -> 64 channel 3x3 convs of stage 0 (bottleneck c2 at 160^2: 15 GFLOP on 105 MB, 3.5x off both rooflines on the
+// 128 x 64 implicit-GEMM tile, whose nine taps re-stage every input pixel and whose LDS traffic per MFMA is the highest of all tiles).
+//   * tile 8 x 16 output pixels; the (8+2) x (16+2) x 256-byte input patch is staged once by LDS-DMA (double buffered, source-side XOR swizzle:
+//     16-byte slot c of pixel pi holds chunk c ^ (pi & 15), so the 16 consecutive pixels of a B-fragment read hit 16 different bank groups);
+//   * wave = (16-channel group, row half): its 16 x 576 filter slice, hi and lo, lives in 144 VGPRs as v_mfma_f32_16x16x32_bf16 A operands;
+//   * a patch-row fragment (one ds_read_b128 pair: hi, lo) serves up to three output rows (kh = patch row - output row): 72 fragment reads for
+//     216 MFMAs per wave and tile - the loop is MFMA-bound, not LDS-bound;
+//   * the tile's 128 x 64 outputs are collected in LDS as BF16X2 rows and stored row-shaped (16 lanes = one pixel's 256-byte run).
+// Per output: taps in (kh, kw) order, channel groups inside a tap, lo-terms first - fixed per pixel, so batch size does not change a frame's bits.
+__global__ __launch_bounds__(512, 1) void conv3x3_reg_split64_kernel(const ConvK a, unsigned x_bytes, unsigned y_bytes, int tiles_x, int tiles_y, int ntiles) {
+  constexpr int NW = 8;
+  constexpr int TH = 8, TW = 16, PW = TW + 2, PH = TH + 2, NPIX = PW * PH;
+  constexpr int PPI = 4;                          // pixels per DMA instruction (64 lanes x 16 bytes, 256 bytes per pixel)
+  constexpr int NINSTR = (NPIX + PPI - 1) / PPI;
+  constexpr int PBUF = NINSTR * 1024;
+  constexpr int SROWB = 256 + 16;
+  __shared__ __attribute__((aligned(16))) char patch[2 * PBUF];
+  __shared__ __attribute__((aligned(16))) char stage[TH * TW * SROWB];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cgp = wv & 3, rh = wv >> 2;           // 16-channel group, row half (output rows 4 rh .. 4 rh + 3)
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  bf16x8 wf[9][2][2];                             // [tap][32-channel group][hi / lo]
+  {
+    const bf16* wr = (const bf16*)a.w + (size_t)(16 * cgp + r16) * a.Kpad + 8 * kq;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        wf[tap][c][0] = *(const bf16x8*)(wr + (tap * 2 + c) * 64);
+        wf[tap][c][1] = *(const bf16x8*)(wr + (tap * 2 + c) * 64 + 32);
+      }
+  }
+  const f32x4 bv = *(const f32x4*)(a.bias + 16 * cgp + 4 * kq);
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
+  auto issue_patch = [&](int tile, int buf) {
+    const int tx = tile % tiles_x;
+    const int t2 = tile / tiles_x;
+    const int ty = t2 % tiles_y;
+    const int b = t2 / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    for (int j = wv; j < NINSTR; j += NW) {
+      const int pi = j * PPI + (lane >> 4);
+      const int py = pi / PW, px = pi - py * PW;
+      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+      const bool ok = pi < NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const int src_chunk = (lane & 15) ^ (pi & 15);
+      const unsigned vo = ok ? (unsigned)(((long long)b * a.x_bstride + ((long long)iy * a.W + ix) * a.ldx) * 2 + src_chunk * 16) : 0x80000000u;   // ldx: bf16 elements
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(patch + buf * PBUF + j * 1024), 16, vo, 0, 0, 0);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) issue_patch(tile, 0);
+  for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+    const int buf = it & 1;
+    // the 4 stores of the previous tile were issued after this tile's DMA and may stay in flight
+    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __syncthreads();                                // patch[buf] landed for every wave; everyone has left the previous tile (patch[buf ^ 1], stage)
+    if (tile + (int)gridDim.x < ntiles) issue_patch(tile + gridDim.x, buf ^ 1);
+    const int tx = tile % tiles_x;
+    const int t2 = tile / tiles_x;
+    const int ty = t2 % tiles_y;
+    const int b = t2 / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const char* pbuf = patch + buf * PBUF;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[2][2][2];                             // [parity][group][hi / lo]
+    // fragment addresses are tile-invariant; recomputed per tile behind an opaque copy (hoisted out of the tile loop they cost 70 VGPRs and spill)
+    int q0 = 4 * rh * PW + r16;
+    asm volatile("" : "+v"(q0));
+    auto read_px = [&](bf16x8 (&dst)[2][2], int pr, int kw) {
+      const int pi = q0 + pr * PW + kw;
+      const unsigned a0 = (unsigned)(pi << 8) | (unsigned)(((pi & 15) ^ kq) << 4);     // chunk kq of group 0, hi; the others differ in slot bits 2, 3
+      dst[0][0] = *(const bf16x8*)(pbuf + a0);
+      dst[0][1] = *(const bf16x8*)(pbuf + (a0 ^ 0x40));
+      dst[1][0] = *(const bf16x8*)(pbuf + (a0 ^ 0x80));
+      dst[1][1] = *(const bf16x8*)(pbuf + (a0 ^ 0xC0));
+    };
+    read_px(xf[0], 0, 0);
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {                  // s = patch row * 3 + kw
+      const int pr = s / 3, kw = s - pr * 3;
+      if (s + 1 < 18) read_px(xf[(s + 1) & 1], (s + 1) / 3, (s + 1) % 3);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kh = pr - r;
+        if (kh >= 0 && kh <= 2) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh * 3 + kw][c][0], xf[s & 1][c][1], acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh * 3 + kw][c][1], xf[s & 1][c][0], acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh * 3 + kw][c][0], xf[s & 1][c][0], acc[r], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue: lane = pixel r16 of each of the wave's 4 rows, channels 16 cgp + 4 kq + (0..3) -> BF16X2 rows in LDS ----
+    dispatch_act(a.act, [&](auto actc) {
+      constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bf16x4 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bf16 hi, lo; split2(act_c<ACT>(acc[r][e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
+        char* q = stage + ((4 * rh + r) * TW + r16) * SROWB + (cgp >> 1) * 128 + (16 * (cgp & 1) + 4 * kq) * 2;
+        *(bf16x4*)q = oh;
+        *(bf16x4*)(q + 64) = ol;
+      }
+    });
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 512 * i;
+      const int p = idx >> 4, ck = idx & 15;
+      const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
+      const bool ok = oy < a.H && ox < a.W;
+      const unsigned vo = ok ? (unsigned)(4 * ((long long)b * a.y_bstride + ((long long)oy * a.W + ox) * a.ldy) + ck * 16) : 0x80000000u;   // ldy: channels
+      __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_*)(stage + p * SROWB + ck * 16), ry, vo, 0, 0);
+    }
+  }
+}
+
+static int g_conv_reg = 3;    // A/B hook (rtd_debug_option "conv_reg"; bit 1: the 64-channel split kernel): 0 = narrow 3x3 layers stay on the implicit-GEMM kernels
 void conv_set_reg(int v) { g_conv_reg = v; }
 
 // returns true when the launch was taken by the direct kernel
@@ -3870,6 +4004,19 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
       return;
     }
   }
+  // 64 -> 64 channel 3x3 on wide maps (stage-0 c2): direct kernel on 8 x 16 tiles.  Chosen on the per-IMAGE tile count: every batch size runs the
+  // same arithmetic (batch invariance is bit-exact)
+  if ((g_conv_reg & 2) && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !dual && a.res_mode == RES_NONE && x.c == 64 && y.c == 64 && y.dt == BF16X2) {
+    const long long y_bytes = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * 4;
+    const int tiles_x = (x.w + 15) / 16, tiles_y = (x.h + 7) / 8;
+    const long long ntiles = (long long)x.n * tiles_x * tiles_y;
+    if (tiles_x * tiles_y >= 128 && ntiles < (1ll << 30) && y_bytes < (1ll << 31)) {
+      const unsigned gx = (unsigned)std::min<long long>(ntiles, 256);        // persistent, one block per CU
+      hipLaunchKernelGGL(conv3x3_reg_split64_kernel, dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+  }
   const long long mt = (k.M + 127) / 128, ntn = (k.N + 127) / 128, ntn64 = (k.N + 63) / 64;
   // ---- persistent three-role kernel (conv_igemm_wsp_kernel): grids with several tiles per CU
   if (g_split_persist && g_split_kernel == 2 && k.N >= 128 && k.Kpad / 64 >= 2 && (k.Kpad / 64 >= 8 || k.res_mode == RES_NONE || g_split_persist == 2)) {
@@ -3960,7 +4107,7 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
 
 void conv_reset_options() {
   g_glds_min_blocks = 4; g_splitk_enable = 0; g_glds_drop = 0; g_conv_mode = 0; g_force_v1 = 0; g_ws256_min_blocks = 0; g_glds_min_n = 128;
-  g_wsa_min_ntn = 8; g_ws2_min_blocks = 257; g_reg_epilogue = 1; g_ws64_max_blocks = 160; g_prefetch = 1; g_conv_reg = 1; g_conv_stream = 1;
+  g_wsa_min_ntn = 8; g_ws2_min_blocks = 257; g_reg_epilogue = 1; g_ws64_max_blocks = 160; g_prefetch = 1; g_conv_reg = 3; g_conv_stream = 1;
   g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160; g_split_kernel = 2; g_split_flex = 2; g_split_flex_min_nk = 16; g_split_flex_force = 0; g_split_persist = 0; g_split_persist_min_tiles = 384; g_split_flex_small_max = 128; g_split_sx = 2;
 }
 

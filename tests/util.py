@@ -43,21 +43,24 @@ def sample(t, n=2048):
     return f[::step][:n].numpy()
 
 
-def match_detections(ref_labels, ref_boxes, ref_scores, labels, boxes, scores, score_tol, box_tol):
+def match_detections(ref_labels, ref_boxes, ref_scores, labels, boxes, scores, score_tol, box_tol, return_unmatched=False):
     """Order-tolerant comparison of two (labels, boxes, scores) triples for ONE frame.
 
     torch.topk's tie order is unspecified and equal / near-equal scores exist even in fp32
     (SURVEY.md §7 "hard parts"), so rows are matched greedily: same label, |dscore| <= score_tol,
-    max|dbox| <= box_tol.  Returns (n_matched, n_ref, worst_score_err, worst_box_err over matches).
+    max|dbox| <= box_tol.  Returns (n_matched, n_ref, worst_score_err, worst_box_err over matches)
+    [+ the indices of the reference rows left without a partner when return_unmatched].
     """
     ref_labels, labels = np.asarray(ref_labels), np.asarray(labels)
     ref_boxes, boxes = np.asarray(ref_boxes, np.float64), np.asarray(boxes, np.float64)
     ref_scores, scores = np.asarray(ref_scores, np.float64), np.asarray(scores, np.float64)
     used = np.zeros(len(labels), bool)
     matched, ws, wb = 0, 0.0, 0.0
+    unmatched = []
     for i in range(len(ref_labels)):
         cand = np.where((labels == ref_labels[i]) & ~used & (np.abs(scores - ref_scores[i]) <= score_tol))[0]
         if len(cand) == 0:
+            unmatched.append(i)
             continue
         d = np.abs(boxes[cand] - ref_boxes[i]).max(axis=1)
         j = int(np.argmin(d))
@@ -66,4 +69,8 @@ def match_detections(ref_labels, ref_boxes, ref_scores, labels, boxes, scores, s
             matched += 1
             ws = max(ws, abs(scores[cand[j]] - ref_scores[i]))
             wb = max(wb, d[j])
+        else:
+            unmatched.append(i)
+    if return_unmatched:
+        return matched, len(ref_labels), ws, wb, unmatched
     return matched, len(ref_labels), ws, wb
