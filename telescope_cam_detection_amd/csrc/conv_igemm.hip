@@ -3682,14 +3682,16 @@ void conv_set_split_ws64_max_blocks(int v) { g_split_ws64_max_blocks = v; }
 // Arithmetic per output: K chunks in order into a zero accumulator (lo-terms first inside a chunk), + bias, + residual (hi + lo),
 // activation, one hi/lo rounding.  Kernel choice depends on the per-IMAGE extents only, so every batch size runs the same arithmetic.
 // ------------------------------------------------------------------------------------------------
-template <int NGX, int NG2, bool RES, int NEXTN>   // NGX / NG2: 32-channel K groups read from x / from ConvK::x2
+template <int NGX, int NG2, bool RES, int NEXTN, bool F32OUT = false>   // NGX / NG2: 32-channel K groups read from x / from ConvK::x2; F32OUT: fp32 rows out
 __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsigned x_bytes, unsigned r_bytes, unsigned y_bytes, unsigned x2_bytes, int ntiles,
                                                             unsigned yn_bytes) {
   constexpr int NKX = 2 * NGX, NK2 = 2 * NG2, NKK = NKX + NK2;   // 16-deep MFMA chunks
   constexpr int NG_ = NGX + NG2;
   constexpr int SROW = 144;
   __shared__ __attribute__((aligned(16))) char slabs[8][32 * SROW];
-  __shared__ __attribute__((aligned(16))) char xs[2][32 * (NG_ * 128 + 16)];
+  constexpr int XBUFS = NG_ <= 4 ? 2 : 1;                        // K = 256: one buffer (two barriers per tile) keeps two blocks per CU
+  static_assert(!F32OUT || (!RES && !NEXTN), "fp32 output: plain conv only");
+  __shared__ __attribute__((aligned(16))) char xs[XBUFS][32 * (NG_ * 128 + 16)];
   constexpr int YROW = NEXTN * 4 + 16;
   __shared__ __attribute__((aligned(16))) char y1s[NEXTN ? 32 * YROW : 16];   // the follower's output tile: accumulator-shaped writes, row-shaped stores
   __shared__ __attribute__((aligned(16))) float sbias[256];
@@ -3740,8 +3742,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
   constexpr int XROW = NG_ * 128 + 16;                            // + 16: consecutive rows shift by 4 banks (conflict-free ds_read_b128)
   constexpr int CPRX = NGX * 8, CPR2 = NG2 ? NG2 * 8 : 1;         // 16-byte chunks per pixel and source
   constexpr int LX = (32 * CPRX + 511) / 512, L2 = NG2 ? (32 * CPR2 + 511) / 512 : 0;
-  static_assert(LX <= 2 && L2 <= 1, "staging registers");       // (fixed extents below: hipcc drops the host stub of a kernel template whose lambdas see dependent-extent arrays)
-  auto issue = [&](int t, u32x4_ (&gx)[2], u32x4_ (&g2)[1], u32x4_ (&rv)[4], unsigned (&yrow)[4]) {
+  static_assert(LX <= 4 && L2 <= 1, "staging registers");       // (fixed extents below: hipcc drops the host stub of a kernel template whose lambdas see dependent-extent arrays)
+  auto issue = [&](int t, u32x4_ (&gx)[4], u32x4_ (&g2)[1], u32x4_ (&rv)[4], unsigned (&yrow)[4]) {
     // one division per tile: the tile's first pixel (uniform); a tile crosses at most one image boundary (OHW >= 32)
     const int m0 = t * 32;
     const int b0 = m0 / a.OHW, p0 = m0 - b0 * a.OHW;
@@ -3774,12 +3776,13 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
 
   dispatch_act(a.act, [&](auto actc) {
     constexpr int ACT = decltype(actc)::value;
-    u32x4_ gx[2], g2[1], rvn[4];
+    u32x4_ gx[4], g2[1], rvn[4];
     unsigned yrown[4];
     int t = blockIdx.x;
     if (t < ntiles) issue(t, gx, g2, rvn, yrown);
     for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
-      char* xb = xs[it & 1];
+      char* xb = xs[XBUFS == 2 ? (it & 1) : 0];
+      if (XBUFS == 1) __syncthreads();                           // every wave has read the previous tile
 #pragma unroll
       for (int i = 0; i < LX; ++i) {
         const int e = tid + 512 * i, px = e / CPRX, ck = e - px * CPRX;
@@ -3816,6 +3819,16 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
 #pragma unroll
         for (int e = 0; e < 8; ++e) { r[e] = (float)h0[e] + (float)l0[e]; r[8 + e] = (float)h1[e] + (float)l1[e]; }
       }
+      if (F32OUT) {                                              // fp32 rows: the wave's 32 channels are one 128-byte run per pixel as well
+        char* sf = sl + pl * SROW + 64 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = act_c<ACT>(acc[4 * q + e] + bl[4 * q + e]);
+          *(f32x4*)(sf + 16 * q) = o;
+        }
+      } else {
       bf16x8 oh[2], ol[2];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -3828,6 +3841,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
         oh[e >> 3][e & 7] = hi; ol[e >> 3][e & 7] = lo;
       }
       *(bf16x8*)sl_acc = oh[0]; *(bf16x8*)(sl_acc + 16) = oh[1]; *(bf16x8*)(sl_acc + 64) = ol[0]; *(bf16x8*)(sl_acc + 80) = ol[1];
+      }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_*)(sl_row + j * 8 * SROW), ry, yrow[j], 0, 0);
@@ -3880,16 +3894,20 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
   });
 }
 
-static int g_split_sx = 2;   // rtd_debug_option "split_sx": 0 = off, 1 = only K = 64 (+ 64) -> 256 (stage 0), 2 = also K = 128 -> N % 256 == 0 (stage 1)
+static int g_split_sx = 3;   // rtd_debug_option "split_sx": 0 = off, 1 = only K = 64 (+ 64) -> 256 (stage 0), 2 = also K = 128 -> N % 256 == 0 (stage 1), 3 = also K = 256 (fp32 or BF16X2 out)
 void conv_set_split_sx(int v) { g_split_sx = v; }
 // shapes the streaming split kernel takes; per-IMAGE extents only (see the kernel comment)
 static bool sx_shape_ok(const ConvArgs& a) {
   const Tensor& x = a.x;
   const Tensor& y = a.y;
   const bool dual = a.x2.p != nullptr;
-  if (!g_split_sx || x.dt != BF16X2 || y.dt != BF16X2 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.x_up2) return false;
+  if (!g_split_sx || x.dt != BF16X2 || !(y.dt == BF16X2 || y.dt == F32) || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.x_up2) return false;
   if (a.res_mode != RES_NONE && (a.res.dt != BF16X2 || dual)) return false;
   if (y.c % 256 || (long long)y.h * y.w < 6400) return false;
+  // K = 256 (value projection 256 -> 1536 fp32): plain conv, either output type
+  // (N >= 1024 only: with one or two channel blocks per pixel tile the tiled kernel is faster - decoder input projection 36 vs 46 us)
+  if (x.c == 256) return g_split_sx >= 3 && y.c >= 1024 && !dual && a.res_mode == RES_NONE && a.next_y.p == nullptr;
+  if (y.dt != BF16X2) return false;
   if (dual) return x.c == 64 && a.x2.c == 64 && y.c == 256;
   if (x.c == 64) return true;
   return x.c == 128 && g_split_sx >= 2 && a.next_y.p == nullptr;
@@ -3917,6 +3935,8 @@ static bool dispatch_sx(const ConvK& k, const ConvArgs& a, long long x_bytes, lo
   if (dual) { if (nx == 64) RTD_SX(2, 2, false, 64); else if (nx == 128) RTD_SX(2, 2, false, 128); else RTD_SX(2, 2, false, 0); }
   else if (a.x.c == 64 && res) { if (nx == 64) RTD_SX(2, 0, true, 64); else if (nx == 128) RTD_SX(2, 0, true, 128); else RTD_SX(2, 0, true, 0); }
   else if (a.x.c == 64) { if (nx == 64) RTD_SX(2, 0, false, 64); else if (nx == 128) RTD_SX(2, 0, false, 128); else RTD_SX(2, 0, false, 0); }
+  else if (a.x.c == 256 && y.dt == F32) hipLaunchKernelGGL((conv1x1_sx_kernel<8, 0, false, 0, true>), grid, blk, 0, s, k, (unsigned)x_bytes, 0u, (unsigned)y_bytes, 0u, (int)ntiles, 0u);
+  else if (a.x.c == 256) RTD_SX(8, 0, false, 0);
   else if (res) RTD_SX(4, 0, true, 0);
   else RTD_SX(4, 0, false, 0);
 #undef RTD_SX
@@ -4108,7 +4128,7 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
 void conv_reset_options() {
   g_glds_min_blocks = 4; g_splitk_enable = 0; g_glds_drop = 0; g_conv_mode = 0; g_force_v1 = 0; g_ws256_min_blocks = 0; g_glds_min_n = 128;
   g_wsa_min_ntn = 8; g_ws2_min_blocks = 257; g_reg_epilogue = 1; g_ws64_max_blocks = 160; g_prefetch = 1; g_conv_reg = 3; g_conv_stream = 1;
-  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160; g_split_kernel = 2; g_split_flex = 2; g_split_flex_min_nk = 16; g_split_flex_force = 0; g_split_persist = 0; g_split_persist_min_tiles = 384; g_split_flex_small_max = 128; g_split_sx = 2;
+  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160; g_split_kernel = 2; g_split_flex = 2; g_split_flex_min_nk = 16; g_split_flex_force = 0; g_split_persist = 0; g_split_persist_min_tiles = 384; g_split_flex_small_max = 128; g_split_sx = 3;
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t s) {

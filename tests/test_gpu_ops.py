@@ -298,6 +298,8 @@ SPLIT_CONV_CASES = [
     (1, 81, 80, 64, 256, 1, 1, 0, "silu", 2, 0),        # streaming split kernel (>= 6400 pixels per image): ragged last 32-pixel tile, post residual
     (2, 80, 80, 128, 512, 1, 1, 0, "relu", 1, 0),       # stage-1 c3: K = 128, two 256-channel blocks in gridDim.y
     (1, 100, 70, 64, 512, 1, 1, 0, "none", 0, 0),       # no residual, linear
+    (1, 80, 80, 256, 1024, 1, 1, 0, "none", 0, 0),      # streaming kernel with K = 256 (one pixel-tile buffer), four channel blocks, BF16X2 out
+    (1, 90, 75, 256, 1280, 1, 1, 0, "silu", 0, 1),      # ... fp32 rows out, ragged last tile
     (2, 160, 160, 64, 64, 3, 1, 1, "relu", 0, 0),       # stage-0 c2: the direct 64-channel kernel (>= 128 8 x 16 tiles per image)
     (1, 130, 125, 64, 64, 3, 1, 1, "silu", 0, 0),       # ... ragged tiles both ways
 ]
