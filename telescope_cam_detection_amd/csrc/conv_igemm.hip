@@ -3894,7 +3894,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
   });
 }
 
-static int g_split_sx = 3;   // rtd_debug_option "split_sx": 0 = off, 1 = only K = 64 (+ 64) -> 256 (stage 0), 2 = also K = 128 -> N % 256 == 0 (stage 1), 3 = also K = 256 (fp32 or BF16X2 out)
+static int g_split_sx = 3;   // rtd_debug_option "split_sx": 0 = off, 1 = only K = 64 (+ 64) -> 256 (stage 0), 2 = also K = 128 -> N % 256 == 0 (stage 1), 3 = also K = 256 -> N >= 1024 without
+                             // a residual (value projection), 4 = also with a residual from 40^2 maps on (stage-2 expand convs: 51.5 vs 39.5 us on the tiled kernel - off)
 void conv_set_split_sx(int v) { g_split_sx = v; }
 // shapes the streaming split kernel takes; per-IMAGE extents only (see the kernel comment)
 static bool sx_shape_ok(const ConvArgs& a) {
@@ -3903,10 +3904,12 @@ static bool sx_shape_ok(const ConvArgs& a) {
   const bool dual = a.x2.p != nullptr;
   if (!g_split_sx || x.dt != BF16X2 || !(y.dt == BF16X2 || y.dt == F32) || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.x_up2) return false;
   if (a.res_mode != RES_NONE && (a.res.dt != BF16X2 || dual)) return false;
-  if (y.c % 256 || (long long)y.h * y.w < 6400) return false;
-  // K = 256 (value projection 256 -> 1536 fp32): plain conv, either output type
+  if (y.c % 256) return false;
+  // K = 256 (value projection 256 -> 1536 fp32; split_sx 4: stage-2 expand convs 256 -> 1024 + residual at 40^2): either output type
   // (N >= 1024 only: with one or two channel blocks per pixel tile the tiled kernel is faster - decoder input projection 36 vs 46 us)
-  if (x.c == 256) return g_split_sx >= 3 && y.c >= 1024 && !dual && a.res_mode == RES_NONE && a.next_y.p == nullptr;
+  if (x.c == 256) return g_split_sx >= 3 && y.c >= 1024 && !dual && a.next_y.p == nullptr && (a.res_mode == RES_NONE || (g_split_sx >= 4 && y.dt == BF16X2)) &&
+                         (long long)y.h * y.w >= (g_split_sx >= 4 ? 1600 : 6400);
+  if ((long long)y.h * y.w < 6400) return false;
   if (y.dt != BF16X2) return false;
   if (dual) return x.c == 64 && a.x2.c == 64 && y.c == 256;
   if (x.c == 64) return true;
@@ -3936,6 +3939,7 @@ static bool dispatch_sx(const ConvK& k, const ConvArgs& a, long long x_bytes, lo
   else if (a.x.c == 64 && res) { if (nx == 64) RTD_SX(2, 0, true, 64); else if (nx == 128) RTD_SX(2, 0, true, 128); else RTD_SX(2, 0, true, 0); }
   else if (a.x.c == 64) { if (nx == 64) RTD_SX(2, 0, false, 64); else if (nx == 128) RTD_SX(2, 0, false, 128); else RTD_SX(2, 0, false, 0); }
   else if (a.x.c == 256 && y.dt == F32) hipLaunchKernelGGL((conv1x1_sx_kernel<8, 0, false, 0, true>), grid, blk, 0, s, k, (unsigned)x_bytes, 0u, (unsigned)y_bytes, 0u, (int)ntiles, 0u);
+  else if (a.x.c == 256 && res) RTD_SX(8, 0, true, 0);
   else if (a.x.c == 256) RTD_SX(8, 0, false, 0);
   else if (res) RTD_SX(4, 0, true, 0);
   else RTD_SX(4, 0, false, 0);
