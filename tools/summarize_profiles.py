@@ -36,6 +36,8 @@ def family(name: str) -> str:
         return "conv3x3_direct"
     if "stem0_u8" in name:
         return "conv_stem0_u8"
+    if "conv1x1_sx" in name or "conv1x1_stream" in name:
+        return "conv1x1_streaming"
     if "conv_igemm_ws" in name or "conv_igemm_glds" in name:
         return "conv_igemm_lds_dma"
     if "conv_igemm" in name:
