@@ -228,6 +228,41 @@ def test_full_size_properties_bf16_bs8():
     eng.close()
 
 
+def test_full_size_properties_bf16x3_bs8():
+    """The default engine at the benchmark configuration (R50 640 bs8, hipGraph): replay determinism, frame-order equivariance (bit-exact:
+    frames are independent units and every kernel choice depends on per-image extents or on the grid as a whole, never on a frame's
+    slot), sorted scores, label range, and batch invariance: a frame of the bs-8 call equals the bs-1 call of the same handle bit for bit
+    (the bs-1 plan picks other tile shapes on the small grids; every kernel keeps an output's K order)."""
+    from telescope_cam_detection_amd.synth import noise_frame, scene_frame
+    from telescope_cam_detection_amd.arch import ARCHS
+    arch = ARCHS["r50"]
+    w = weights_for(arch, 0)
+    frames = [scene_frame(50 + i, 640, 640) if i % 2 else noise_frame(50 + i, 640, 640) for i in range(8)]
+    eng = make_engine(arch, w, frames, (640, 640), "bf16x3", use_graph=True)
+    a = eng.infer_raw(frames)
+    b = eng.infer_raw(frames)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    labels, boxes, scores = a
+    assert labels.min() >= 0 and labels.max() < 80 and np.isfinite(boxes).all()
+    assert (np.diff(scores, axis=1) <= 0).all() and (scores >= 0).all() and (scores <= 1).all()
+    perm = [3, 0, 7, 1, 6, 2, 5, 4]
+    pl, pb, ps = eng.infer_raw([frames[i] for i in perm])
+    for j, i in enumerate(perm):
+        np.testing.assert_array_equal(labels[i], pl[j])
+        np.testing.assert_array_equal(boxes[i], pb[j])
+        np.testing.assert_array_equal(scores[i], ps[j])
+    worst = 0.0
+    for i in (2, 5):
+        sl, sb, ss = eng.infer_raw([frames[i]])
+        m, n, ws, wb, un = match_detections(labels[i], boxes[i], scores[i], sl[0], sb[0], ss[0], 1e-3, 1e-2, return_unmatched=True)
+        exact = np.array_equal(labels[i], sl[0]) and np.array_equal(boxes[i], sb[0]) and np.array_equal(scores[i], ss[0])
+        print(f"bs8[{i}] vs bs1 (bf16x3): matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px bit-exact={exact}")
+        assert exact, (i, m, n, ws, wb)       # measured: bit-exact - the small-grid tile shapes of the bs-1 plan keep every output's K order
+        worst = max(worst, wb)
+    eng.close()
+
+
 def test_patch_maxpool_equals_per_output_maxpool():
     """the bf16 2x2-patch max-pool kernel against the one-output-per-thread kernel: max is exact, the stem must match bitwise"""
     from telescope_cam_detection_amd import _capi
@@ -269,6 +304,31 @@ def test_fused_reduce_conv_matches_separate_launch():
     rel = np.linalg.norm(outs[0] - outs[1]) / np.linalg.norm(outs[0])
     print(f"fused reduce conv: rel l2 {rel:.2e} max {err:.2e}")
     assert rel < 3e-3 and err < 3e-2
+
+
+def test_bf16x3_fused_reduce_convs_match_separate_launches():
+    """bf16x3: the streaming expand convs of stage 0 carry the next block's reduce conv (also s0's last block -> stage 1's first c1):
+    three launches fewer, stage outputs equal to the unfused plan to the engine's rounding (only that GEMM's accumulation order differs)."""
+    from telescope_cam_detection_amd import _capi
+    from telescope_cam_detection_amd.synth import noise_frame, scene_frame
+    from telescope_cam_detection_amd.arch import ARCHS
+    arch = ARCHS["r50"]
+    w = weights_for(arch, 0)
+    frames = [scene_frame(90, 640, 640), noise_frame(91, 640, 640)]
+    outs, launches = [], []
+    for v in (0, 1):
+        _capi.debug_option("c1_fuse", v)
+        e = make_engine(arch, w, frames, (640, 640), "bf16x3")
+        e.infer_raw(frames)
+        outs.append([e.debug_tensor(f"backbone{i}").astype(np.float64).copy() for i in range(3)])
+        launches.append(len(e.profile(2, 1)))
+        e.close()
+    _capi.debug_option("c1_fuse", 1)
+    assert launches[1] == launches[0] - 3
+    for a, b in zip(*outs):
+        rel = np.linalg.norm(a - b) / np.linalg.norm(a)
+        print(f"bf16x3 fused reduce convs: rel l2 {rel:.2e}")
+        assert rel < 2e-5
 
 
 def test_split_bf16_self_attention_matches_fp32_mfma_attention():
