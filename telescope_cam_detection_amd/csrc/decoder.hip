@@ -153,6 +153,9 @@ __device__ void row_gemm_split(const bf16* Ah, const bf16* Al, int lda, const De
     const char* w0 = (const char*)L.w + (((size_t)t * kc * 2048) & wmask) + lane * 16;
     const char* w1 = (const char*)L.w + (((size_t)(has2 ? t + NW : t) * kc * 2048) & wmask) + lane * 16;
     f32x4_ acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // the pass's two bias values are requested with its first filter fragments (read in the epilogue they cost an exposed L2 round trip per pass)
+    const float bias0 = (n0 + r16 < L.N) ? L.b[n0 + r16] : 0.f, bias1 = (n1 + r16 < L.N) ? L.b[n1 + r16] : 0.f;
+    asm volatile("" ::: "memory");                              // (keeps the two loads up here: hipcc sinks a load to its use otherwise)
     // PF register sets, each one 64-deep K step of both tiles (8 x 16-byte loads per lane); a set is reloaded with the step PF
     // ahead right after its MFMAs were issued, so 8 PF loads per wave stay in flight (the loop is L2-latency bound: one step in
     // flight per wave was 0.9 us per step; rtd_debug_option "dec_pf" picks 2 or 3).
@@ -205,7 +208,7 @@ __device__ void row_gemm_split(const bf16* Ah, const bf16* Al, int lda, const De
       if (h == 1 && !has2) break;
       const int col = (h == 0 ? n0 : n1) + r16;
       if (col < L.N) {
-        const float bv = L.b[col];
+        const float bv = h == 0 ? bias0 : bias1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = q * 4 + r;
