@@ -1468,17 +1468,26 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_ker
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x), 0, a.x2 ? g.x2_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
-    int k0 = 0, kh = 0, kw = 0, c0 = 0;
-    auto issue = [&](int buf) {
+    // K order: channel group outer, taps inner (the filter keeps its tap-major layout, only the walk changes).  With taps outer a pixel's 128-byte
+    // group slice is re-read by the nine taps eight K-steps apart - 8 MB of other slices per XCD in between, more than its L2 holds: the 3x3 layers
+    // at 80^2 fetched their input 4-6 times from beyond L2.  Every BF16X2 tile kernel walks K the same way (one summation order per output).
+    // (one walk only: offered both at run time, hipcc merges the two mirror-image counters by selecting a POINTER to kh / kw / c0 and
+    // keeps them in scratch memory - the loaders then run a scratch round trip per K-step and every layer is 40-60 % slower)
+    const int nk_main = a.x2 ? a.k2_start / BK : nk;
+    int ksi = 0, kh = 0, kw = 0, c0 = 0;
+    auto issue = [&](int buf) __attribute__((always_inline)) {      // (called twice: left to the inliner's budget, its captures live in scratch)
       if (g.probe & 4) return;
       char* sa = smem + buf * STAGE + w4 * 1024;
-      if (a.x2 && k0 >= a.k2_start) {
-        const int d2 = (k0 - a.k2_start) * 2;
+      int kf;                                                   // filter column of this K-step (bf16 elements)
+      if (ksi >= nk_main) {
+        const int d2 = (ksi - nk_main) * BK * 2;
+        kf = a.k2_start + (ksi - nk_main) * BK;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, (lds_ptr_t)(sa + i * 4096), 16, (unsigned)a2_off[i] + (a2_off[i] < 0 ? 0u : (unsigned)d2), 0, 0, 0);
       } else {
         const int delta = ((kh * a.W + kw) * (int)a.ldx + c0) * 2;
+        kf = (kh * a.KW + kw) * a.Cin + c0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
@@ -1489,12 +1498,11 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_ker
       }
 #pragma unroll
       for (int i = 0; i < NBI; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sa + BM * 128 + i * 4096), 16, (unsigned)(b_off[i] + k0 * 2), 0, 0, 0);
-      k0 += BK;
-      c0 += BK;
-      if (c0 >= a.Cin) {
-        c0 = 0;
-        if (++kw == a.KW) { kw = 0; ++kh; }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sa + BM * 128 + i * 4096), 16, (unsigned)(b_off[i] + kf * 2), 0, 0, 0);
+      ++ksi;
+      if (++kw == a.KW) {
+        kw = 0;
+        if (++kh == a.KH) { kh = 0; c0 += BK; }
       }
     };
     for (int t = 0; t < AHEAD && t < nk; ++t) issue(t);
@@ -1688,17 +1696,26 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsf_ker
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x), 0, a.x2 ? g.x2_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
-    int k0 = 0, kh = 0, kw = 0, c0 = 0;
-    auto issue = [&](int buf) {
+    // K order: channel group outer, taps inner (the filter keeps its tap-major layout, only the walk changes).  With taps outer a pixel's 128-byte
+    // group slice is re-read by the nine taps eight K-steps apart - 8 MB of other slices per XCD in between, more than its L2 holds: the 3x3 layers
+    // at 80^2 fetched their input 4-6 times from beyond L2.  Every BF16X2 tile kernel walks K the same way (one summation order per output).
+    // (one walk only: offered both at run time, hipcc merges the two mirror-image counters by selecting a POINTER to kh / kw / c0 and
+    // keeps them in scratch memory - the loaders then run a scratch round trip per K-step and every layer is 40-60 % slower)
+    const int nk_main = a.x2 ? a.k2_start / BK : nk;
+    int ksi = 0, kh = 0, kw = 0, c0 = 0;
+    auto issue = [&](int buf) __attribute__((always_inline)) {      // (called twice: left to the inliner's budget, its captures live in scratch)
       if (g.probe & 4) return;
       char* sa = smem + buf * STAGE + w4 * 1024;
-      if (a.x2 && k0 >= a.k2_start) {
-        const int d2 = (k0 - a.k2_start) * 2;
+      int kf;                                                   // filter column of this K-step (bf16 elements)
+      if (ksi >= nk_main) {
+        const int d2 = (ksi - nk_main) * BK * 2;
+        kf = a.k2_start + (ksi - nk_main) * BK;
 #pragma unroll
         for (int i = 0; i < NAI; ++i)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, (lds_ptr_t)(sa + i * 4096), 16, a2_off[i] + ((a2_off[i] >> 31) ? 0u : (unsigned)d2), 0, 0, 0);
       } else {
         const int delta = ((kh * a.W + kw) * (int)a.ldx + c0) * 2;
+        kf = (kh * a.KW + kw) * a.Cin + c0;
 #pragma unroll
         for (int i = 0; i < NAI; ++i) {
           const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
@@ -1709,12 +1726,11 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsf_ker
       }
 #pragma unroll
       for (int i = 0; i < NBI; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sa + AROWS * 128 + i * 4096), 16, (unsigned)(b_off[i] + k0 * 2), 0, 0, 0);
-      k0 += BK;
-      c0 += BK;
-      if (c0 >= a.Cin) {
-        c0 = 0;
-        if (++kw == a.KW) { kw = 0; ++kh; }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sa + AROWS * 128 + i * 4096), 16, (unsigned)(b_off[i] + kf * 2), 0, 0, 0);
+      ++ksi;
+      if (++kw == a.KW) {
+        kw = 0;
+        if (++kh == a.KH) { kh = 0; c0 += BK; }
       }
     };
     for (int t = 0; t < AHEAD && t < nk; ++t) issue(t);
@@ -3669,7 +3685,7 @@ void conv_set_split_ws64_max_blocks(int v) { g_split_ws64_max_blocks = v; }
 // block for ONE or two K-steps.  Same scheme as conv1x1_stream_kernel (no LDS tile, no role split), on hi/lo pairs:
 //   * a WAVE owns one 32-channel group of the output ( = one [32 hi | 32 lo] 128-byte run per pixel) and keeps that group's
 //     filter, hi and lo, in registers (4 x K/16 fragments); the block's 8 waves cover 256 channels of a 32-pixel tile, wider
-//     layers put 256-channel blocks in gridDim.y; persistent grid, tiles block-cyclic;
+//     layers run several 256-channel blocks per tile on one XCD; persistent grid, tiles cyclic per tile stream;
 //   * pixel fragments come straight from global memory in MFMA B-operand shape (lane = pixel, 16 bytes of K; the 8 waves' copies
 //     hit in L1); three v_mfma_f32_32x32x16_bf16 per 16-deep chunk (w_hi x_lo, w_lo x_hi, w_hi x_hi);
 //   * filter rows are permuted at load time (MFMA row 8b+4h+r <- channel 16h+4b+r): a lane's 16 accumulators are 16 CONSECUTIVE
@@ -3684,7 +3700,7 @@ void conv_set_split_ws64_max_blocks(int v) { g_split_ws64_max_blocks = v; }
 // ------------------------------------------------------------------------------------------------
 template <int NGX, int NG2, bool RES, int NEXTN, bool F32OUT = false>   // NGX / NG2: 32-channel K groups read from x / from ConvK::x2; F32OUT: fp32 rows out
 __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsigned x_bytes, unsigned r_bytes, unsigned y_bytes, unsigned x2_bytes, int ntiles,
-                                                            unsigned yn_bytes) {
+                                                            unsigned yn_bytes, int ny) {
   constexpr int NKX = 2 * NGX, NK2 = 2 * NG2, NKK = NKX + NK2;   // 16-deep MFMA chunks
   constexpr int NG_ = NGX + NG2;
   constexpr int SROW = 144;
@@ -3699,8 +3715,13 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, pl = lane & 31;
-  const int cb = (blockIdx.y * 8 + wv) * 32;                     // this wave's output channel group
-  if (tid < 256) sbias[tid] = a.bias[blockIdx.y * 256 + tid];
+  // 1-D grid: block -> (XCD = id & 7, slot = id >> 3) -> (tile stream = slot / ny, 256-channel block cy = slot % ny).  The ny channel blocks of a
+  // tile stream sit on ONE XCD and walk the same tiles at the same time, so a pixel tile comes from HBM once and from that XCD's L2 ny - 1
+  // times (with the channel blocks in the grid's y dimension the value projection fetched every tile six times: 426 MB instead of 69 - HBM-bound)
+  const int bid = blockIdx.x, slot = bid >> 3;
+  const int cy = slot % ny, t0 = (slot / ny) * 8 + (bid & 7), tstride = ((int)gridDim.x >> 3) / ny * 8;
+  const int cb = (cy * 8 + wv) * 32;                             // this wave's output channel group
+  if (tid < 256) sbias[tid] = a.bias[cy * 256 + tid];
 
   bf16x8 wfh[NKK], wfl[NKK];
   {
@@ -3724,7 +3745,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
     b1v = *(const f32x4*)(a.next_bias + 16 * slice + 4 * (lane >> 4));
   }
   __syncthreads();
-  prefetch_share(a, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, tid, 512, pf_dummy);
+  prefetch_share(a, bid, gridDim.x, tid, 512, pf_dummy);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(NG2 ? a.x2 : a.x), 0, NG2 ? x2_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res : a.x), 0, RES ? r_bytes : 0u, 0x00020000);
@@ -3778,9 +3799,9 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
     constexpr int ACT = decltype(actc)::value;
     u32x4_ gx[4], g2[1], rvn[4];
     unsigned yrown[4];
-    int t = blockIdx.x;
+    int t = t0;
     if (t < ntiles) issue(t, gx, g2, rvn, yrown);
-    for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
+    for (int it = 0; t < ntiles; t += tstride, ++it) {
       char* xb = xs[XBUFS == 2 ? (it & 1) : 0];
       if (XBUFS == 1) __syncthreads();                           // every wave has read the previous tile
 #pragma unroll
@@ -3797,7 +3818,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
 #pragma unroll
       for (int j = 0; j < 4; ++j) { rv[j] = rvn[j]; yrow[j] = yrown[j]; }
       __syncthreads();                                           // the tile is in xs[it & 1]; every wave has left tile it - 1 (whose buffer the NEXT write takes)
-      if (t + (int)gridDim.x < ntiles) issue(t + gridDim.x, gx, g2, rvn, yrown);
+      if (t + tstride < ntiles) issue(t + tstride, gx, g2, rvn, yrown);
       const char* xf = xb + pl * XROW + 16 * h;
       f32x16 acc;
 #pragma unroll
@@ -3931,14 +3952,16 @@ static bool dispatch_sx(const ConvK& k, const ConvArgs& a, long long x_bytes, lo
   const long long ntiles = ((long long)k.M + 31) / 32;
   if (ntiles >= (1ll << 30)) return false;
   const int ny = y.c / 256;
-  const dim3 grid((unsigned)std::min<long long>(ntiles, std::max(1, 512 / ny)), ny), blk(512);     // persistent: two 8-wave blocks per CU
+  // persistent, two 8-wave blocks per CU: 8 XCDs x nts tile streams x ny channel blocks
+  const int nts = (int)std::max<long long>(1, std::min<long long>(64 / ny, (ntiles + 7) / 8));
+  const dim3 grid((unsigned)(8 * nts * ny)), blk(512);
 #define RTD_SX(NGX, NG2, RES_, NX) hipLaunchKernelGGL((conv1x1_sx_kernel<NGX, NG2, RES_, NX>), grid, blk, 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, \
-                                                     (unsigned)y_bytes, (unsigned)x2_bytes, (int)ntiles, (unsigned)yn_bytes)
+                                                     (unsigned)y_bytes, (unsigned)x2_bytes, (int)ntiles, (unsigned)yn_bytes, ny)
   const int nx = next ? a.next_y.c : 0;
   if (dual) { if (nx == 64) RTD_SX(2, 2, false, 64); else if (nx == 128) RTD_SX(2, 2, false, 128); else RTD_SX(2, 2, false, 0); }
   else if (a.x.c == 64 && res) { if (nx == 64) RTD_SX(2, 0, true, 64); else if (nx == 128) RTD_SX(2, 0, true, 128); else RTD_SX(2, 0, true, 0); }
   else if (a.x.c == 64) { if (nx == 64) RTD_SX(2, 0, false, 64); else if (nx == 128) RTD_SX(2, 0, false, 128); else RTD_SX(2, 0, false, 0); }
-  else if (a.x.c == 256 && y.dt == F32) hipLaunchKernelGGL((conv1x1_sx_kernel<8, 0, false, 0, true>), grid, blk, 0, s, k, (unsigned)x_bytes, 0u, (unsigned)y_bytes, 0u, (int)ntiles, 0u);
+  else if (a.x.c == 256 && y.dt == F32) hipLaunchKernelGGL((conv1x1_sx_kernel<8, 0, false, 0, true>), grid, blk, 0, s, k, (unsigned)x_bytes, 0u, (unsigned)y_bytes, 0u, (int)ntiles, 0u, ny);
   else if (a.x.c == 256 && res) RTD_SX(8, 0, true, 0);
   else if (a.x.c == 256) RTD_SX(8, 0, false, 0);
   else if (res) RTD_SX(4, 0, true, 0);
