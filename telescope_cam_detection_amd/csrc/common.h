@@ -122,6 +122,7 @@ void conv_set_split_flex_force(int v);
 void conv_set_split_flex_small_max(int v);
 void conv_set_split_persist(int v);
 void conv_set_split_sx(int v);
+void conv_set_split_k2(int v);
 void conv_set_split_persist_min_tiles(int v);
 int conv_npad(int N);
 void conv_set_force_v1(int v);      // A/B hook: 1 = never take the large-tile (v2) path

@@ -56,6 +56,7 @@ struct ConvK {
   // ldx2, x2_bstride count bf16 ELEMENTS (twice the channels); y_split / res_split = the output / residual is a BF16X2 tensor, its
   // ldy / y_bstride (ldr / r_bstride) count channels as for fp32 and addresses go through split_off()
   int split = 0, y_split = 0, res_split = 0;
+  int raw = 0;           // two-pass split-K: the tile kernels write bare fp32 partial sums (no bias) to slice `s` of ConvG::slab
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -858,12 +859,13 @@ __device__ __forceinline__ void ws_copy_out_split_rows(const ConvK& a, const bf1
 // Copy-out of the split kernels' fp32 staging tile: bias (+ residual: BF16X2 or fp32) -> activation -> BF16X2 or fp32 output, 8 channels
 // per thread and iteration.  ldy / ldr count channels for either type (ConvK::y_split).
 template <int ITERS, int ACT, int BN, int ROWS = 128>
-__device__ __forceinline__ void ws_copy_out_sp(const ConvK& a, const float* st, int SLD, int tid, int m0, int n0) {
+__device__ __forceinline__ void ws_copy_out_sp(const ConvK& a, const float* st, int SLD, int tid, int m0, int n0, long long yoff = 0) {
   constexpr int CH8 = BN / 8, RSTEP = 512 / CH8;
   const int c8 = tid % CH8;
   const int c = n0 + c8 * 8;
   if (c >= a.N) return;
-  const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
+  f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
+  if (a.raw) { b0 = f32x4{0.f, 0.f, 0.f, 0.f}; b1 = b0; }     // split-K partial sums: the reduce pass adds the bias
   int m = m0 + tid / CH8;
   const int b = m / a.OHW;
   int p = m - b * a.OHW;
@@ -901,8 +903,8 @@ __device__ __forceinline__ void ws_copy_out_sp(const ConvK& a, const float* st, 
         split_store8((bf16*)a.y, ypix, c, v);
       } else {
         f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-        *(f32x4*)((float*)a.y + ypix + c) = o0;
-        *(f32x4*)((float*)a.y + ypix + c + 4) = o1;
+        *(f32x4*)((float*)a.y + yoff + ypix + c) = o0;
+        *(f32x4*)((float*)a.y + yoff + ypix + c + 4) = o1;
       }
     }
     m += RSTEP;
@@ -1417,9 +1419,14 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_ker
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
+  // two-pass split-K (g.splitk = S > 1): the grid is S x tiles, slice-major; slice sl multiplies the channel groups [sl, sl + 1) Cin / S of every
+  // tap and writes bare partial sums to its slab slice (ConvK::raw, set up by the host); k_splitk_reduce finishes the layer
+  int sl = 0;
+  if (g.splitk > 1) { const int tiles = (int)gridDim.x / g.splitk; sl = wg / tiles; wg -= sl * tiles; }
+  const long long yoff = (long long)sl * a.M * a.N;
   const int nt = wg % a.ntn, mt = wg / a.ntn;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int nk = a.Kpad / BK;
+  const int nk = a.Kpad / BK / g.splitk;
 
   // accumulators: 32x32 tiles [channel tile][pixel tile] x 16, or 16x16 tiles [4 channel tiles][2 TJ pixel tiles] x 4 - 32 TJ floats per lane either way
   f32x16 acc[M16 ? 1 : 2][M16 ? 1 : TJ];
@@ -1474,7 +1481,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_ker
     // (one walk only: offered both at run time, hipcc merges the two mirror-image counters by selecting a POINTER to kh / kw / c0 and
     // keeps them in scratch memory - the loaders then run a scratch round trip per K-step and every layer is 40-60 % slower)
     const int nk_main = a.x2 ? a.k2_start / BK : nk;
-    int ksi = 0, kh = 0, kw = 0, c0 = 0;
+    int ksi = 0, kh = 0, kw = 0, c0 = sl * (a.Cin / g.splitk);
     auto issue = [&](int buf) __attribute__((always_inline)) {      // (called twice: left to the inliner's budget, its captures live in scratch)
       if (g.probe & 4) return;
       char* sa = smem + buf * STAGE + w4 * 1024;
@@ -1610,7 +1617,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_ker
   float* st = (float*)smem;
   if (!loader) for_each_group([&](int cl, int pl, const f32x4& v) { *(f32x4*)(&st[pl * SLD + cl]) = v; });
   __syncthreads();
-  dispatch_act(a.act, [&](auto actc) { ws_copy_out_sp<CITERS, decltype(actc)::value, BN>(a, st, SLD, tid, m0, n0); });
+  dispatch_act(a.act, [&](auto actc) { ws_copy_out_sp<CITERS, decltype(actc)::value, BN>(a, st, SLD, tid, m0, n0, yoff); });
 }
 
 
@@ -1653,9 +1660,14 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsf_ker
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
+  // two-pass split-K (g.splitk = S > 1): the grid is S x tiles, slice-major; slice sl multiplies the channel groups [sl, sl + 1) Cin / S of every
+  // tap and writes bare partial sums to its slab slice (ConvK::raw, set up by the host); k_splitk_reduce finishes the layer
+  int sl = 0;
+  if (g.splitk > 1) { const int tiles = (int)gridDim.x / g.splitk; sl = wg / tiles; wg -= sl * tiles; }
+  const long long yoff = (long long)sl * a.M * a.N;
   const int nt = wg % a.ntn, mt = wg / a.ntn;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int nk = a.Kpad / BK;
+  const int nk = a.Kpad / BK / g.splitk;
 
   f32x4 acc[CT][MT];
 #pragma unroll
@@ -1702,7 +1714,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsf_ker
     // (one walk only: offered both at run time, hipcc merges the two mirror-image counters by selecting a POINTER to kh / kw / c0 and
     // keeps them in scratch memory - the loaders then run a scratch round trip per K-step and every layer is 40-60 % slower)
     const int nk_main = a.x2 ? a.k2_start / BK : nk;
-    int ksi = 0, kh = 0, kw = 0, c0 = 0;
+    int ksi = 0, kh = 0, kw = 0, c0 = sl * (a.Cin / g.splitk);
     auto issue = [&](int buf) __attribute__((always_inline)) {      // (called twice: left to the inliner's budget, its captures live in scratch)
       if (g.probe & 4) return;
       char* sa = smem + buf * STAGE + w4 * 1024;
@@ -1803,7 +1815,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsf_ker
   float* st = (float*)smem;
   if (!loader) for_each_group([&](int cl, int pl, const f32x4& v) { *(f32x4*)(&st[pl * SLD + cl]) = v; });
   __syncthreads();
-  dispatch_act(a.act, [&](auto actc) { ws_copy_out_sp<CITERS, decltype(actc)::value, BN, BM>(a, st, SLD, tid, m0, n0); });
+  dispatch_act(a.act, [&](auto actc) { ws_copy_out_sp<CITERS, decltype(actc)::value, BN, BM>(a, st, SLD, tid, m0, n0, yoff); });
 }
 
 
@@ -3970,6 +3982,52 @@ static bool dispatch_sx(const ConvK& k, const ConvArgs& a, long long x_bytes, lo
   return true;
 }
 
+
+// Second pass of the two-pass split-K: y = act(sum_s slab[s] + bias (+ res)), slices in fixed order (one summation order per output whatever the
+// batch size), written in the layer's own output format.  One thread = 8 channels of a pixel.
+__global__ __launch_bounds__(256) void k_splitk_reduce(const ConvK a, const float* __restrict__ slab, int S) {
+  const int n8 = a.N >> 3;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)a.M * n8) return;
+  const int m = (int)(idx / n8), c = (int)(idx - (long long)m * n8) << 3;
+  const long long MN = (long long)a.M * a.N;
+  const float* q = slab + (long long)m * a.N + c;
+  f32x4 s0 = *(const f32x4*)q, s1 = *(const f32x4*)(q + 4);
+  for (int s = 1; s < S; ++s) {
+    const f32x4 t0 = *(const f32x4*)(q + s * MN), t1 = *(const f32x4*)(q + s * MN + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s0[e] += t0[e]; s1[e] += t1[e]; }
+  }
+  const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
+  float v[8] = {s0[0] + b0[0], s0[1] + b0[1], s0[2] + b0[2], s0[3] + b0[3], s1[0] + b1[0], s1[1] + b1[1], s1[2] + b1[2], s1[3] + b1[3]};
+  const int b = m / a.OHW, p = m - b * a.OHW;
+  const long long ypix = (long long)b * a.y_bstride + (long long)p * a.ldy;
+  float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (a.res_mode != RES_NONE) {
+    const long long rpix = (long long)b * a.r_bstride + (long long)p * a.ldr;
+    if (a.res_split) split_load8((const bf16*)a.res, rpix, c, rv);
+    else {
+      const f32x4 t0 = *(const f32x4*)((const float*)a.res + rpix + c), t1 = *(const f32x4*)((const float*)a.res + rpix + c + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { rv[e] = t0[e]; rv[4 + e] = t1[e]; }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (a.res_mode == RES_PRE) v[e] += rv[e];
+    v[e] = act_fn(v[e], a.act);
+    if (a.res_mode == RES_POST) v[e] += rv[e];
+  }
+  if (a.y_split) split_store8((bf16*)a.y, ypix, c, v);
+  else {
+    *(f32x4*)((float*)a.y + ypix + c) = f32x4{v[0], v[1], v[2], v[3]};
+    *(f32x4*)((float*)a.y + ypix + c + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  }
+}
+// rtd_debug_option "split_k2": two-pass split-K on long-K layers whose per-IMAGE tile count is small (stage 3, the 20^2 PAN level, enc.proj.2 at 640 px;
+// most layers at smaller inputs).  The slice count depends on per-image extents and K only: every batch size runs the same arithmetic.
+static int g_split_k2 = 1;
+void conv_set_split_k2(int v) { g_split_k2 = v; }
 bool conv_split_supported(const ConvArgs& a) {
   const Tensor& x = a.x;
   const Tensor& y = a.y;
@@ -4064,9 +4122,33 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
       return;
     }
   }
+  // ---- two-pass split-K: S slices of the channel groups, bare fp32 partial sums into the workspace slab, k_splitk_reduce finishes
+  int S = 1;
+  if (g_split_k2 && g_split_kernel == 2 && !dual && !a.x_up2 && a.ws.slab && k.N % 8 == 0) {
+    const long long tiles_img = (((long long)OH * OW + 127) / 128) * ((k.N + 127) / 128);
+    const int groups = x.c / SPLIT_GROUP, nk_total = a.KH * a.KW * groups;
+    // measured on R50 640^2 (stage-3 3x3, K = 4608: 144 K-steps): batch 1 54 -> 35 us per layer (16 blocks -> 32), batch 8 57 -> 62 us; shorter K
+    // loops (stage-3 1x1, the 20^2 PAN level) lose at batch 8 and gain nothing at batch 1, hence the 128-step floor
+    if (nk_total >= 128 && tiles_img <= 8 && groups % 4 == 0) S = 4;
+    else if (nk_total >= 128 && tiles_img <= 16 && groups % 2 == 0) S = 2;
+    if ((size_t)S * (size_t)k.M * (size_t)k.N * 4 > a.ws.slab_bytes) S = 1;
+  }
+  const ConvK korig = k;
+  if (S > 1) {
+    k.raw = 1; k.act = ACT_NONE; k.res_mode = RES_NONE; k.res = nullptr; k.y = a.ws.slab; k.y_f32 = 1; k.y_split = 0; k.res_split = 0;
+    k.ldy = k.N; k.y_bstride = (long long)k.OHW * k.N; g.splitk = S;
+  }
+  auto finish = [&]() {
+    HIP_CHECK(hipGetLastError());
+    if (S > 1) {
+      const long long items = (long long)korig.M * (korig.N >> 3);
+      hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, korig, (const float*)a.ws.slab, S);
+      HIP_CHECK(hipGetLastError());
+    }
+  };
   const long long mt = (k.M + 127) / 128, ntn = (k.N + 127) / 128, ntn64 = (k.N + 63) / 64;
   // ---- persistent three-role kernel (conv_igemm_wsp_kernel): grids with several tiles per CU
-  if (g_split_persist && g_split_kernel == 2 && k.N >= 128 && k.Kpad / 64 >= 2 && (k.Kpad / 64 >= 8 || k.res_mode == RES_NONE || g_split_persist == 2)) {
+  if (S == 1 && g_split_persist && g_split_kernel == 2 && k.N >= 128 && k.Kpad / 64 >= 2 && (k.Kpad / 64 >= 8 || k.res_mode == RES_NONE || g_split_persist == 2)) {
     constexpr int PMT = 7;
     const long long mtl = (k.M + 16 * PMT - 1) / (16 * PMT), ntb = (k.N + 127) / 128;
     const long long tiles = mtl * ntb;
@@ -4080,8 +4162,8 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
   }
   // ---- flexible tile height (conv_igemm_wsf_kernel): MFMA-bound layers (>= 16 K-steps) pick the tile whose grid fills whole rounds of the chip
   // split_flex 2: only grids that leave CUs idle with 128-pixel tiles (20^2 maps at batch 8, most layers at batch 1)
-  if (g_split_flex && g_split_kernel == 2 && k.Kpad / 64 >= g_split_flex_min_nk && k.N >= 64 &&
-      (g_split_flex != 2 || ((k.M + 127) / 128) * ((k.N + 127) / 128) <= g_split_flex_small_max)) {
+  if (g_split_flex && g_split_kernel == 2 && k.Kpad / 64 / S >= g_split_flex_min_nk && k.N >= 64 &&
+      (g_split_flex != 2 || ((k.M + 127) / 128) * ((k.N + 127) / 128) * S <= g_split_flex_small_max)) {
     int best_mt = 0, best_bn = 0, best_st = 0;
     double best = 1e30;
     if (g_split_flex_force) {                      // sweeps (tools/conv_bench.py --opt split_flex_force): mt + 100 * (bn == 64) + 1000 * stages
@@ -4090,7 +4172,7 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
     for (int bn = (k.N > 64 ? 128 : 64); bn >= 64; bn -= 64) {
       const long long ntb = (k.N + bn - 1) / bn;
       for (int mtc = 4; mtc <= 13; ++mtc) {
-        const long long blocks = ((k.M + 16 * mtc - 1) / (16 * mtc)) * ntb;
+        const long long blocks = ((k.M + 16 * mtc - 1) / (16 * mtc)) * ntb * S;
         const long long rounds = (blocks + 255) / 256;
         const bool two = blocks > 256 && mtc <= 8;                 // 2 stages, two blocks per CU share the MFMA pipes; else 3 stages, one block per CU
         double eff = (bn == 128 ? 1.0 : 0.78) * (1.0 - 0.6 / mtc);  // small tiles: more LDS reads and barriers per MFMA
@@ -4100,7 +4182,7 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
       }
     }
     k.ntn = (int)((k.N + best_bn - 1) / best_bn);
-    const long long blocks = ((k.M + 16 * best_mt - 1) / (16 * best_mt)) * k.ntn;
+    const long long blocks = ((k.M + 16 * best_mt - 1) / (16 * best_mt)) * k.ntn * S;
     const dim3 grid((unsigned)blocks), blk(512);
     bool launched = true;
 #define RTD_WSF(ST, BNN, MTT) hipLaunchKernelGGL((conv_igemm_wsf_kernel<ST, BNN, MTT>), grid, blk, 0, s, g)
@@ -4121,13 +4203,13 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
     }
 #undef RTD_WSF_MT
 #undef RTD_WSF
-    if (launched) { HIP_CHECK(hipGetLastError()); return; }
+    if (launched) { finish(); return; }
     k.ntn = 1;
   }
   if (g_split_kernel != 0) {                      // the dedicated split kernel: 1 = 32x32x16 MFMAs, 2 = 16x16x32
     const bool n64 = k.N <= 64 || (mt * ntn < g_split_ws64_max_blocks && ntn64 > ntn);
     k.ntn = (int)(n64 ? ntn64 : ntn);
-    const long long blocks = mt * k.ntn;
+    const long long blocks = mt * k.ntn * S;
     const bool four = blocks < g_split_ws2_min_blocks;
     const dim3 grid((unsigned)blocks), blk(512);
 #define RTD_WSX(ST, BNN) do { if (g_split_kernel == 2) hipLaunchKernelGGL((conv_igemm_wsx_kernel<ST, BNN, true>), grid, blk, 0, s, g); \
@@ -4135,9 +4217,10 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
     if (n64) { if (four) RTD_WSX(4, 64); else RTD_WSX(2, 64); }
     else { if (four) RTD_WSX(4, 128); else RTD_WSX(2, 128); }
 #undef RTD_WSX
-    HIP_CHECK(hipGetLastError());
+    finish();
     return;
   }
+  RTD_CHECK(S == 1, 1, "conv (bf16x3): split-K needs the dedicated split kernels");
   if (k.N <= 64 || (mt * ntn < g_split_ws64_max_blocks && ntn64 > ntn)) {
     k.ntn = (int)ntn64;
     // wide grids (stage-0 c1 / c2 at 160^2: 1600 tiles): 2 stages, two blocks per CU - one block's prologue and copy-out run under the other's
@@ -4155,7 +4238,7 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
 void conv_reset_options() {
   g_glds_min_blocks = 4; g_splitk_enable = 0; g_glds_drop = 0; g_conv_mode = 0; g_force_v1 = 0; g_ws256_min_blocks = 0; g_glds_min_n = 128;
   g_wsa_min_ntn = 8; g_ws2_min_blocks = 257; g_reg_epilogue = 1; g_ws64_max_blocks = 160; g_prefetch = 1; g_conv_reg = 3; g_conv_stream = 1;
-  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160; g_split_kernel = 2; g_split_flex = 2; g_split_flex_min_nk = 16; g_split_flex_force = 0; g_split_persist = 0; g_split_persist_min_tiles = 384; g_split_flex_small_max = 128; g_split_sx = 3;
+  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160; g_split_kernel = 2; g_split_flex = 2; g_split_flex_min_nk = 16; g_split_flex_force = 0; g_split_persist = 0; g_split_persist_min_tiles = 384; g_split_flex_small_max = 128; g_split_sx = 3; g_split_k2 = 1;
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t s) {

@@ -1455,6 +1455,10 @@ void rtd_destroy(rtd_handle h) {
     if (h->resize_tmp) (void)hipFree(h->resize_tmp);
     if (h->u8_stage) (void)hipFree(h->u8_stage);
     if (h->block_host) (void)hipHostFree(h->block_host);
+    // the fork / join events were last recorded inside a stream capture; record them once on the live stream before they go back to the runtime's
+    // pool (seen once in ~6 full test runs: a torch event created later in the process failed with hipErrorCapturedEvent on its first query)
+    if (h->ev_fork && h->stream) { (void)hipEventRecord(h->ev_fork, h->stream); (void)hipEventSynchronize(h->ev_fork); }
+    if (h->ev_join && h->stream) { (void)hipEventRecord(h->ev_join, h->stream); (void)hipEventSynchronize(h->ev_join); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side) (void)hipStreamDestroy(h->side);
@@ -1661,6 +1665,7 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "split_flex_small_max") == 0) { conv_set_split_flex_small_max(value); return RTD_OK; }
   if (strcmp(name, "split_persist") == 0) { conv_set_split_persist(value); return RTD_OK; }
   if (strcmp(name, "split_sx") == 0) { conv_set_split_sx(value); return RTD_OK; }
+  if (strcmp(name, "split_k2") == 0) { conv_set_split_k2(value); return RTD_OK; }
   if (strcmp(name, "split_persist_min_tiles") == 0) { conv_set_split_persist_min_tiles(value); return RTD_OK; }
   if (strcmp(name, "glds_drop") == 0) { conv_set_glds_drop(value); return RTD_OK; }
   if (strcmp(name, "glds_min_blocks") == 0) { conv_set_glds_min_blocks(value); return RTD_OK; }

@@ -288,7 +288,7 @@ SPLIT_CONV_CASES = [
     (2, 160, 160, 64, 256, 1, 1, 0, "relu", 1, 0),      # stage-0 c3
     (1, 8400, 1, 256, 1536, 1, 1, 0, "none", 0, 1),     # value projection: fp32 output
     (1, 400, 1, 2048, 256, 1, 1, 0, "none", 0, 1),      # enc.proj.2: long K, fp32 output, 4-stage kernel
-    (2, 20, 20, 512, 512, 3, 1, 1, "relu", 0, 0),       # stage-3 c2: K = 4608 real channels x taps
+    (2, 20, 20, 512, 512, 3, 1, 1, "relu", 0, 0),       # stage-3 c2: K = 4608 real channels x taps (two-pass split-K, 2 slices, BF16X2 out)
     (1, 70, 50, 256, 64, 1, 1, 0, "gelu", 0, 0),
     (2, 40, 41, 256, 1024, 1, 1, 0, "relu", 1, 1),      # fp32 output with a BF16X2 residual
     (8, 40, 40, 256, 256, 3, 1, 1, "silu", 2, 0),       # 40^2 x 8 maps: flexible tile height (112 px -> 230 blocks), post residual
@@ -300,6 +300,7 @@ SPLIT_CONV_CASES = [
     (1, 100, 70, 64, 512, 1, 1, 0, "none", 0, 0),       # no residual, linear
     (1, 80, 80, 256, 1024, 1, 1, 0, "none", 0, 0),      # streaming kernel with K = 256 (one pixel-tile buffer), four channel blocks, BF16X2 out
     (1, 90, 75, 256, 1280, 1, 1, 0, "silu", 0, 1),      # ... fp32 rows out, ragged last tile
+    (1, 20, 20, 512, 256, 3, 1, 1, "silu", 1, 1),       # 144 K-steps on 8 tiles per image: two-pass split-K in 4 slices, residual + fp32 rows in the reduce pass
     (2, 160, 160, 64, 64, 3, 1, 1, "relu", 0, 0),       # stage-0 c2: the direct 64-channel kernel (>= 128 8 x 16 tiles per image)
     (1, 130, 125, 64, 64, 3, 1, 1, "silu", 0, 0),       # ... ragged tiles both ways
 ]
