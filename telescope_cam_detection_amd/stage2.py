@@ -69,6 +69,8 @@ class CropBatcher:
                 rects.append(r)
         return kept, rects
 
+    MAX_CROPS_PER_LAUNCH = 64        # rtd_crop_resize_batch's limit (include/rtdetr_mi355.h)
+
     def preprocess_batch(self, frames, rects_per_frame):
         """frames: list of device uint8 HWC tensors; rects_per_frame: list (per frame) of (x1,y1,x2,y2) lists.
         Returns a [N, 3, S, S] fp32 torch tensor on the frames' device (N = total number of crops)."""
@@ -81,18 +83,21 @@ class CropBatcher:
         out = torch.empty((n, 3, S, S), dtype=torch.float32, device=dev)
         if n == 0:
             return out
-        ptrs = (C.c_void_p * n)()
-        hw = (C.c_int32 * (2 * n))()
-        rc = (C.c_int32 * (4 * n))()
-        for i, (f, r) in enumerate(flat):
-            assert f.is_cuda and f.dtype == torch.uint8 and f.is_contiguous() and f.dim() == 3 and f.shape[2] == 3
-            ptrs[i] = f.data_ptr()
-            hw[2 * i], hw[2 * i + 1] = int(f.shape[0]), int(f.shape[1])
-            rc[4 * i], rc[4 * i + 1], rc[4 * i + 2], rc[4 * i + 3] = (int(v) for v in r)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        code = _capi.lib().rtd_crop_resize_batch(n, ptrs, hw, rc, S, self.mean, self.std, out.data_ptr(), C.c_void_p(stream))
-        if code != _capi.RTD_OK:
-            _capi._raise(code, None)
+        for i0 in range(0, n, self.MAX_CROPS_PER_LAUNCH):               # the kernel takes up to 64 crops per launch: a busy frame batch is chunked
+            part = flat[i0:i0 + self.MAX_CROPS_PER_LAUNCH]
+            k = len(part)
+            ptrs = (C.c_void_p * k)()
+            hw = (C.c_int32 * (2 * k))()
+            rc = (C.c_int32 * (4 * k))()
+            for i, (f, r) in enumerate(part):
+                assert f.is_cuda and f.dtype == torch.uint8 and f.is_contiguous() and f.dim() == 3 and f.shape[2] == 3
+                ptrs[i] = f.data_ptr()
+                hw[2 * i], hw[2 * i + 1] = int(f.shape[0]), int(f.shape[1])
+                rc[4 * i], rc[4 * i + 1], rc[4 * i + 2], rc[4 * i + 3] = (int(v) for v in r)
+            code = _capi.lib().rtd_crop_resize_batch(k, ptrs, hw, rc, S, self.mean, self.std, out[i0:i0 + k].data_ptr(), C.c_void_p(stream))
+            if code != _capi.RTD_OK:
+                _capi._raise(code, None)
         return out
 
 

@@ -56,6 +56,25 @@ def test_crop_batch_matches_torch_preprocess(S):
     assert batcher.preprocess_batch(dev, [[], []]).shape == (0, 3, S, S)
 
 
+@pytest.mark.gpu
+def test_crop_batch_above_the_per_launch_limit_is_chunked():
+    """A busy frame batch (8 frames x up to 300 detections) carries more than the kernel's 64 crops per launch: chunked, same pixels."""
+    rng = np.random.default_rng(9)
+    frame = scene_frame(13, 480, 640)
+    dev = [torch.from_numpy(frame).cuda()]
+    batcher = CropBatcher(input_size=64)
+    rects = []
+    for _ in range(150):
+        cw, ch = int(rng.integers(64, 300)), int(rng.integers(64, 300))
+        x, y = int(rng.integers(0, 640 - cw + 1)), int(rng.integers(0, 480 - ch + 1))
+        rects.append((x, y, x + cw, y + ch))
+    out = batcher.preprocess_batch(dev, [rects]).cpu()
+    assert out.shape == (150, 3, 64, 64)
+    for i in (0, 63, 64, 127, 128, 149):
+        x1, y1, x2, y2 = rects[i]
+        torch.testing.assert_close(out[i], s2o.preprocess(frame[y1:y2, x1:x2], 64)[0], atol=2e-5, rtol=1e-5)
+
+
 def test_bbox_normalisation_matches_the_reference_rule():
     for b in ({"x1": 30.5, "y1": 80.0, "x2": 10.0, "y2": 20.0}, {"x1": 5, "y1": 5, "x2": 5.2, "y2": 9}, {"x1": 1, "y1": 2, "x2": 30, "y2": 40, "area": 7}):
         assert normalised_bbox(dict(b)) == s2o.ensure_valid_bbox(dict(b))
