@@ -43,7 +43,8 @@ struct PlanOpts {
   int stem_fused_split = 1;   // the same for the bf16x3 engine (hi/lo pairs made on the fly from the bytes): on
   int sel_fused = 1;    // LayerNorm + score head + class max of the query selection in one launch
   int dec_fused = 1;    // 0 = one launch per decoder op
-  int side_stream = 1;  // the query-selection chain runs on a second stream beside the value projection (0: one stream)
+  int side_stream = 3;  // bit 0: the query-selection chain runs on a second stream beside the value projection; bit 1: the decoder input
+                        // projections of the two larger levels run there beside the PAN path (0: one stream)
 };
 PlanOpts g_opts;
 
@@ -822,25 +823,30 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   Tensor lat1 = pcat0.slice_c(d, d);
   B.conv("enc.lat.1", F0, lat1, 1, 1, 0, ACT_SILU);
   Tensor F1 = csp("enc.fpn.1", cat1, "enc0", &lat1);
-  // PAN bottom-up
-  B.conv("enc.down.0", F1, pcat0.slice_c(0, d), 3, 2, 1, ACT_SILU);
-  Tensor P1 = csp("enc.pan.0", pcat0, "enc1");
-  B.conv("enc.down.1", P1, pcat1.slice_c(0, d), 3, 2, 1, ACT_SILU);
-  Tensor P2 = csp("enc.pan.1", pcat1, "enc2");
-  Tensor pan[3] = {F1, P1, P2};
-
-  // ---- decoder input + query selection (HF:v2.py:1533-1623) ------------------------------------
+  // ---- decoder input (HF:v2.py:1533-1623): the projections of the two larger levels only need F1 / P1, so (side_stream bit 1) they run on the
+  // side stream beside the PAN path, whose 40^2 and 20^2 grids leave a quarter to two thirds of the CUs idle
   const int dm = c.d_model, S = e->S, Q = c.num_queries, C = c.num_classes, NL = c.dec_layers;
   Tensor mem = B.act(P, n, S, 1, dm, "memory");
-  for (int l = 0; l < 3; ++l) {
+  const bool early_proj = (e->opts.side_stream & 2) != 0;
+  auto dec_proj = [&](int l, const Tensor& src) {
     Tensor v = mem;
     v.p = B.dry ? nullptr : (char*)mem.p + (size_t)e->lvl_start[l] * dm * dtype_size(P);
     v.h = lh[l]; v.w = lw[l];
-    B.conv(nm("dec.proj.%d", l), pan[l], v, 1, 1, 0, ACT_NONE);
-  }
+    B.conv(nm("dec.proj.%d", l), src, v, 1, 1, 0, ACT_NONE);
+  };
+  // PAN bottom-up
+  if (early_proj) { B.marker(1); B.lane = 1; dec_proj(0, F1); B.lane = 0; }
+  B.conv("enc.down.0", F1, pcat0.slice_c(0, d), 3, 2, 1, ACT_SILU);
+  Tensor P1 = csp("enc.pan.0", pcat0, "enc1");
+  if (early_proj) { B.marker(1); B.lane = 1; dec_proj(1, P1); B.lane = 0; }
+  B.conv("enc.down.1", P1, pcat1.slice_c(0, d), 3, 2, 1, ACT_SILU);
+  Tensor P2 = csp("enc.pan.1", pcat1, "enc2");
+  if (!early_proj) { dec_proj(0, F1); dec_proj(1, P1); }
+  dec_proj(2, P2);
+  if (early_proj) B.marker(2);
   // The query-selection chain (enc_output -> scores -> top-k -> gather: narrow grids, latency-bound) and the value projection both start
   // from `mem` and meet again in the decoder prologue: the chain runs on the side stream beside the projection (e->opts.side_stream).
-  const bool side = e->opts.side_stream != 0;
+  const bool side = (e->opts.side_stream & 1) != 0;
   if (side) { B.marker(1); B.lane = 1; }
   // enc_output on masked memory, fp32 from here on (selection + decoder are exact fp32)
   Tensor eo = B.linear("dec.enc_out.fc", mem, dm, F32, ACT_NONE);

@@ -263,6 +263,29 @@ def test_full_size_properties_bf16x3_bs8():
     eng.close()
 
 
+def test_side_stream_plan_equals_the_serial_plan():
+    """side_stream (query selection beside the value projection, decoder input projections beside the PAN path: fork / join edges in the
+    hipGraph) runs the same kernels on the same data as the one-stream plan: bit-identical outputs, eager and replayed."""
+    from telescope_cam_detection_amd import _capi
+    from telescope_cam_detection_amd.synth import noise_frame, scene_frame
+    from telescope_cam_detection_amd.arch import ARCHS
+    arch = ARCHS["r50"]
+    w = weights_for(arch, 0)
+    frames = [scene_frame(70, 640, 640), noise_frame(71, 640, 640), scene_frame(72, 640, 640)]
+    outs = []
+    for v in (0, 1, 3):
+        _capi.debug_option("side_stream", v)
+        e = make_engine(arch, w, frames, (640, 640), "bf16x3", use_graph=True)
+        for _ in range(3):
+            o = e.infer_raw(frames)
+        outs.append(o)
+        e.close()
+    _capi.debug_option("side_stream", 3)
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            np.testing.assert_array_equal(x, y)
+
+
 def test_patch_maxpool_equals_per_output_maxpool():
     """the bf16 2x2-patch max-pool kernel against the one-output-per-thread kernel: max is exact, the stem must match bitwise"""
     from telescope_cam_detection_amd import _capi
