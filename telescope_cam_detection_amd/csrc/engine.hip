@@ -1469,6 +1469,7 @@ void rtd_destroy(rtd_handle h) {
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    (void)hipGetLastError();                         // nothing a teardown call reported may stay behind as this thread's sticky error
   }
   delete h;
 }
