@@ -3681,7 +3681,7 @@ static int g_split_persist = 0;            // rtd_debug_option "split_persist": 
 static int g_split_persist_min_tiles = 384;   // persistent kernel from this many 112 x 128 tiles on ("split_persist_min_tiles")
 void conv_set_split_persist(int v) { g_split_persist = v; }
 void conv_set_split_persist_min_tiles(int v) { g_split_persist_min_tiles = v; }
-static int g_split_flex_small_max = 128;   // "split_flex_small_max"
+static int g_split_flex_small_max = 200;   // "split_flex_small_max" (same-box sweep on R50 bs 8 after the K-walk change: 128 / 200 / 256 / 400 -> 4.816 / 4.776 / 4.779 / 4.777 ms per step)
 void conv_set_split_flex_small_max(int v) { g_split_flex_small_max = v; }
 static int g_split_flex_force = 0;
 void conv_set_split_flex_force(int v) { g_split_flex_force = v; }
@@ -4238,7 +4238,7 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
 void conv_reset_options() {
   g_glds_min_blocks = 4; g_splitk_enable = 0; g_glds_drop = 0; g_conv_mode = 0; g_force_v1 = 0; g_ws256_min_blocks = 0; g_glds_min_n = 128;
   g_wsa_min_ntn = 8; g_ws2_min_blocks = 257; g_reg_epilogue = 1; g_ws64_max_blocks = 160; g_prefetch = 1; g_conv_reg = 3; g_conv_stream = 1;
-  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160; g_split_kernel = 2; g_split_flex = 2; g_split_flex_min_nk = 16; g_split_flex_force = 0; g_split_persist = 0; g_split_persist_min_tiles = 384; g_split_flex_small_max = 128; g_split_sx = 3; g_split_k2 = 1;
+  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160; g_split_kernel = 2; g_split_flex = 2; g_split_flex_min_nk = 16; g_split_flex_force = 0; g_split_persist = 0; g_split_persist_min_tiles = 384; g_split_flex_small_max = 200; g_split_sx = 3; g_split_k2 = 1;
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t s) {
