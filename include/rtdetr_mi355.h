@@ -148,7 +148,7 @@ int64_t rtd_arena_bytes(rtd_handle h);
  *   conv_reg is a bit set: 1 = direct 3x3 kernels for the narrow stem / stage-0 layers, 2 = the 64-channel BF16X2 one [3]
  * RTD_PREC_BF16X3 kernels: split_kernel [2: 0 round-1 tile, 1 dedicated kernel on 32x32x16 MFMAs, 2 on 16x16x32] | split_ws2_min_blocks [257] |
  *   split_ws64_max_blocks [160] | split_flex [2: flexible tile heights 0 never, 1 every grid, 2 grids of <= split_flex_small_max [200] tiles],
- *   split_flex_min_nk [16], split_flex_force [0] | split_persist [0] persistent three-role kernel, split_persist_min_tiles [384] |
+ *   split_flex_min_nk [4], split_flex_force [0] | split_persist [0] persistent three-role kernel, split_persist_min_tiles [384] |
  *   split_k2 [1: two-pass split-K on >= 128 K-steps with <= 16 tiles per image] |
  *   split_sx [3: streaming 1x1 kernel 0 off, 1 stage-0 shapes, 2 + K = 128, 3 + K = 256 -> N >= 1024 (value projection), 4 + with residual (slower)]
  * "reset" (any value): every dispatch switch and every plan-build default back to the values in brackets.

@@ -3685,7 +3685,7 @@ static int g_split_flex_small_max = 200;   // "split_flex_small_max" (same-box s
 void conv_set_split_flex_small_max(int v) { g_split_flex_small_max = v; }
 static int g_split_flex_force = 0;
 void conv_set_split_flex_force(int v) { g_split_flex_force = v; }
-static int g_split_flex_min_nk = 16;       // flexible tiles from this many K-steps on (shorter K loops are not MFMA-bound); "split_flex_min_nk"
+static int g_split_flex_min_nk = 4;        // flexible tiles from this many K-steps on; "split_flex_min_nk" (same-box sweep, R50 bs 8: 16 / 8 / 4 / 2 -> 4.884 / 4.878 / 4.854 / 4.866 ms)
 void conv_set_split_flex(int v) { g_split_flex = v; }
 void conv_set_split_flex_min_nk(int v) { g_split_flex_min_nk = v; }
 void conv_set_split_ws64_max_blocks(int v) { g_split_ws64_max_blocks = v; }
@@ -4238,7 +4238,7 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
 void conv_reset_options() {
   g_glds_min_blocks = 4; g_splitk_enable = 0; g_glds_drop = 0; g_conv_mode = 0; g_force_v1 = 0; g_ws256_min_blocks = 0; g_glds_min_n = 128;
   g_wsa_min_ntn = 8; g_ws2_min_blocks = 257; g_reg_epilogue = 1; g_ws64_max_blocks = 160; g_prefetch = 1; g_conv_reg = 3; g_conv_stream = 1;
-  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160; g_split_kernel = 2; g_split_flex = 2; g_split_flex_min_nk = 16; g_split_flex_force = 0; g_split_persist = 0; g_split_persist_min_tiles = 384; g_split_flex_small_max = 200; g_split_sx = 3; g_split_k2 = 1;
+  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160; g_split_kernel = 2; g_split_flex = 2; g_split_flex_min_nk = 4; g_split_flex_force = 0; g_split_persist = 0; g_split_persist_min_tiles = 384; g_split_flex_small_max = 200; g_split_sx = 3; g_split_k2 = 1;
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t s) {
