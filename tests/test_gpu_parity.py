@@ -134,9 +134,10 @@ def x3_check(name, arch, eng, frames, ref_topk, ref_scores_all, refs, score_tol,
         mine = set(np.argsort(-mx[b], kind="stable")[:Q].tolist())
         ref = set(np.asarray(ref_topk[b]).tolist())
         diff = mine ^ ref
-        flips.append(len(diff) // 2)
+        kth = np.sort(ref_scores_all[b])[-Q]
+        # exact ties with the rank-Q score (masked anchors share one score: whole groups of identical rows) are interchangeable, not flips
+        flips.append(len([t for t in diff if float(ref_scores_all[b][t]) != float(kth)]) // 2)
         if diff:
-            kth = np.sort(ref_scores_all[b])[-Q]
             worst = max(abs(float(ref_scores_all[b][t]) - float(kth)) for t in diff)
             print(f"{name}[{b}] selection differs in {len(diff) // 2} token(s); farthest from the rank-{Q} score: {worst:.2e}")
             assert worst <= 2 * score_tol, (b, worst)
@@ -706,6 +707,28 @@ def test_non_square_input_with_partial_tiles_bf16_and_fp32():
         m, n, ws, wb = match_detections(l, bx, sc, l2, bx2, sc2, 3e-2, 4.0)
         print(f"non-square bf16 vs fp32 [{b}]: matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
         assert m >= n - 18, ("bf16", b, m, n, ws, wb)                            # measured: 10-12 of 300 miss at 3e-2 / 4 px
+
+
+def test_bf16x3_non_square_frames_with_ragged_tiles_against_the_oracle():
+    """R50 at 480 x 608 (multiples of 32; 120 x 152, 60 x 76, 30 x 38 and 15 x 19 maps are not multiples of the 8 x 16 / 32- / 128-pixel tiles): the
+    default engine's direct, streaming (fused follower, tiles straddling images), tiled, flexible and split-K kernels all meet ragged tiles inside
+    the network.  Against the oracle at the north-star tolerance, free-running and with the oracle's query selection."""
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.synth import noise_frame, scene_frame
+    arch = ARCHS["r50"]
+    w = weights_for(arch, 3)
+    size = (480, 608)
+    frames = [scene_frame(300, size[0], size[1]), noise_frame(301, size[0], size[1]), scene_frame(302, 360, 500)]      # the third one is resampled
+    (ol, ob, osc), col = oracle_run(arch, w, frames, size)
+    eng = make_engine(arch, w, frames, size, "bf16x3", use_graph=True)
+    eng.infer_raw(frames)
+    for i in range(3):
+        e = rel_err(nchw(eng.debug_tensor(f"enc{i}")), col[f"enc{i}"].numpy())
+        print(f"480x608 enc{i} rel l2 err {e:.2e}")
+        assert e < 1e-4
+    refs = [("oracle", [t.numpy() for t in ol], [t.numpy() for t in ob], [t.numpy() for t in osc])]
+    x3_check("r50_480x608", arch, eng, frames, col["topk"].numpy(), col["enc_cls_max"].numpy(), refs, 5e-4)
+    eng.close()
 
 
 def test_detector_keeps_working_after_the_callers_degrade_writes():
