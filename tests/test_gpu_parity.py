@@ -731,6 +731,22 @@ def test_bf16x3_non_square_frames_with_ragged_tiles_against_the_oracle():
     eng.close()
 
 
+@pytest.mark.parametrize("aname,size,bs", [("r34", (640, 640), 2), ("r101", (640, 640), 1), ("r18", (320, 320), 5)])
+def test_bf16x3_other_backbones_and_sizes_against_the_oracle(aname, size, bs):
+    """The variants the reference's config files name besides R50 (r18vd / r34vd basic blocks, r101vd) and a small input / odd batch: default
+    engine vs the oracle at the north-star tolerance (no golden file: the oracle itself is pinned to HF on the committed cases)."""
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.synth import noise_frame, scene_frame
+    arch = ARCHS[aname]
+    w = weights_for(arch, 5)
+    frames = [scene_frame(400 + i, size[0], size[1]) if i % 2 == 0 else noise_frame(400 + i, size[0], size[1]) for i in range(bs)]
+    (ol, ob, osc), col = oracle_run(arch, w, frames, size)
+    eng = make_engine(arch, w, frames, size, "bf16x3", use_graph=True)
+    refs = [("oracle", [t.numpy() for t in ol], [t.numpy() for t in ob], [t.numpy() for t in osc])]
+    x3_check(f"{aname}_{size[0]}_bs{bs}", arch, eng, frames, col["topk"].numpy(), col["enc_cls_max"].numpy(), refs, 1e-3 if aname == "r101" else 5e-4)
+    eng.close()
+
+
 def test_detector_keeps_working_after_the_callers_degrade_writes():
     """src/inference_engine_yolox.py:726-748 on the real engine: `detector.input_size = ...`, `detector.device = "cpu"` and
     `detector.model.to("cpu")` (raises, caught by the caller) - then detect, detect_batch and the pipelined pair must give what
