@@ -14,7 +14,7 @@ exists offline).  One "step" = one batch of 8 frames through preprocess -> netwo
 fixed [8,300,6] result block stays in HBM).  N > 1: one process per GPU, cameras sharded over ranks (weak scaling), and one
 RCCL all-gather of every rank's result block per step - the collate step for rank 0's web server.
 
-Engine (--precision): "bf16x3" (default) = hi/lo bf16 pairs, three MFMAs per product, fp32 accumulate - the engine that meets
+Engine (--precision): "f16x3" (default) = hi/lo bf16 pairs, three MFMAs per product, fp32 accumulate - the engine that meets
 the north-star tolerance (1e-3 on scores, 1e-2 px on boxes; tests/test_gpu_parity.py) AND the throughput target;
 "bf16" = plain bf16 storage / MFMA (faster, 2-4x outside the tolerance - printed as `bf16_engine` beside the headline);
 "fp32" = exact fp32 MFMAs.
@@ -44,8 +44,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense)
-MFMA_PER_PRODUCT = {"bf16": 1, "bf16x3": 3, "fp32": 1}                  # MFMA flops issued per algorithmic flop
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16x3": 2500.0, "fp32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+MFMA_PER_PRODUCT = {"bf16": 1, "f16x3": 3, "fp32": 1}                  # MFMA flops issued per algorithmic flop
 HBM_PEAK_GBS = 8000.0
 CANON_GFLOP_PER_FRAME = {"r18": 60.53, "r50": 133.91}  # BASELINE.md 3 @640x640
 
@@ -76,7 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--arch", default="r50")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32"])
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16", "fp32"])
     ap.add_argument("--streams", type=int, default=1, help="engine handles (batches in flight) per GPU behind `value`")
     ap.add_argument("--multi-streams", type=int, default=3, help="handles of the extra `multi_stream` measurement (0 = skip)")
     ap.add_argument("--workload", default="detect", choices=["detect", "two_stage"],
@@ -224,7 +224,7 @@ def main():
                    "global_batch": world * B, "parallelism": f"camera-shard x{world}" + (" + RCCL all_gather of detections" if world > 1 else ""),
                    "streams_per_gpu": S, "batches_in_flight_per_gpu": S,
                    "kernel_profile": "throughput" if (S > 1 and not args.latency_profile) else "latency", "hip_graph": not args.no_graph,
-                   "engine": {"bf16x3": "hi/lo bf16 pairs, 3 MFMAs per product, fp32 accumulate (meets 1e-3 / 1e-2 px)",
+                   "engine": {"f16x3": "hi/lo bf16 pairs, 3 MFMAs per product, fp32 accumulate (meets 1e-3 / 1e-2 px)",
                               "bf16": "bf16 storage + MFMA, fp32 accumulate (outside the 1e-3 / 1e-2 px tolerance)",
                               "fp32": "exact fp32 MFMAs"}[args.precision]},
         "rccl_ranks": rccl_ranks,
@@ -257,7 +257,7 @@ def main():
             "alg_gbytes_per_s_unfused": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
             "share_of_step": round(d["ms"] / total_ms, 3),
             "method": "rtd_profile: hipEvent pairs around every launch of one eager forward on ONE engine stream (no second batch in flight), mean of 5; "
-                      "`achieved` counts ALGORITHMIC flops (2 per MAC); the bf16x3 engine issues 3 MFMA flops per algorithmic flop (mfma_issue_frac)",
+                      "`achieved` counts ALGORITHMIC flops (2 per MAC); the f16x3 engine issues 3 MFMA flops per algorithmic flop (mfma_issue_frac)",
         }
         # HBM bytes per launch / rocprofv3 durations / MFMA-busy counters come from the committed PMC passes (separate rocprofv3 runs of
         # this same command: counters cannot be read live).  They are attached only when the profile was measured on THESE kernel sources.
@@ -312,7 +312,7 @@ def main():
                                "note": f"same K steps round-robin over {MS} throughput-profile handles ({MS} bs-{B} batches in flight)"}
         for e in es:
             e.close()
-    if args.precision == "bf16x3" and not args.no_bf16_line and args.workload == "detect" and world == 1:
+    if args.precision == "f16x3" and not args.no_bf16_line and args.workload == "detect" and world == 1:
         el, es, _ = measure("bf16", 1)
         out["bf16_engine"] = {"value": round(world * B * args.steps / el, 2), "unit": "frames/s", "streams_per_gpu": 1,
                               "ms_per_step": round(1000.0 * el / args.steps, 4),

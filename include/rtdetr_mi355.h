@@ -36,10 +36,13 @@ enum {
   RTD_E_STATE = 5    /* call order (e.g. infer before load_weights) */
 };
 
-/* RTD_PREC_BF16X3: every trunk activation and filter is a hi + lo pair of bf16 (x = hi + lo to 2^-18) and every contraction runs as
- * three bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate): fp32-grade results at bf16 MFMA rates - the engine that meets the
- * reference tolerance (1e-3 on scores, 1e-2 px on boxes against fp32 eager, src/rtdetr_detector.py:256-257) at >= 1000 frames/s. */
-enum { RTD_PREC_BF16 = 0, RTD_PREC_FP32 = 1, RTD_PREC_BF16X3 = 2 };
+/* RTD_PREC_F16X3 (the default engine): every trunk activation and filter is a hi + lo pair of IEEE fp16 (x = hi + lo to 2^-22 relative,
+ * 2^-25 absolute below 2^-3, saturating at +-65504) and every contraction runs as three fp16 MFMAs (hi*hi + hi*lo + lo*hi, fp32
+ * accumulate): fp32-grade results at the 16-bit MFMA rate / 3.  It meets the reference tolerance (1e-3 on scores, 1e-2 px on boxes
+ * against fp32 eager, src/rtdetr_detector.py:256-257) on 640-px AND 1280-px frames (tests/test_gpu_parity.py) at >= 1000 frames/s.
+ * RTD_PREC_BF16: plain bf16 storage, one MFMA per product - faster, outside that tolerance (~1 px).  RTD_PREC_FP32: the reference
+ * arithmetic on fp32 MFMAs. */
+enum { RTD_PREC_BF16 = 0, RTD_PREC_FP32 = 1, RTD_PREC_F16X3 = 2 };
 enum { RTD_LAYER_BASIC = 0, RTD_LAYER_BOTTLENECK = 1 };
 
 /* Constructor arguments of RTDETRDetector (src/rtdetr_detector.py:29-58) that matter to the device
@@ -137,29 +140,31 @@ int rtd_debug_force_topk(rtd_handle h, const int32_t* idx, int32_t n);
 /* time every kernel of one forward of batch n with HIP events on the handle's stream */
 int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int32_t capacity, int32_t* count);
 int64_t rtd_arena_bytes(rtd_handle h);
-/* process-wide A/B switches for tests and profiling (defaults in brackets; unknown names return RTD_E_INVALID).
- * Kernel dispatch, effective at the next launch / graph capture:
- *   conv_mode [0]   0 auto | 1 small register-staged tiles | 2 + large register-staged tile | 3,4 wave-specialised LDS-DMA tile with
- *                   4 / 2 stages | 5 single-role LDS-DMA | 6 whole-K-step fragment prefetch | 7 256-pixel tile | 8 A-stationary
- *                   kernel wherever eligible | 9 streaming 1x1 kernels whatever the grid size | 10 128 x 64 tile everywhere
- *   conv_reg [1], conv_stream [1], stream2 [1], stream2_max_n [2048], stream_slab [1], stream_min_tiles [2048], wsa_min_ntn [8], ws2_min_blocks [257], ws64_max_blocks [160],
- *   ws256_min_blocks [0], glds_min_blocks [4], glds_min_n [128], splitk [0], reg_epilogue [1], prefetch [1], maxpool_v1 [0],
- *   dec_pf [2; + 16: L2-hot filter probe, results wrong], glds_drop [0: timing-only probes, results wrong when set]
- *   conv_reg is a bit set: 1 = direct 3x3 kernels for the narrow stem / stage-0 layers, 2 = the 64-channel BF16X2 one [3]
- * RTD_PREC_BF16X3 kernels: split_kernel [2: 0 round-1 tile, 1 dedicated kernel on 32x32x16 MFMAs, 2 on 16x16x32] | split_ws2_min_blocks [257] |
- *   split_ws64_max_blocks [160] | split_flex [2: flexible tile heights 0 never, 1 every grid, 2 grids of <= split_flex_small_max [200] tiles],
- *   split_flex_min_nk [4], split_flex_force [0] | split_persist [0] persistent three-role kernel, split_persist_min_tiles [384] |
+/* A/B switches for tests and profiling (defaults in brackets; unknown names return RTD_E_INVALID).  Every switch edits a process-wide
+ * TEMPLATE that rtd_create snapshots into the handle: a call changes handles created AFTERWARDS (and the kernel-level rtd_op_* /
+ * rtd_bench_* entry points below, which read the template when called) - never a live handle, so two handles of one process cannot see
+ * each other's settings and all plans of a handle (one per batch size, built lazily) agree with each other.
+ * Conv dispatch, bf16 / fp32 operands (csrc/common.h ConvOpts):
+ *   conv_mode [0]   0 auto | 1 register-staged fallback kernel only | 3, 4 wave-specialised LDS-DMA tile with 4 / 2 stages everywhere |
+ *                   7 256-pixel tile | 8 A-stationary kernel wherever eligible | 9 streaming 1x1 kernels whatever the grid size |
+ *                   10 128 x 64 tile everywhere
+ *   conv_reg [3: bit 0 direct 3x3 kernels for the narrow stem / stage-0 layers, bit 1 the 64-channel pair kernel], conv_stream [1], stream2 [1],
+ *   stream2_max_n [2048], stream_slab [1], stream_min_tiles [2048], wsa_min_ntn [8], ws2_min_blocks [257], ws64_max_blocks [160],
+ *   ws256_min_blocks [0], glds_min_blocks [4], glds_min_n [128], reg_epilogue [1], prefetch [1],
+ *   glds_drop [0: timing-only probes, results wrong when set]
+ * Conv dispatch, pair operands (RTD_PREC_F16X3): split_ws2_min_blocks [257] | split_ws64_max_blocks [160] |
+ *   split_flex [1: flexible tile heights on grids of <= split_flex_small_max [200] tiles], split_flex_min_nk [4] |
  *   split_k2 [1: two-pass split-K on >= 128 K-steps with <= 16 tiles per image] |
  *   split_sx [3: streaming 1x1 kernel 0 off, 1 stage-0 shapes, 2 + K = 128, 3 + K = 256 -> N >= 1024 (value projection), 4 + with residual (slower)]
- * "reset" (any value): every dispatch switch and every plan-build default back to the values in brackets.
- * Plan-build switches are process-wide DEFAULTS that a handle snapshots at rtd_create: all plans of a handle agree with each other and a later
- * call cannot change a live handle (set them before rtd_create):
+ * Plan building:
  *   sc_fold [1] projection shortcut folded into the block's last conv | up_fold [1] FPN upsample folded into the CSP's first conv |
- *   c1_fuse [1] a block's reduce conv computed inside the previous block's expand conv (bf16: stage 0/1; bf16x3: stage 0 and the first block
- *   of stage 1) | attn_split [2] self-attention on split-bf16 MFMAs (bit 0 AIFI, bit 1 decoder) |
- *   arena_reuse [1] | stem_fused [0] (bf16) / stem_fused_split [1] (bf16x3): stem.0 straight from the uint8 frames | side_stream [3: bit 0 query
- *   selection on a second stream beside the value projection, bit 1 decoder input projections beside the PAN path] | dec_fused [1], dec_split [1: 0 fp32 MFMA, 2 bf16 filters], sel_fused [1] |
- *   dec_stamps [0] */
+ *   c1_fuse [1] a block's reduce conv computed inside the previous block's expand conv (bf16: stage 0/1; f16x3: stage 0 and the first block
+ *   of stage 1) | attn_split [2] self-attention on fp16-pair MFMAs (bit 0 AIFI, bit 1 decoder) |
+ *   arena_reuse [1] | stem_fused [0] (bf16) / stem_fused_split [1] (f16x3): stem.0 straight from the uint8 frames | side_stream [3: bit 0 query
+ *   selection on a second stream beside the value projection, bit 1 decoder input projections beside the PAN path] | dec_fused [1],
+ *   dec_split [1: 0 fp32 MFMA, 2 hi-only filters], sel_fused [1] | dec_stamps [0]
+ * Tools: profile_twice [0], bench_rewarm [0].
+ * "reset" (any value): every template back to the values in brackets. */
 int rtd_debug_option(const char* name, int value);
 
 /* ---- Stage 2: crop + classifier pre-processing for a whole batch of detections ------------------
@@ -171,8 +176,8 @@ int rtd_debug_option(const char* name, int value);
 int rtd_crop_resize_batch(int32_t n, const uint8_t* const* frames_dev, const int32_t* frame_hw, const int32_t* rects,
                           int32_t out_size, const float* mean3, const float* std3, float* out_dev, void* stream);
 
-/* ---- kernel-level test entry points (device pointers; dtype 0 = bf16, 1 = fp32, 4 = BF16X2: hi/lo bf16 pairs in 32-channel groups
- * [32 hi | 32 lo], 4 bytes per channel - the storage of RTD_PREC_BF16X3, rtd_op_conv / rtd_op_conv_dual only) --------------- */
+/* ---- kernel-level test entry points (device pointers; dtype 0 = bf16, 1 = fp32, 4 = F16X2: hi/lo fp16 pairs in 32-channel groups
+ * [32 hi | 32 lo], 4 bytes per channel - the storage of RTD_PREC_F16X3, rtd_op_conv / rtd_op_conv_dual only) --------------- */
 int rtd_op_conv(int dtype, const void* x, const void* w_ohwi_f32, const float* bias, const void* res,
                 void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                 int act, int res_mode, int out_f32);
@@ -184,7 +189,7 @@ int rtd_op_conv_dual(int dtype, const void* x, const void* x2, const void* w_f32
                      int act, int res_mode, int out_f32, int x_up2);
 /* 1x1 conv (optionally with a second input, as rtd_op_conv_dual) with the FOLLOWING 1x1 conv Cout -> Cnext fused into the launch
  * (how the plan runs a bottleneck's reduce conv inside the previous block's expand conv): y = act(W [x | x2] + b (+ res)),
- * y1 = next_act(W1 y + b1), both written.  dtype 1 (bf16) / 4 (bf16x2); RTD_E_INVALID for shapes the streaming kernels do not take. */
+ * y1 = next_act(W1 y + b1), both written.  dtype 1 (bf16) / 4 (f16x2); RTD_E_INVALID for shapes the streaming kernels do not take. */
 int rtd_op_conv_next(int dtype, const void* x, const void* x2, const void* w_f32, const float* bias, const void* res, void* y,
                      const void* w1_f32, const float* bias1, void* y1, int B, int H, int W, int Cin, int C2, int Cout, int Cnext,
                      int act, int res_mode, int next_act);

@@ -57,7 +57,7 @@ CASES = {
     "t_tiny_160": ("tiny", 1, (160, 160), [(4000, 160, 160), (4001, 160, 160)], "scene"),
     "t_tiny_160x224": ("tiny", 1, (160, 224), [(4002, 160, 224)], "noise"),
     "t_tinyb_192x128": ("tinyb", 2, (192, 128), [(4003, 192, 128), (4004, 100, 90), (4005, 300, 260)], "scene"),
-    # every width a multiple of 32: the small case of the bf16x3 engine (non-square, one resized frame)
+    # every width a multiple of 32: the small case of the f16x3 engine (non-square, one resized frame)
     "t_tinyc_160x224": ("tinyc", 3, (160, 224), [(4006, 160, 224), (4007, 200, 150)], "scene"),
 }
 

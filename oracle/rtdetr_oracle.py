@@ -243,8 +243,10 @@ def ms_deform_attn(arch, w, pfx, hs, pos, ref, memory, shapes):
     return linear(w, pfx + ".op", o)
 
 
-def decoder_and_heads(arch, w, pan, collect=None):
-    """HF:v2.py:1533-1623 (query selection) ; :555-661 (decoder loop) ; :1880-1881 (last layer)."""
+def decoder_and_heads(arch, w, pan, collect=None, force_topk=None):
+    """HF:v2.py:1533-1623 (query selection) ; :555-661 (decoder loop) ; :1880-1881 (last layer).
+    force_topk [B,Q] (tests only): run the decoder on these memory tokens instead of the restatement's own top-Q - the reference under the
+    selection of the implementation being checked, for frames where a near-tie at the rank-Q cut fell the other way."""
     srcs, shapes = [], []
     for l, fmap in enumerate(pan):
         s = conv_bn(w, f"dec.proj.{l}", fmap)
@@ -257,6 +259,8 @@ def decoder_and_heads(arch, w, pan, collect=None):
     enc_cls = linear(w, "dec.enc_score", om)
     enc_box = mlp_head(w, "dec.enc_bbox", om, 3) + anchors
     _, topk = torch.topk(enc_cls.max(-1).values, arch.num_queries, dim=1)
+    if force_topk is not None:
+        topk = torch.as_tensor(force_topk, dtype=torch.int64).view(topk.shape)
     ref_unact = enc_box.gather(1, topk.unsqueeze(-1).repeat(1, 1, 4))
     target = om.gather(1, topk.unsqueeze(-1).repeat(1, 1, om.shape[-1]))
     if collect is not None:
@@ -299,7 +303,7 @@ def postprocess(logits, boxes, orig_sizes_wh):
 
 
 @torch.no_grad()
-def model_forward(arch, w, images, orig_sizes_wh, collect=None):
+def model_forward(arch, w, images, orig_sizes_wh, collect=None, force_topk=None):
     """`Model.forward` of src/rtdetr_detector.py:161-170: network + post-processor."""
     feats = backbone(arch, w, images)
     if collect is not None:
@@ -309,7 +313,7 @@ def model_forward(arch, w, images, orig_sizes_wh, collect=None):
     if collect is not None:
         for i, f in enumerate(pan):
             collect[f"enc{i}"] = f
-    logits, boxes = decoder_and_heads(arch, w, pan, collect)
+    logits, boxes = decoder_and_heads(arch, w, pan, collect, force_topk)
     if collect is not None:
         collect["logits"] = logits
         collect["pred_boxes"] = boxes

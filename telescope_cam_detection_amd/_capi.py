@@ -15,51 +15,48 @@ from . import build as _build
 from .arch import Arch
 
 RTD_OK, RTD_E_INVALID, RTD_E_OOM, RTD_E_HIP, RTD_E_WEIGHTS, RTD_E_STATE = range(6)
-PREC_BF16, PREC_FP32, PREC_BF16X3 = 0, 1, 2
-DT_BF16, DT_F32, DT_BF16X2 = 0, 1, 4
-SPLIT_GROUP = 32      # channels per [hi | lo] group of a BF16X2 tensor (csrc/common.h)
+PREC_BF16, PREC_FP32, PREC_F16X3 = 0, 1, 2
+DT_BF16, DT_F32, DT_F16X2 = 0, 1, 4
+SPLIT_GROUP = 32      # channels per [hi | lo] group of a F16X2 tensor (csrc/common.h)
 
 
 def precision_code(name) -> int:
-    """'bf16x3' (default engine: hi/lo bf16 pairs, three MFMAs per product - meets the reference tolerance), 'bf16', 'fp32'."""
+    """'f16x3' (default engine: hi/lo fp16 pairs, three MFMAs per product - meets the reference tolerance), 'bf16', 'fp32'."""
     if isinstance(name, int):
         return name
     s = str(name).lower()
-    if s in ("bf16x3", "split", "bf16x2"):
-        return PREC_BF16X3
+    if s in ("f16x3", "fp16x3", "pair"):
+        return PREC_F16X3
     if s in ("fp32", "f32", "float32"):
         return PREC_FP32
     if s in ("bf16", "bfloat16"):
         return PREC_BF16
-    raise ValueError(f"unknown precision {name!r} (bf16x3 | bf16 | fp32)")
+    raise ValueError(f"unknown precision {name!r} (f16x3 | bf16 | fp32)")
 
 
 def to_split(x: np.ndarray) -> np.ndarray:
-    """fp32 [..., C] (C % 32 == 0) -> BF16X2 storage as uint16 [..., 2C]: per 32-channel group [32 hi | 32 lo],
-    hi = bf16_rne(x), lo = bf16_rne(x - hi).  Host-side mirror of csrc/common.h split_store8 (tests / tools)."""
-    x = np.ascontiguousarray(x, np.float32)
+    """fp32 [..., C] (C % 32 == 0) -> F16X2 storage as uint16 [..., 2C]: per 32-channel group [32 hi | 32 lo],
+    hi = fp16_rne(x), lo = fp16_rne(x - hi) (subnormals kept, +-65504 saturation).  Host-side mirror of csrc/common.h
+    split_store8 (tests / tools)."""
+    x = np.clip(np.ascontiguousarray(x, np.float32), -65504.0, 65504.0)
     C_ = x.shape[-1]
     assert C_ % SPLIT_GROUP == 0
-
-    def rne(v):
-        u = v.view(np.uint32).astype(np.uint64)
-        return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
-
-    hi = rne(x)
-    hif = (hi.astype(np.uint32) << 16).view(np.float32)
-    lo = rne((x - hif).astype(np.float32))
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
     g = x.shape[:-1] + (C_ // SPLIT_GROUP, SPLIT_GROUP)
-    out = np.stack([hi.reshape(g), lo.reshape(g)], axis=-2)          # [..., groups, 2, 32]
+    out = np.stack([hi.view(np.uint16).reshape(g), lo.view(np.uint16).reshape(g)], axis=-2)          # [..., groups, 2, 32]
     return np.ascontiguousarray(out.reshape(x.shape[:-1] + (2 * C_,)))
 
 
 def from_split(s: np.ndarray) -> np.ndarray:
-    """BF16X2 storage (uint16 [..., 2C]) -> fp32 [..., C] (hi + lo, exact in fp32)."""
+    """F16X2 storage (uint16 [..., 2C]) -> fp32 [..., C] (hi + lo, exact in fp32)."""
     s = np.ascontiguousarray(s, np.uint16)
     C_ = s.shape[-1] // 2
     g = s.reshape(s.shape[:-1] + (C_ // SPLIT_GROUP, 2, SPLIT_GROUP))
-    f = (g.astype(np.uint32) << 16).view(np.float32)
+    f = g.view(np.float16).astype(np.float32)
     return np.ascontiguousarray((f[..., 0, :] + f[..., 1, :]).reshape(s.shape[:-1] + (C_,)))
+
+
 ACT = {"none": 0, "relu": 1, "silu": 2, "gelu": 3}
 
 

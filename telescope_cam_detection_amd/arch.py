@@ -76,7 +76,7 @@ ARCHS = {
     "tinyb": Arch("tinyb", "basic", (1, 1, 1, 1), (32, 64, 128, 256), embedding_size=32,
                   enc_dim=64, enc_ffn=128, enc_heads=2, d_model=64, dec_ffn=128, dec_heads=2,
                   dec_layers=2, num_queries=50, expansion=0.5),
-    # a one-block-per-stage R18 trunk with small heads: every trunk width is a whole 32-channel group, which the bf16x3 engine's hi/lo
+    # a one-block-per-stage R18 trunk with small heads: every trunk width is a whole 32-channel group, which the f16x3 engine's hi/lo
     # layout needs (basic blocks need embedding_size == hidden_sizes[0], HF:rt_detr_resnet.py:150-163)
     "tinyc": Arch("tinyc", "basic", (1, 1, 1, 1), (64, 128, 256, 512), embedding_size=64,
                   enc_dim=64, enc_ffn=128, enc_heads=2, d_model=64, dec_ffn=128, dec_heads=2,

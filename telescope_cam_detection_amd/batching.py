@@ -290,7 +290,7 @@ def make_rtdetr_coordinator(config: Dict[str, Any], coordinator_cls=None, detect
     # several detectors share the GPU: their kernels lean towards throughput (rtd_config.profile); the reference's own
     # detector class knows no such argument and is never built with depth > 1
     prof = {"profile": "throughput"} if depth > 1 else {}
-    if "precision" in rt:                               # build-specific key detection.rtdetr.precision: bf16x3 (default) | bf16 | fp32
+    if "precision" in rt:                               # build-specific key detection.rtdetr.precision: f16x3 (default) | bf16 | fp32
         prof["precision"] = rt["precision"]
     try:
         detector = detector_cls(

@@ -8,13 +8,13 @@
 
 namespace rtd {
 
-// BF16X2 ("split"): every value is carried as two bf16, x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <= 2^-18 |x|).
+// F16X2 ("split"): every value is carried as two bf16, x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <= 2^-18 |x|).
 // Storage: a pixel's channels in groups of 32, each group 128 bytes = [32 x hi | 32 x lo]; 4 bytes per channel, so `ld`, `c` and
 // slice_c() count real channels exactly as for F32 (slices on multiples of 32 channels).  A K-step of the LDS-DMA conv kernels (128
 // bytes per pixel row) is then one channel group, and hi*hi + hi*lo + lo*hi runs as three bf16 MFMAs on the same staged bytes
-// (rtd_config.precision = RTD_PREC_BF16X3: fp32-grade products at 3/16 of the fp32 MFMA cost).
-enum DType : int { BF16 = 0, F32 = 1, U8 = 2, I32 = 3, BF16X2 = 4 };
-constexpr int SPLIT_GROUP = 32;   // channels per [hi | lo] group of a BF16X2 tensor
+// (rtd_config.precision = RTD_PREC_F16X3: fp32-grade products at 3/16 of the fp32 MFMA cost).
+enum DType : int { BF16 = 0, F32 = 1, U8 = 2, I32 = 3, F16X2 = 4 };
+constexpr int SPLIT_GROUP = 32;   // channels per [hi | lo] group of a F16X2 tensor
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GELU = 3 };
 enum ResMode : int { RES_NONE = 0, RES_PRE = 1, RES_POST = 2 };
 
@@ -23,6 +23,13 @@ inline size_t dtype_size(int dt) { return dt == BF16 ? 2 : (dt == U8 ? 1 : 4); }
 typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// element type of a pair tensor (F16X2 / "f16x3" engine): IEEE fp16.  hi = fp16(x), lo = fp16(x - hi): 22 significant bits for
+// |x| >= 2^-3, an ABSOLUTE error <= 2^-25 below that (lo goes subnormal; gfx950's matrix cores keep fp16 subnormal operands -
+// tools/f16_denorm_probe.hip), saturating at +-65504.  Round 2 carried bf16 pairs (2^-17 relative): measured 6x further from the fp32
+// reference on R101 1280-px frames (tools/pair_sim.py), where 1e-2 px is 7.8e-6 of the frame.
+typedef _Float16 sp16;
+typedef _Float16 sp16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sp16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -35,7 +42,7 @@ struct Tensor {
   int64_t ld = 0;
   int64_t bstride = 0;
   int64_t pixels() const { return (int64_t)n * h * w; }
-  Tensor slice_c(int c0, int cn) const {   // BF16X2: c0 must be a multiple of SPLIT_GROUP (group g lives at byte 128 g)
+  Tensor slice_c(int c0, int cn) const {   // F16X2: c0 must be a multiple of SPLIT_GROUP (group g lives at byte 128 g)
     Tensor t = *this;
     t.p = (char*)p + (size_t)c0 * dtype_size(dt);
     t.c = cn;
@@ -66,13 +73,46 @@ struct Error : std::runtime_error {
 // ------------------------------------------------------------------------------------------
 // kernel launch wrappers (implemented in conv_igemm.hip / ops.hip)
 // ------------------------------------------------------------------------------------------
-// per-engine scratch for the in-launch split-K reduction of conv_igemm_ws_kernel (shared by all layers: launches on one
-// stream are sequential, every launch leaves the tickets at zero)
+// Dispatch switches of the conv family (rtd_debug_option names in the comments).  A handle SNAPSHOTS the process-wide template
+// (conv_opts_template(), which rtd_debug_option edits) at rtd_create and every launch of its plans carries that snapshot
+// (ConvArgs::opts): a later rtd_debug_option call, or the settings another handle was created with, cannot change what a live handle
+// runs.  The kernel-level entry points (rtd_op_*, rtd_bench_*) read the template at call time.
+struct ConvOpts {
+  // ---- bf16 / fp32 operands
+  int conv_mode = 0;          // 0 auto; test / A-B modes: 1 = register-staged fallback kernel only, 3 / 4 = wave-specialised tile with 4 / 2 stages
+                              // everywhere, 7 = 256-pixel tile, 8 = A-stationary kernel, 9 = streaming kernels on any grid, 10 = 128 x 64 tile
+  int glds_min_blocks = 4;    // bf16: smallest grid of 128 x 128 tiles the LDS-DMA kernels take (fp32: 512, fixed)
+  int glds_min_n = 128;       // bf16: smallest Cout the LDS-DMA kernels take (64 measured slower on the stage-0 reduce convs: 45 vs 42 us)
+  int wsa_min_ntn = 8;        // A-stationary kernel from this many channel tiles on (0 = never)
+  int ws2_min_blocks = 257;   // grids that do not fit one block per CU run the 2-stage kernel at 2 blocks per CU
+  int ws64_max_blocks = 160;  // 128 x 128-tile grids below this take the 128 x 64 tile (0 = never)
+  int ws256_min_blocks = 0;   // 256-pixel tiles from this many blocks on (0 = only under ConvArgs::prefer256)
+  int reg_epilogue = 1;       // residual-free bf16 tiles finish in registers
+  int conv_reg = 3;           // direct 3x3 kernels for the narrow layers (bit 1: the 64-channel pair kernel)
+  int conv_stream = 1;        // streaming 1x1 kernels for the thin wide-grid layers (bf16)
+  int stream_min_tiles = 2048;
+  int stream2 = 1;            // ... for the reducing K = 256 layers
+  int stream2_max_n = 2048;
+  int stream_slab = 1;        // 0 = accumulator-shaped global accesses
+  int prefetch = 1;           // 0 = launches ignore ConvArgs::pf
+  int glds_drop = 0;          // timing-only probes (results wrong): 1 = x descriptor has 0 records, 2 = w, 4 = no DMA at all, 32 = block stamps
+  // ---- pair (F16X2) operands
+  int split_ws2_min_blocks = 257;
+  int split_ws64_max_blocks = 160;
+  int split_flex = 1;             // flexible tile heights (conv_igemm_wsf_kernel) on grids of <= split_flex_small_max 128 x 128 tiles
+  int split_flex_min_nk = 4;      // ... from this many K-steps on (same-box sweep, R50 bs 8: 16 / 8 / 4 / 2 -> 4.884 / 4.878 / 4.854 / 4.866 ms)
+  int split_flex_small_max = 200; // (sweep 128 / 200 / 256 / 400 -> 4.816 / 4.776 / 4.779 / 4.777 ms per step)
+  int split_sx = 3;               // streaming pair kernel: 0 off, 1 = K = 64 (+ 64) -> 256 (stage 0), 2 = also K = 128 (stage 1), 3 = also K = 256 -> N >= 1024
+                                  // without a residual (value projection), 4 = also with a residual from 40^2 maps on (51.5 vs 39.5 us on the tiled kernel: off)
+  int split_k2 = 1;               // two-pass split-K on long-K layers with few tiles per image
+};
+ConvOpts& conv_opts_template();
+bool conv_set_option(const char* name, int value);   // edits the template; false = not a conv option
+
+// scratch of one plan for the two-pass split-K of the pair kernels (fp32 partial sums); launches on one stream are sequential
 struct ConvWorkspace {
   float* slab = nullptr;
   size_t slab_bytes = 0;
-  unsigned* cnt = nullptr;
-  size_t cnt_entries = 0;
 };
 
 struct ConvArgs {
@@ -95,12 +135,13 @@ struct ConvArgs {
   const float* next_bias = nullptr;
   Tensor next_y;                    // [B,OH,OW,64]
   int next_kpad = 0, next_act = ACT_NONE;
-  int prefer256 = 0;   // throughput profile (rtd_config.profile): take the 256-pixel tile from 100 blocks on
+  int prefer256 = 0;   // throughput profile (rtd_config.profile): take the 256-pixel tile from 100 blocks on (bf16 / fp32 operands)
+  const ConvOpts* opts = nullptr;   // the handle's snapshot of the dispatch switches; nullptr = the process-wide template
   Tensor y;            // output [B,OH,OW,N] (view)
   int KH = 1, KW = 1, stride = 1, pad = 0;
   int Kpad = 0, Npad = 0;
   int act = ACT_NONE, res_mode = RES_NONE;
-  ConvWorkspace ws;    // optional: enables split-K on small grids
+  ConvWorkspace ws;    // optional: enables the two-pass split-K (pair kernels)
   // optional: bytes the launch pulls towards the Infinity Cache for a LATER launch (the next layer's filter): one dword per
   // 128-byte line, spread over the grid, issued while the first tile is in flight (tools/conv_bench.py: cold filters cost the
   // K-heavy small-grid layers 5-13 us each; after a whole step of activation traffic they are cold in every step)
@@ -111,46 +152,16 @@ void launch_conv(const ConvArgs& a, hipStream_t s);
 bool conv_dual_supported(const ConvArgs& a);
 bool conv_next_supported(const ConvArgs& a);   // can `a` (shapes for ONE image) carry a fused following 1x1 conv (ConvArgs::next_*)?   // can this build's kernels run `a` with its second input? (the plan builder asks before fusing)
 int conv_kpad(int K);                 // padded filter row length the kernels expect
-int conv_kpad_split(int K);           // BF16X2 filter row length in bf16 elements (K real taps x channels)
-bool conv_split_supported(const ConvArgs& a);   // BF16X2 input: does the split kernel take this launch?
-void conv_set_split_ws2_min_blocks(int v);
-void conv_set_split_ws64_max_blocks(int v);
-void conv_set_split_kernel(int v);
-void conv_set_split_flex(int v);
-void conv_set_split_flex_min_nk(int v);
-void conv_set_split_flex_force(int v);
-void conv_set_split_flex_small_max(int v);
-void conv_set_split_persist(int v);
-void conv_set_split_sx(int v);
-void conv_set_split_k2(int v);
-void conv_set_split_persist_min_tiles(int v);
+int conv_kpad_split(int K);           // F16X2 filter row length in bf16 elements (K real taps x channels)
+bool conv_split_supported(const ConvArgs& a);   // F16X2 input: does the split kernel take this launch?
 int conv_npad(int N);
-void conv_set_force_v1(int v);      // A/B hook: 1 = never take the large-tile (v2) path
-void conv_set_glds_min_blocks(int v);
-void conv_set_splitk(int v);        // A/B hook: 0 = never split K
-void conv_set_glds_drop(int v);     // timing-only traffic probe (MI355X guide §7): drop one operand's DMA via a 0-record descriptor
-void conv_set_ws256_min_blocks(int v);   // A/B hook: grid size from which the 256-pixel tile is used
-void conv_set_reg(int v);           // A/B hook: 0 = no direct 3x3 kernel for the narrow layers
-void conv_set_stream(int v);        // A/B hook: 0 = no streaming 1x1 kernel for the thin wide-grid layers
-void conv_set_stream_min_tiles(int v);
-void conv_set_stream_slab(int v);
-void conv_set_stream2(int v);
-void conv_set_stream2_max_n(int v);
-void conv_set_glds_min_n(int v);    // A/B hook: smallest Cout the LDS-DMA kernels take (bf16)
-void conv_set_reg_epilogue(int v);   // A/B hook: 0 = every ws tile goes through the fp32 staging epilogue
-void conv_set_ws2_min_blocks(int v);
-void conv_set_ws64_max_blocks(int v);
-void conv_set_wsa_min_ntn(int v);
-void conv_set_prefetch(int v);      // A/B hook: 0 = launches ignore ConvArgs::pf
-void conv_set_mode(int v);          // A/B hook: 0 auto, 1 = v1 only, 2 = v1 + v2 (no LDS-DMA kernel)
-void conv_reset_options();          // every conv dispatch switch back to its default (rtd_debug_option "reset")
+size_t conv_split_slab_bytes(const ConvArgs& a);   // workspace the launch would use for its two-pass split-K (0 = it does not split)
 
 void launch_layernorm(const Tensor& x, const Tensor* res, const float* g, const float* b, const Tensor& y,
                       float eps, hipStream_t s);
 // y = a + b (b broadcast over batch when b.n == 1)
 void launch_add(const Tensor& a, const Tensor& b, const Tensor& y, hipStream_t s);
 void launch_maxpool3x3s2(const Tensor& x, const Tensor& y, hipStream_t s);
-void maxpool_set_v1(int v);
 void launch_upsample2x(const Tensor& x, const Tensor& y, hipStream_t s);
 void launch_avgpool2(const Tensor& x, const Tensor& y, hipStream_t s);
 // qk: [B,L,2*D] (q | k), v: [B,L,D] -> o [B,L,D]; softmax(q k^T / sqrt(hd)) v per head
@@ -243,14 +254,12 @@ struct DecArgs {
   float* logits;            // mode 2: [B*Q, C]
   void* out_bf16;           // mode 4: write the output tokens as bf16 here instead of fp32 hs_out (nullptr = fp32)
   float* stamps;            // diagnostic: [blocks][16] phase end times (10 ns units) or nullptr
-  int probe;                // timing probes (wrong results): bit 0 = every filter fragment read comes from one 64 KiB window (L2-hot filter)
   // weights
   DecLin o, offaw, op, fc1, fc2, bb0, bb1, bb2, qp0, qp1, qk, v, cls;
   DecLN ln1, ln2, ln3;
 };
 
 void launch_dec_layer(const DecArgs& a, hipStream_t s);
-void dec_set_pf(int v);
 
 // Query selection scores (HF:v2.py:1580-1586): per memory token LayerNorm(enc_output.fc) -> enc_score_head -> max over classes,
 // one launch; neither the normalised memory nor the class logits are written (the 300 selected rows are normalised again by
@@ -278,32 +287,36 @@ void launch_crop_resize(const CropBatch& cb, int n, int out_size, const float me
 
 void launch_f32_to(const float* src, void* dst, int dt, int64_t n, hipStream_t s);
 void launch_to_f32(const void* src, int dt, float* dst, int64_t n, hipStream_t s);
-// dense [rows][C] fp32 <-> BF16X2 rows (C % 32 == 0); `ld*` in channels
+// dense [rows][C] fp32 <-> F16X2 rows (C % 32 == 0); `ld*` in channels
 void launch_f32_to_split(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int C, hipStream_t s);
 void launch_split_to_f32(const void* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int C, hipStream_t s);
 
 #if defined(__HIPCC__)
-// ---- BF16X2 helpers: element offset (in bf16 units, from the tensor base) of the hi half of channel c of a pixel whose first
+// ---- F16X2 helpers: element offset (in bf16 units, from the tensor base) of the hi half of channel c of a pixel whose first
 // channel sits at channel offset `pix_off` (= pixel index * ld); the lo half is SPLIT_GROUP elements further
 __device__ __forceinline__ long long split_off(long long pix_off, int c) { return 2 * pix_off + ((c >> 5) << 6) + (c & 31); }
-__device__ __forceinline__ void split2(float v, bf16& hi, bf16& lo) {
-  hi = (bf16)v;
-  lo = (bf16)(v - (float)hi);
+__device__ __forceinline__ void split2(float v, sp16& hi, sp16& lo) {
+  v = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);   // saturate instead of inf (hi = inf would make lo = NaN)
+  hi = (sp16)v;
+  lo = (sp16)(v - (float)hi);
 }
-// 8 consecutive channels (c % 8 == 0) of a BF16X2 pixel <-> fp32
-__device__ __forceinline__ void split_load8(const bf16* base, long long pix_off, int c, float (&v)[8]) {
-  const bf16* q = base + split_off(pix_off, c);
-  const bf16x8 h = *(const bf16x8*)q, l = *(const bf16x8*)(q + SPLIT_GROUP);
+// the three products of a pair x pair contraction step are issued as a*b on these (fp32 accumulate): hi*lo + lo*hi + hi*hi
+__device__ __forceinline__ f32x4 mfma_pair16(const sp16x8& a, const sp16x8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma_pair32(const sp16x8& a, const sp16x8& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+// 8 consecutive channels (c % 8 == 0) of a F16X2 pixel <-> fp32
+__device__ __forceinline__ void split_load8(const sp16* base, long long pix_off, int c, float (&v)[8]) {
+  const sp16* q = base + split_off(pix_off, c);
+  const sp16x8 h = *(const sp16x8*)q, l = *(const sp16x8*)(q + SPLIT_GROUP);
 #pragma unroll
   for (int k = 0; k < 8; ++k) v[k] = (float)h[k] + (float)l[k];
 }
-__device__ __forceinline__ void split_store8(bf16* base, long long pix_off, int c, const float (&v)[8]) {
-  bf16* q = base + split_off(pix_off, c);
-  bf16x8 h, l;
+__device__ __forceinline__ void split_store8(sp16* base, long long pix_off, int c, const float (&v)[8]) {
+  sp16* q = base + split_off(pix_off, c);
+  sp16x8 h, l;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { bf16 a, b; split2(v[k], a, b); h[k] = a; l[k] = b; }
-  *(bf16x8*)q = h;
-  *(bf16x8*)(q + SPLIT_GROUP) = l;
+  for (int k = 0; k < 8; ++k) { sp16 a, b; split2(v[k], a, b); h[k] = a; l[k] = b; }
+  *(sp16x8*)q = h;
+  *(sp16x8*)(q + SPLIT_GROUP) = l;
 }
 // Reductions over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} (the 16-lane rows of a wave: an MFMA 16x16 accumulator's row groups)
 // on gfx950's row-swap VALU ops instead of two ds_bpermute round trips each: v_permlane16_swap exchanges odd rows of its first

@@ -18,6 +18,7 @@
 // staged global -> registers -> LDS (rows padded by one 16-byte access so ds_read_b128 is
 // conflict-free), next tile's global loads issued before the current tile's MFMAs.
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -52,8 +53,8 @@ struct ConvK {
   void* next_y;
   long long next_ldy, next_y_bstride;
   int next_kpad, next_act;
-  // BF16X2 operands (common.h): `split` = x / x2 / w are [32 hi | 32 lo] grouped bf16 and Cin, ldx, x_bstride, Kreal, Kpad, k2_start,
-  // ldx2, x2_bstride count bf16 ELEMENTS (twice the channels); y_split / res_split = the output / residual is a BF16X2 tensor, its
+  // F16X2 operands (common.h): `split` = x / x2 / w are [32 hi | 32 lo] grouped bf16 and Cin, ldx, x_bstride, Kreal, Kpad, k2_start,
+  // ldx2, x2_bstride count bf16 ELEMENTS (twice the channels); y_split / res_split = the output / residual is a F16X2 tensor, its
   // ldy / y_bstride (ldr / r_bstride) count channels as for fp32 and addresses go through split_off()
   int split = 0, y_split = 0, res_split = 0;
   int raw = 0;           // two-pass split-K: the tile kernels write bare fp32 partial sums (no bias) to slice `s` of ConvG::slab
@@ -304,12 +305,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
           for (int q = 0; q < 4; ++q) v[q] += rv[q];
         }
         if (a.y_split) {
-          bf16x4 oh, ol;
+          sp16x4 oh, ol;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { bf16 hi, lo; split2(v[q], hi, lo); oh[q] = hi; ol[q] = lo; }
-          bf16* yb = (bf16*)a.y + split_off(yoff, c);
-          *(bf16x4*)yb = oh;
-          *(bf16x4*)(yb + SPLIT_GROUP) = ol;
+          for (int q = 0; q < 4; ++q) { sp16 hi, lo; split2(v[q], hi, lo); oh[q] = hi; ol[q] = lo; }
+          sp16* yb = (sp16*)a.y + split_off(yoff, c);
+          *(sp16x4*)yb = oh;
+          *(sp16x4*)(yb + SPLIT_GROUP) = ol;
         } else if (a.y_f32) {
           f32x4 o = {v[0], v[1], v[2], v[3]};
           *(f32x4*)((float*)a.y + yoff + c) = o;
@@ -325,426 +326,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
 
 
 // ------------------------------------------------------------------------------------------------
-// v2: the large-tile path.  128 pixels x BN channels x 128 bytes of K per step (64 bf16 / 32 fp32),
-// LDS double-buffered (ONE barrier per K-step, next tile's global loads in flight under the MFMAs),
-// XCD-aware block order, and an epilogue staged through LDS so that every global store / residual
-// load is a coalesced 16-byte access along NHWC's channel dimension (a pixel's BN channels are one
-// contiguous 128-256 byte run) instead of 64 lanes x 8 bytes at a pixel stride.
-// Requires Cin % (128/sizeof(T)) == 0, N % 8 == 0 and 8-element aligned output / residual strides.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int BN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvK a) {
-  constexpr int BM = 128;
-  constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int BK = 128 / (int)sizeof(T);
-  constexpr int ROWB = 144;                      // 128 data bytes + one 16-byte pad (conflict-free ds_read_b128)
-  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
-  constexpr int WM = 64, WN = BN / 2, TM = 2, TN = WN / 32;
-  constexpr int STAGE = (BM + BN) * ROWB;
-  constexpr int SLD = BN + 4;                    // fp32 staging row (floats)
-  constexpr int KSUB = Mma<T>::KSUB;
-  typedef typename Mma<T>::Frag Frag;
-  static_assert(BM * SLD * 4 <= 2 * STAGE, "epilogue staging must fit in the operand buffers");
-
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wv = tid >> 6;
-  const int wm = wv & 1, wn = wv >> 1;
-  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD one
-  // contiguous run of tiles (neighbouring pixel tiles share halo rows and all N tiles of a pixel
-  // tile share the input tile in that XCD's L2).  Bijective for any grid size.
-  int wg;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int nt = wg % a.ntn, mt = wg / a.ntn;
-  const int m0 = mt * BM, n0 = nt * BN;
-
-  const int ch = tid & 7;                        // this thread's 16-byte chunk inside a tile row
-  const int row0 = tid >> 3;                     // its rows: row0 + 32*i
-  long long a_base[A_CH];
-  int a_iy0[A_CH], a_ix0[A_CH];
-#pragma unroll
-  for (int i = 0; i < A_CH; ++i) {
-    const int m = m0 + row0 + 32 * i;
-    if (m < a.M) {
-      const int b = m / a.OHW;
-      const int r = m - b * a.OHW;
-      const int oy = r / a.OW;
-      const int ox = r - oy * a.OW;
-      a_base[i] = (long long)b * a.x_bstride + ch * EPC;
-      a_iy0[i] = oy * a.stride - a.pad;
-      a_ix0[i] = ox * a.stride - a.pad;
-    } else {
-      a_base[i] = 0;
-      a_iy0[i] = -(1 << 28);
-      a_ix0[i] = -(1 << 28);
-    }
-  }
-  const T* __restrict__ xg = (const T*)a.x;
-  const T* __restrict__ wg_ = (const T*)a.w + (long long)(n0 + row0) * a.Kpad + ch * EPC;
-
-  uint4 areg[A_CH], breg[B_CH];
-  int kh = 0, kw = 0, c0 = 0;                    // tap / channel offset of the tile being LOADED (uniform)
-  auto load_tiles = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-        v = *(const uint4*)(xg + a_base[i] + ((long long)iy * a.W + ix) * a.ldx + c0);
-      areg[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) breg[i] = *(const uint4*)(wg_ + (long long)(32 * i) * a.Kpad + k0);
-    c0 += BK;
-    if (c0 >= a.Cin) {
-      c0 = 0;
-      if (++kw == a.KW) { kw = 0; ++kh; }
-    }
-  };
-  auto store_tiles = [&](int buf) {
-    char* sa = smem + buf * STAGE + row0 * ROWB + ch * 16;
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) *(uint4*)(sa + 32 * i * ROWB) = areg[i];
-    char* sb = sa + BM * ROWB;
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) *(uint4*)(sb + 32 * i * ROWB) = breg[i];
-  };
-
-  f32x16 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = a.Kpad / BK;
-  const int foff = (lane & 31) * ROWB + (lane >> 5) * 16;
-  load_tiles(0);
-  store_tiles(0);
-  __syncthreads();
-  for (int ks = 0; ks < nk; ++ks) {
-    const bool more = ks + 1 < nk;
-    if (more) load_tiles((ks + 1) * BK);
-    const char* sa = smem + (ks & 1) * STAGE + wm * WM * ROWB + foff;
-    const char* sb = smem + (ks & 1) * STAGE + (BM + wn * WN) * ROWB + foff;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {             // 4 x 32 bytes of K
-      Frag xf[TM], wf[TN];
-#pragma unroll
-      for (int j = 0; j < TM; ++j) xf[j] = *(const Frag*)(sa + j * 32 * ROWB + kk * 32);
-#pragma unroll
-      for (int i = 0; i < TN; ++i) wf[i] = *(const Frag*)(sb + i * 32 * ROWB + kk * 32);
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
-    }
-    if (more) store_tiles((ks + 1) & 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue phase 1: accumulators -> LDS as fp32 [pixel][channel] ---------------------------
-  float* st = (float*)smem;
-  {
-    const int h = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int pl = wm * WM + j * 32 + (lane & 31);
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          *(f32x4*)(&st[pl * SLD + wn * WN + i * 32 + 8 * g + 4 * h]) = v;
-        }
-    }
-  }
-  __syncthreads();
-  // ---- phase 2: 8 channels of one pixel per thread-iteration, coalesced along channels ----------
-  constexpr int CPP = BN / 8;                    // 8-channel chunks per pixel
-  constexpr int NIT = BM * CPP / 256;
-  const int c8 = tid % CPP;
-  const int c = n0 + c8 * 8;
-  if (c < a.N) {
-    const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
-    dispatch_act(a.act, [&](auto actc) {
-    constexpr int ACT = decltype(actc)::value;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int pl = (tid + it * 256) / CPP;
-      const int m = m0 + pl;
-      if (m >= a.M) continue;
-      const f32x4 s0 = *(const f32x4*)(&st[pl * SLD + c8 * 8]), s1 = *(const f32x4*)(&st[pl * SLD + c8 * 8 + 4]);
-      float v[8] = {s0[0] + b0[0], s0[1] + b0[1], s0[2] + b0[2], s0[3] + b0[3],
-                    s1[0] + b1[0], s1[1] + b1[1], s1[2] + b1[2], s1[3] + b1[3]};
-      const int b = m / a.OHW;
-      const int p = m - b * a.OHW;
-      float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (a.res_mode != RES_NONE) {
-        const long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
-        if (a.res_f32) {
-          const f32x4 t0 = *(const f32x4*)((const float*)a.res + roff), t1 = *(const f32x4*)((const float*)a.res + roff + 4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { rv[q] = t0[q]; rv[4 + q] = t1[q]; }
-        } else {
-          const bf16x8 t = *(const bf16x8*)((const bf16*)a.res + roff);
-#pragma unroll
-          for (int q = 0; q < 8; ++q) rv[q] = (float)t[q];
-        }
-      }
-      if (a.res_mode == RES_PRE) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += rv[q];
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = act_c<ACT>(v[q]);
-      if (a.res_mode == RES_POST) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += rv[q];
-      }
-      const long long yoff = (long long)b * a.y_bstride + (long long)p * a.ldy + c;
-      if (a.y_f32) {
-        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-        *(f32x4*)((float*)a.y + yoff) = o0;
-        *(f32x4*)((float*)a.y + yoff + 4) = o1;
-      } else {
-        bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-        *(bf16x8*)((bf16*)a.y + yoff) = o;
-      }
-    }
-    });
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// v3: the LDS-DMA path.  Same 128 x 128 x 128-byte tile and LDS-staged epilogue as v2, but both
-// operands go global -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR staging, no ds_write: in v2
-// the ds_write_b128 traffic of the register-staged tiles costs more LDS-pipe cycles than the MFMAs).
+// The LDS-DMA tile kernels (everything below the register-staged fallback above).  128-byte tile rows, both operands go
+// global -> LDS with `buffer_load_dwordx4 ... lds`: no VGPR staging and no ds_write (the ds_write_b128 traffic of register-staged
+// tiles costs more LDS-pipe cycles than the MFMAs).
 //  * one wave-instruction writes 1 KiB = 8 tile rows x 128 B linearly, so rows are unpadded and the
 //    bank-conflict swizzle lives on the SOURCE side: LDS slot s of row r holds the row's 16-byte
 //    chunk s ^ ((r >> 1) & 7); readers apply the same involution (conflict-free for ds_read_b128's
 //    16-lane groups, checked against the bank rule of MI355X_MICROARCH.md §LDS).
 //  * the im2col gather is the per-lane source offset; zero padding = an out-of-range buffer offset
 //    (the range check makes the DMA write zeros - probed with tools/glds_probe.hip).
-//  * 2 LDS buffers, one `vmcnt(0)` + barrier per K-step: tile k+1 streams in under tile k's MFMAs.
+//  * the epilogue is staged through LDS so that every global store / residual load is a coalesced 16-byte access along NHWC's
+//    channel dimension; XCD-aware bijective block order (neighbouring pixel tiles share halo rows in one XCD's L2).
 // ------------------------------------------------------------------------------------------------
 
 struct ConvG {
   ConvK k;
   unsigned x_bytes, w_bytes;   // extents of the two buffers from their base pointers (buffer descriptors)
-  unsigned x2_bytes;           // extent of the second input (ws kernel only)
+  unsigned x2_bytes;           // extent of the second input
   unsigned y_bytes;            // extent of the output (A-stationary kernel: buffer stores), 0 = not provided
-  int probe;                   // timing-only probes (results wrong): bit 2 = issue no DMA at all
-  // split-K (ws kernel): grid = tiles x splitk; every slice publishes its fp32 accumulators to `slab`, the block that
-  // draws the last ticket of a tile sums them and runs the epilogue
-  int splitk;
-  float* slab;                 // [tiles][splitk][128 x 128] fp32, fragment order
-  unsigned* cnt;               // [tiles] arrival tickets, zero between launches
+  int probe;                   // timing-only probes (results wrong): bit 2 = issue no DMA at all; bit 5 = block stamps into `slab`
+  int splitk;                  // pair kernels, two-pass split-K: the grid is splitk x tiles (1 = off), see launch_conv_split
+  float* slab;                 // diagnostics (probe bit 5): [blocks][8] stamps
 };
-
-template <typename T, int STAGES>
-__global__ __launch_bounds__(256, (STAGES == 2 ? 2 : 1)) void conv_igemm_glds_kernel(const ConvG g) {
-  const ConvK& a = g.k;
-  constexpr int BM = 128, BN = 128;
-  constexpr int ES = (int)sizeof(T);
-  constexpr int BK = 128 / ES;
-  constexpr int STAGE = (BM + BN) * 128;
-  constexpr int SLD = BN + 4;
-  constexpr int SMEM = (STAGES * STAGE > BM * SLD * 4) ? STAGES * STAGE : BM * SLD * 4;
-  typedef typename Mma<T>::Frag Frag;
-  __shared__ __attribute__((aligned(16))) char smem[SMEM];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wv = tid >> 6;
-  const int wm = wv & 1, wn = wv >> 1;
-  int wg;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int nt = wg % a.ntn, mt = wg / a.ntn;
-  const int m0 = mt * BM, n0 = nt * BN;
-
-  // ---- loader geometry: DMA instruction i covers tile rows [32 i, 32 i + 32); this lane's row / slot
-  const int lrow = wv * 8 + (lane >> 3);
-  const int chunk = (lane & 7) ^ ((wv * 4 + (lane >> 4)) & 7);     // source chunk for LDS slot (lane & 7)
-  int a_off[4], a_iy0[4], a_ix0[4], b_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + i * 32 + lrow;
-    if (m < a.M) {
-      const int b = m / a.OHW;
-      const int r = m - b * a.OHW;
-      const int oy = r / a.OW;
-      const int ox = r - oy * a.OW;
-      a_iy0[i] = oy * a.stride - a.pad;
-      a_ix0[i] = ox * a.stride - a.pad;
-      a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)a_iy0[i] * a.W + a_ix0[i]) * a.ldx) * ES) + chunk * 16;
-    } else {
-      a_iy0[i] = -(1 << 28);
-      a_ix0[i] = -(1 << 28);
-      a_off[i] = 0;
-    }
-    b_off[i] = (n0 + i * 32 + lrow) * a.Kpad * ES + chunk * 16;
-  }
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
-
-  int kh = 0, kw = 0, c0 = 0, k0 = 0;            // position of the tile being ISSUED (wave-uniform)
-  auto issue = [&](int buf) {
-    if (g.probe & 4) return;
-    char* sa = smem + buf * STAGE + wv * 1024;
-    const int delta = ((kh * a.W + kw) * (int)a.ldx + c0) * ES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-      const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      const unsigned vo = ok ? (unsigned)(a_off[i] + delta) : 0x80000000u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 4096), 16, vo, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sa + BM * 128 + i * 4096), 16, (unsigned)(b_off[i] + k0 * ES), 0, 0, 0);
-    k0 += BK;
-    c0 += BK;
-    if (c0 >= a.Cin) {
-      c0 = 0;
-      if (++kw == a.KW) { kw = 0; ++kh; }
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // fragment read offsets: row (lane & 31), chunk 2 kk + (lane >> 5), swizzled with ((row >> 1) & 7)
-  int foff[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 128 + (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
-
-  const int nk = a.Kpad / BK;
-  auto compute = [&](int buf) {
-    const char* sa = smem + buf * STAGE + wm * 64 * 128;
-    const char* sb = smem + buf * STAGE + (BM + wn * 64) * 128;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      Frag xf[2], wf[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) xf[j] = *(const Frag*)(sa + j * 4096 + foff[kk]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) wf[i] = *(const Frag*)(sb + i * 4096 + foff[kk]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
-    }
-  };
-  if constexpr (STAGES == 2) {
-    // 2 blocks per CU: the co-resident block covers this block's DMA latency
-    issue(0);
-    for (int ks = 0; ks < nk; ++ks) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile ks has landed (issued one iteration ago)
-      __syncthreads();                                    // ... for every wave; tile ks-1's buffer is free
-      if (ks + 1 < nk) issue((ks + 1) & 1);
-      compute(ks & 1);
-    }
-  } else {
-    // small grids (<= 1 block per CU): nothing else hides the DMA latency, so keep STAGES-1 tiles in
-    // flight.  Each wave issues 8 DMA instructions per tile -> counted vmcnt(8 * tiles still allowed in
-    // flight); raw s_barrier (a __syncthreads() would drain vmcnt to 0).
-    constexpr int AHEAD = STAGES - 1;
-    for (int t = 0; t < AHEAD && t < nk; ++t) issue(t);
-    for (int ks = 0; ks < nk; ++ks) {
-      const int younger = nk - 1 - ks;                   // tiles issued after tile ks (at most AHEAD-1 = 2 here)
-      if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                      // tile ks visible to all waves; buffer of tile ks-1 is free
-      if (ks + AHEAD < nk) issue((ks + AHEAD) % STAGES);
-      compute(ks % STAGES);
-    }
-  }
-  __syncthreads();                                      // all MFMA operand reads done: smem becomes the fp32 staging tile
-
-  float* st = (float*)smem;
-  {
-    const int h = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int pl = wm * 64 + j * 32 + (lane & 31);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-          *(f32x4*)(&st[pl * SLD + wn * 64 + i * 32 + 8 * q + 4 * h]) = v;
-        }
-    }
-  }
-  __syncthreads();
-  const int c8 = tid & 15;
-  const int c = n0 + c8 * 8;
-  if (c < a.N) {
-    const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
-    dispatch_act(a.act, [&](auto actc) {
-    constexpr int ACT = decltype(actc)::value;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int pl = (tid >> 4) + it * 16;
-      const int m = m0 + pl;
-      if (m >= a.M) continue;
-      const f32x4 s0 = *(const f32x4*)(&st[pl * SLD + c8 * 8]), s1 = *(const f32x4*)(&st[pl * SLD + c8 * 8 + 4]);
-      float v[8] = {s0[0] + b0[0], s0[1] + b0[1], s0[2] + b0[2], s0[3] + b0[3],
-                    s1[0] + b1[0], s1[1] + b1[1], s1[2] + b1[2], s1[3] + b1[3]};
-      const int b = m / a.OHW;
-      const int p = m - b * a.OHW;
-      float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (a.res_mode != RES_NONE) {
-        const long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
-        if (a.res_f32) {
-          const f32x4 t0 = *(const f32x4*)((const float*)a.res + roff), t1 = *(const f32x4*)((const float*)a.res + roff + 4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { rv[q] = t0[q]; rv[4 + q] = t1[q]; }
-        } else {
-          const bf16x8 t = *(const bf16x8*)((const bf16*)a.res + roff);
-#pragma unroll
-          for (int q = 0; q < 8; ++q) rv[q] = (float)t[q];
-        }
-      }
-      if (a.res_mode == RES_PRE) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += rv[q];
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = act_c<ACT>(v[q]);
-      if (a.res_mode == RES_POST) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += rv[q];
-      }
-      const long long yoff = (long long)b * a.y_bstride + (long long)p * a.ldy + c;
-      if (a.y_f32) {
-        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-        *(f32x4*)((float*)a.y + yoff) = o0;
-        *(f32x4*)((float*)a.y + yoff + 4) = o1;
-      } else {
-        bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-        *(bf16x8*)((bf16*)a.y + yoff) = o;
-      }
-    }
-    });
-  }
-}
 
 __device__ __forceinline__ bool g_reg_epilogue_ok(const ConvK& a) { return a.res_mode == RES_NONE && !a.y_f32 && a.reg_epi; }
 
@@ -835,28 +438,28 @@ __device__ __forceinline__ void ws_copy_out(const ConvK& a, const float* st, int
 }
 
 
-// BF16X2 output, tile already final in LDS as split rows ([pixel][2 BN bf16]: the tile's BN / 32 channel groups, each [32 hi | 32 lo],
+// F16X2 output, tile already final in LDS as split rows ([pixel][2 BN sp16]: the tile's BN / 32 channel groups, each [32 hi | 32 lo],
 // exactly the bytes of the pixel's slice in global memory): pure 16-byte moves, 4 BN bytes per pixel row.
 template <int BN, int ROWS = 128>
-__device__ __forceinline__ void ws_copy_out_split_rows(const ConvK& a, const bf16* sb, int SLB, int tid, int m0, int n0) {
+__device__ __forceinline__ void ws_copy_out_split_rows(const ConvK& a, const sp16* sb, int SLB, int tid, int m0, int n0) {
   constexpr int CH = 2 * BN / 8, RSTEP = 512 / CH, ITERS = (ROWS + RSTEP - 1) / RSTEP;
   const int ch = tid % CH;
   if (n0 + (ch >> 3) * SPLIT_GROUP >= a.N) return;               // whole 32-channel groups (N % 32 == 0)
   int m = m0 + tid / CH;
   const int b = m / a.OHW;
   int p = m - b * a.OHW;
-  long long yoff = 2 * ((long long)b * a.y_bstride + (long long)p * a.ldy + n0) + ch * 8;   // bf16 elements
-  const bf16* srow = sb + (tid / CH) * SLB + ch * 8;
+  long long yoff = 2 * ((long long)b * a.y_bstride + (long long)p * a.ldy + n0) + ch * 8;   // sp16 elements
+  const sp16* srow = sb + (tid / CH) * SLB + ch * 8;
   int row = tid / CH;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    if (m < a.M && (ROWS % RSTEP == 0 || row < ROWS)) *(bf16x8*)((bf16*)a.y + yoff) = *(const bf16x8*)srow;
+    if (m < a.M && (ROWS % RSTEP == 0 || row < ROWS)) *(sp16x8*)((sp16*)a.y + yoff) = *(const sp16x8*)srow;
     m += RSTEP; p += RSTEP; row += RSTEP; yoff += 2 * RSTEP * a.ldy; srow += RSTEP * SLB;
     while (p >= a.OHW) { p -= a.OHW; yoff += 2 * (a.y_bstride - (long long)a.OHW * a.ldy); }
   }
 }
 
-// Copy-out of the split kernels' fp32 staging tile: bias (+ residual: BF16X2 or fp32) -> activation -> BF16X2 or fp32 output, 8 channels
+// Copy-out of the split kernels' fp32 staging tile: bias (+ residual: F16X2 or fp32) -> activation -> F16X2 or fp32 output, 8 channels
 // per thread and iteration.  ldy / ldr count channels for either type (ConvK::y_split).
 template <int ITERS, int ACT, int BN, int ROWS = 128>
 __device__ __forceinline__ void ws_copy_out_sp(const ConvK& a, const float* st, int SLD, int tid, int m0, int n0, long long yoff = 0) {
@@ -882,7 +485,7 @@ __device__ __forceinline__ void ws_copy_out_sp(const ConvK& a, const float* st, 
       float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (a.res_mode != RES_NONE) {
         if (a.res_split) {
-          split_load8((const bf16*)a.res, rpix, c, rv);
+          split_load8((const sp16*)a.res, rpix, c, rv);
         } else {
           const f32x4 t0 = *(const f32x4*)((const float*)a.res + rpix + c), t1 = *(const f32x4*)((const float*)a.res + rpix + c + 4);
 #pragma unroll
@@ -900,7 +503,7 @@ __device__ __forceinline__ void ws_copy_out_sp(const ConvK& a, const float* st, 
         for (int q = 0; q < 8; ++q) v[q] += rv[q];
       }
       if (a.y_split) {
-        split_store8((bf16*)a.y, ypix, c, v);
+        split_store8((sp16*)a.y, ypix, c, v);
       } else {
         f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
         *(f32x4*)((float*)a.y + yoff + ypix + c) = o0;
@@ -921,33 +524,21 @@ __device__ __forceinline__ void ws_copy_out_sp(const ConvK& a, const float* st, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// v4: wave-specialised LDS-DMA kernel.  Same tile / swizzle / epilogue as v3, but 8 waves per block with
-// fixed roles: waves 0-3 only read fragments and issue MFMAs (one per SIMD, 64x64 outputs each), waves 4-7
-// only compute im2col offsets and issue the `buffer_load ... lds` DMA, STAGES-1 tiles ahead.  In v3 every
-// wave paid ~8 DMA issues (60-185 cycles each next to MFMAs, MI355X_MICROARCH.md cycle constants) per
-// 16 MFMAs; the `glds_drop=4` probe showed 25 % of the kernel was DMA issue.  Here the issue cost runs on
-// the loader waves beside the MFMA waves.  One s_barrier per K-step orders both roles:
+// Wave-specialised LDS-DMA kernel (bf16 / fp32 operands).  8 waves per block with fixed roles: waves 0-3 only read fragments and
+// issue MFMAs (one per SIMD, 64x64 outputs each), waves 4-7 only compute im2col offsets and issue the `buffer_load ... lds` DMA,
+// STAGES-1 tiles ahead: the DMA issue cost (60-185 cycles per instruction next to MFMAs, MI355X_MICROARCH.md cycle constants) runs
+// on the loader waves beside the MFMA waves.  One s_barrier per K-step orders both roles:
 //   loader : wait tile ks (counted vmcnt) | barrier | issue tile ks+STAGES-1
 //   compute:                                barrier | MFMA tile ks
-// ------------------------------------------------------------------------------------------------
-// DEEP (4 stages only): the MFMA waves hold the fragments of a WHOLE K-step in registers and read tile ks+1 from LDS
-// while the MFMAs of tile ks run, so no ds_read latency is exposed behind the barrier (tools/ingest_probe.hip: the L2 ->
-// LDS path sustains 115-150 GB/s per CU, 2.5x what the non-DEEP K-step takes in; its K-step is bound by the serial
-// ds_read -> MFMA chain after each barrier, not by the DMA).  Tiles land one barrier earlier: 2 tiles stay in flight.
 // BN = 64: a 128 pixel x 64 channel tile for grids that leave most CUs idle with 128 x 128 tiles (stage 3 / PAN at batch 8, nearly
 // everything at batch 1): twice the blocks, each MFMA wave owns 32 pixels x 64 channels (one pixel tile, two channel tiles), the
 // loaders stage 24 KiB per K-step.  Same K order per output, so a layer's results do not depend on which tile width ran it.
-// SPLIT (T = bf16): the operands are BF16X2 tensors.  To the loader they are bf16 tensors of twice the channels - a K-step's 128 bytes
-// per row are one channel group [32 hi | 32 lo] of the pixel / the filter row, same DMA, same swizzle, same LDS image - and the MFMA
-// waves combine the four 16-deep fragments of a K-step as hi*hi + hi*lo + lo*hi (6 MFMAs per accumulator tile and K-step instead of 4;
-// the dropped lo*lo is 2^-18 relative).  A K-step stages the same bytes for 1.5x the MFMAs of the bf16 kernel and covers 32 real
-// channels instead of 64.  The epilogue writes BF16X2 (or fp32) rows.
-template <typename T, int STAGES, bool DEEP = false, int BN = 128, bool SPLIT = false>
+// ------------------------------------------------------------------------------------------------
+template <typename T, int STAGES, int BN = 128>
 __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kernel(const ConvG g) {
   const ConvK& a = g.k;
   constexpr int BM = 128;
-  static_assert(BN == 128 || (BN == 64 && !DEEP), "tile widths");
-  static_assert(!SPLIT || (sizeof(T) == 2 && !DEEP), "split operands are bf16 pairs");
+  static_assert(BN == 128 || BN == 64, "tile widths");
   constexpr int TJ = BN == 128 ? 2 : 1;          // pixel tiles (32 rows) per MFMA wave; channel tiles per wave: always 2
   constexpr int NBI = BN / 32;                    // 32-row filter pieces per loader wave and K-step
   constexpr int PPT = 4 + NBI;                    // LDS-DMA pieces per loader wave and K-step (counted waits)
@@ -959,7 +550,6 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
   constexpr int SMEM = (STAGES * STAGE > BM * SLD * 4) ? STAGES * STAGE : BM * SLD * 4;
   constexpr int AHEAD = STAGES - 1;
   static_assert(STAGES >= 2 && STAGES <= 4, "counted waits below assume 1..3 tiles ahead");
-  static_assert(!DEEP || STAGES == 4, "DEEP issues 4 tiles ahead");
   typedef typename Mma<T>::Frag Frag;
   __shared__ __attribute__((aligned(16))) char smem[SMEM + 256];   // + the prefetch dummy
 
@@ -975,18 +565,13 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  // split-K: the slices of one tile are consecutive ids -> same XCD under the remap above (speed only)
-  const int slice = wg % g.splitk;
-  const int tile = wg / g.splitk;
-  const int nt = tile % a.ntn, mt = tile / a.ntn;
+  const int nt = wg % a.ntn, mt = wg / a.ntn;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int nk_all = a.Kpad / BK;
-  const int ks0 = (int)((long long)slice * nk_all / g.splitk), ks1 = (int)((long long)(slice + 1) * nk_all / g.splitk);
-  const int nk = ks1 - ks0;                                      // K-steps of this slice
+  const int nk = a.Kpad / BK;
 
   // diagnostic (glds_drop bit 5): block-level stamps [block][0..7] (shader clocks from kernel entry; [6],[7] = 100 MHz wall clock
   // at entry / exit): first tile landed, K loop done, staged, stores issued, stores complete
-  long long* stamps = ((g.probe & 32) && g.slab && blockIdx.x < 4096 && lane == 0 && g.splitk == 1) ? (long long*)g.slab + (size_t)blockIdx.x * 8 : nullptr;
+  long long* stamps = ((g.probe & 32) && g.slab && blockIdx.x < 4096 && lane == 0) ? (long long*)g.slab + (size_t)blockIdx.x * 8 : nullptr;
   const long long t_base = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
   if (stamps && wv == 0) stamps[6] = (long long)__builtin_amdgcn_s_memrealtime();
 
@@ -1004,7 +589,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
   const int c8 = tid % CH8;
   const int c = n0 + c8 * 8;
   bf16x8 rpre[4];
-  if (!SPLIT && a.res_mode != RES_NONE && !a.res_f32 && c < a.N) {
+  if (a.res_mode != RES_NONE && !a.res_f32 && c < a.N) {
     int m = m0 + tid / CH8;
     const int b = m / a.OHW;
     int p = m - b * a.OHW;
@@ -1058,14 +643,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x), 0, a.x2 ? g.x2_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
-    int k0 = ks0 * BK;                                            // first K element of this slice
-    int kh, kw, c0;
-    {
-      const int tap = k0 / a.Cin;
-      c0 = k0 - tap * a.Cin;
-      kh = tap / a.KW;
-      kw = tap - kh * a.KW;
-    }
+    int k0 = 0, kh = 0, kw = 0, c0 = 0;
     auto issue = [&](int buf) {
       if (g.probe & 4) return;
       char* sa = smem + buf * STAGE + w4 * 1024;
@@ -1094,24 +672,6 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
         if (++kw == a.KW) { kw = 0; ++kh; }
       }
     };
-    if constexpr (DEEP) {
-      // tile t lives in buffer t % 4.  Before barrier ks tile ks+1 must have landed (the MFMA waves read it during step
-      // ks); after barrier ks the buffer of tile ks (read during step ks-1, reads drained before the barrier) is refilled.
-      for (int t = 0; t < 4 && t < nk; ++t) issue(t);
-      if (nk >= 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      else if (nk == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (nk == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                 // tile 0 visible
-      for (int ks = 0; ks < nk; ++ks) {
-        const int younger = nk - 2 - ks;                            // tiles after ks+1 that exist (<= 2 of them are in flight)
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (ks + 4 < nk) issue(ks & 3);
-      }
-    } else {
     for (int t = 0; t < AHEAD && t < nk; ++t) issue(t);
     for (int ks = 0; ks < nk; ++ks) {
       const int younger = nk - 1 - ks;
@@ -1121,74 +681,6 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
       if (stamps && wv == 4 && ks == 0) stamps[0] = (long long)__builtin_amdgcn_s_memtime() - t_base;
       __builtin_amdgcn_s_barrier();
       if (ks + AHEAD < nk) issue((ks + AHEAD) % STAGES);
-    }
-    }
-  } else if constexpr (DEEP) {
-    // ---- MFMA role, whole-K-step fragment double buffering ------------------------------------------
-    int foff[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 128 + (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
-    Frag fx0[4][2], fw0[4][2], fx1[4][2], fw1[4][2];
-    const int xo = wm * 64 * 128, wo = (BM + wn * 64) * 128;
-    auto step = [&](Frag (&cx)[4][2], Frag (&cw)[4][2], Frag (&nx)[4][2], Frag (&nw)[4][2], int ks) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's reads of tile ks are in registers
-      __builtin_amdgcn_s_barrier();                                 // tile ks+1 visible; buffer of tile ks may be refilled
-      const bool more = ks + 1 < nk;
-      const char* sa = smem + ((ks + 1) & 3) * STAGE + xo;
-      const char* sb = smem + ((ks + 1) & 3) * STAGE + wo;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        if (more) {
-#pragma unroll
-          for (int j = 0; j < 2; ++j) nx[kk][j] = *(const Frag*)(sa + j * 4096 + foff[kk]);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) nw[kk][i] = *(const Frag*)(sb + i * 4096 + foff[kk]);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) Mma<T>::run(cw[kk][i], cx[kk][j], acc[i][j]);
-        __builtin_amdgcn_sched_barrier(0);                          // keep 4 reads : 4 MFMAs interleaved
-      }
-    };
-    __builtin_amdgcn_s_barrier();                                   // tile 0 visible
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fx0[kk][j] = *(const Frag*)(smem + xo + j * 4096 + foff[kk]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fw0[kk][i] = *(const Frag*)(smem + wo + i * 4096 + foff[kk]);
-    }
-    for (int ks = 0; ks < nk; ks += 2) {
-      step(fx0, fw0, fx1, fw1, ks);
-      if (ks + 1 >= nk) break;
-      step(fx1, fw1, fx0, fw0, ks + 1);
-    }
-  } else if constexpr (SPLIT) {
-    // ---- MFMA role, BF16X2 operands: 16-deep fragment kk of a K-step = channels 16 (kk & 1) .. +15 of the group, hi (kk < 2) or lo ----
-    int foff[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 128 + (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
-    for (int ks = 0; ks < nk; ++ks) {
-      __builtin_amdgcn_s_barrier();
-      const char* sa = smem + (ks % STAGES) * STAGE + wm * (32 * TJ) * 128;
-      const char* sb = smem + (ks % STAGES) * STAGE + (BM + wn * 64) * 128;
-#pragma unroll
-      for (int sh = 0; sh < 2; ++sh) {
-        Frag xh[TJ], xl[TJ], wh[2], wl[2];
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) { xh[j] = *(const Frag*)(sa + j * 4096 + foff[sh]); xl[j] = *(const Frag*)(sa + j * 4096 + foff[sh + 2]); }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { wh[i] = *(const Frag*)(sb + i * 4096 + foff[sh]); wl[i] = *(const Frag*)(sb + i * 4096 + foff[sh + 2]); }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) {
-            Mma<T>::run(wh[i], xh[j], acc[i][j]);
-            Mma<T>::run(wh[i], xl[j], acc[i][j]);
-            Mma<T>::run(wl[i], xh[j], acc[i][j]);
-          }
-      }
     }
   } else {
     // ---- MFMA role ---------------------------------------------------------------------------------
@@ -1222,110 +714,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
   if (stamps && wv == 0) stamps[1] = (long long)__builtin_amdgcn_s_memtime() - t_base;
   __syncthreads();                                 // every MFMA operand read is done: smem becomes the fp32 staging tile
 
-  if (g.splitk > 1) {
-    // ---- in-launch split-K reduction (MI355X guide §5 "Projection GEMM" item 2 / Guideline 16, counter form; no spinning):
-    // plain slab stores -> every storing wave drains vmcnt -> barrier -> ONE lane: agent release, ticket fetch_add ->
-    // the last arriver: agent acquire -> barrier -> plain slab loads.  Fragment-order slabs: each store / load
-    // instruction of a wave is one contiguous 1 KiB.
-    float* my = g.slab + ((size_t)tile * g.splitk + slice) * (BM * BN);
-    if (!loader) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-            *(f32x4*)(my + ((((i * TJ + j) * 4 + q) * 256) + w4 * 64 + lane) * 4) = v;
-          }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    unsigned* flag = (unsigned*)smem;
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      *flag = __hip_atomic_fetch_add(g.cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const unsigned ticket = *flag;
-    if (ticket != (unsigned)(g.splitk - 1)) return;            // not the last slice of this tile: done (whole block)
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(g.cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    }
-    __syncthreads();
-    if (!loader) {
-      for (int sl = 0; sl < g.splitk; ++sl) {
-        if (sl == slice) continue;
-        const float* other = g.slab + ((size_t)tile * g.splitk + sl) * (BM * BN);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const f32x4 v = *(const f32x4*)(other + ((((i * TJ + j) * 4 + q) * 256) + w4 * 64 + lane) * 4);
-#pragma unroll
-              for (int u = 0; u < 4; ++u) acc[i][j][4 * q + u] += v[u];
-            }
-      }
-    }
-    __syncthreads();                               // the ticket word in smem is dead before staging overwrites it
-  }
-
-  if constexpr (SPLIT) {
-    if (a.y_split && a.res_mode == RES_NONE) {
-      // bias + activation + hi/lo split on the accumulators, the tile's BF16X2 rows through LDS, plain copy-out
-      constexpr int SLB = 2 * BN + 8;
-      bf16* sb = (bf16*)smem;
-      if (!loader) {
-        const int h = lane >> 5;
-        dispatch_act(a.act, [&](auto actc) {
-          constexpr int ACT = decltype(actc)::value;
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const f32x4 bv = *(const f32x4*)(a.bias + n0 + wn * 64 + i * 32 + 8 * q + 4 * h);
-#pragma unroll
-              for (int j = 0; j < TJ; ++j) {
-                const int pl = wm * (32 * TJ) + j * 32 + (lane & 31);
-                bf16x4 oh, ol;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { bf16 hi, lo; split2(act_c<ACT>(acc[i][j][4 * q + e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
-                bf16* d = sb + pl * SLB + (wn * 2 + i) * 64 + 8 * q + 4 * h;
-                *(bf16x4*)d = oh;
-                *(bf16x4*)(d + SPLIT_GROUP) = ol;
-              }
-            }
-        });
-      }
-      __syncthreads();
-      ws_copy_out_split_rows<BN>(a, sb, SLB, tid, m0, n0);
-      return;
-    }
-    float* st = (float*)smem;
-    if (!loader) {
-      const int h = lane >> 5;
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        const int pl = wm * (32 * TJ) + j * 32 + (lane & 31);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-            *(f32x4*)(&st[pl * SLD + wn * 64 + i * 32 + 8 * q + 4 * h]) = v;
-          }
-      }
-    }
-    __syncthreads();
-    dispatch_act(a.act, [&](auto actc) { ws_copy_out_sp<CITERS, decltype(actc)::value, BN>(a, st, SLD, tid, m0, n0); });
-    return;
-  }
-  if (g_reg_epilogue_ok(a) && g.splitk == 1) {
+  if (g_reg_epilogue_ok(a)) {
     // no residual, bf16 output: bias + activation on the accumulators, bf16 rows through LDS (half the staging bytes), then a
     // plain copy-out - the fp32 staging + per-element epilogue was ~2 us of every launch
     constexpr int SLB = BN + 8;
@@ -1382,15 +771,15 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_ws_kern
 
 
 // ------------------------------------------------------------------------------------------------
-// v4x: the wave-specialised kernel for BF16X2 operands (the bf16x3 engine's convolution), its own function so that the MFMA
-// shape can be chosen: the loader role, the LDS image (128-byte rows = one [32 hi | 32 lo] channel group, source-side XOR swizzle) and
-// the barrier protocol are conv_igemm_ws_kernel's; the MFMA waves run hi*hi + hi*lo + lo*hi either on v_mfma_f32_32x32x16_bf16 (two
-// 16-deep halves of the group per K-step) or, M16, on v_mfma_f32_16x16x32_bf16 (one 32-deep step: lane l reads row l & 15, 16-byte
-// chunk l >> 4 of the hi half, chunk 4 + (l >> 4) of the lo half - conflict-free under the same swizzle).  Microbenchmarks with the DMA
-// switched off (tools/conv_bench.py --opt glds_drop --vals 0,4) show the MFMA-wave side, not the data movement, bounds this kernel
-// (3x3 256 -> 256 at 80^2: 133 us with, 113 us without any DMA), and on random data the chip's clock under MFMA load; the 16x16x32
-// shape holds a higher clock for the same flops (MI355X_MICROARCH.md, DVFS give-back item 7).
-template <int STAGES, int BN, bool M16>
+// The wave-specialised kernel for PAIR operands (F16X2 tensors: the f16x3 engine's convolution).  The loader role, the LDS image
+// (128-byte rows = one [32 hi | 32 lo] channel group, source-side XOR swizzle) and the barrier protocol are conv_igemm_ws_kernel's: to
+// the loader a pair tensor is a 16-bit tensor of twice the channels.  The MFMA waves run hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16
+// (one 32-deep step per K-step: lane l reads row l & 15, 16-byte chunk l >> 4 of the hi half, chunk 4 + (l >> 4) of the lo half -
+// conflict-free under the same swizzle); the dropped lo*lo term is 2^-22 relative.  Microbenchmarks with the DMA switched off
+// (tools/conv_bench.py --opt glds_drop --vals 0,4) show the MFMA-wave side, not the data movement, bounds this kernel (3x3 256 -> 256 at
+// 80^2: 133 us with, 113 us without any DMA), and on random data the chip's clock under MFMA load; the 16x16x32 shape holds a higher
+// clock than 32x32x16 for the same flops (measured +3.6 % end to end in round 2; MI355X_MICROARCH.md, DVFS give-back item 7).
+template <int STAGES, int BN>
 __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_kernel(const ConvG g) {
   const ConvK& a = g.k;
   constexpr int BM = 128;
@@ -1399,7 +788,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_ker
   constexpr int NBI = BN / 32;
   constexpr int PPT = 4 + NBI;
   constexpr int CH8 = BN / 8, RSTEP = 512 / CH8, CITERS = BM / RSTEP;
-  constexpr int BK = 64;                          // bf16 elements per K-step = 32 channels x (hi, lo)
+  constexpr int BK = 64;                          // sp16 elements per K-step = 32 channels x (hi, lo)
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int SLD = BN + 4;
   constexpr int SMEM = (STAGES * STAGE > BM * SLD * 4) ? STAGES * STAGE : BM * SLD * 4;
@@ -1428,22 +817,12 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_ker
   const int m0 = mt * BM, n0 = nt * BN;
   const int nk = a.Kpad / BK / g.splitk;
 
-  // accumulators: 32x32 tiles [channel tile][pixel tile] x 16, or 16x16 tiles [4 channel tiles][2 TJ pixel tiles] x 4 - 32 TJ floats per lane either way
-  f32x16 acc[M16 ? 1 : 2][M16 ? 1 : TJ];
-  f32x4 acc16[M16 ? 4 : 1][M16 ? 2 * TJ : 1];
-  if constexpr (M16) {
+  // accumulators: 16x16 tiles [4 channel tiles][2 TJ pixel tiles] x 4 floats
+  f32x4 acc16[4][2 * TJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2 * TJ; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  } else {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  }
+    for (int j = 0; j < 2 * TJ; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (!loader) prefetch_share(a, blockIdx.x, gridDim.x, tid, 256, smem + SMEM);
 
   if (loader) {
@@ -1477,7 +856,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_ker
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
     // K order: channel group outer, taps inner (the filter keeps its tap-major layout, only the walk changes).  With taps outer a pixel's 128-byte
     // group slice is re-read by the nine taps eight K-steps apart - 8 MB of other slices per XCD in between, more than its L2 holds: the 3x3 layers
-    // at 80^2 fetched their input 4-6 times from beyond L2.  Every BF16X2 tile kernel walks K the same way (one summation order per output).
+    // at 80^2 fetched their input 4-6 times from beyond L2.  Every F16X2 tile kernel walks K the same way (one summation order per output).
     // (one walk only: offered both at run time, hipcc merges the two mirror-image counters by selecting a POINTER to kh / kw / c0 and
     // keeps them in scratch memory - the loaders then run a scratch round trip per K-step and every layer is 40-60 % slower)
     const int nk_main = a.x2 ? a.k2_start / BK : nk;
@@ -1485,7 +864,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_ker
     auto issue = [&](int buf) __attribute__((always_inline)) {      // (called twice: left to the inliner's budget, its captures live in scratch)
       if (g.probe & 4) return;
       char* sa = smem + buf * STAGE + w4 * 1024;
-      int kf;                                                   // filter column of this K-step (bf16 elements)
+      int kf;                                                   // filter column of this K-step (sp16 elements)
       if (ksi >= nk_main) {
         const int d2 = (ksi - nk_main) * BK * 2;
         kf = a.k2_start + (ksi - nk_main) * BK;
@@ -1521,7 +900,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_ker
       __builtin_amdgcn_s_barrier();
       if (ks + AHEAD < nk) issue((ks + AHEAD) % STAGES);
     }
-  } else if constexpr (M16) {
+  } else {
     // ---- MFMA role, 16x16x32: one 32-deep step per K-step.  The wave's 8 filter fragments stay live; pixel fragments come tile by tile ----
     const int r16 = lane & 15, c4 = lane >> 4;
     const int sw = (r16 >> 1) & 7;
@@ -1530,44 +909,18 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_ker
       __builtin_amdgcn_s_barrier();
       const char* sa = smem + (ks % STAGES) * STAGE + wm * (32 * TJ) * 128;
       const char* sb = smem + (ks % STAGES) * STAGE + (BM + wn * 64) * 128;
-      bf16x8 wh[4], wl[4];
+      sp16x8 wh[4], wl[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { wh[i] = *(const bf16x8*)(sb + i * 2048 + foh); wl[i] = *(const bf16x8*)(sb + i * 2048 + fol); }
+      for (int i = 0; i < 4; ++i) { wh[i] = *(const sp16x8*)(sb + i * 2048 + foh); wl[i] = *(const sp16x8*)(sb + i * 2048 + fol); }
 #pragma unroll
       for (int j = 0; j < 2 * TJ; ++j) {
-        const bf16x8 xh = *(const bf16x8*)(sa + j * 2048 + foh), xl = *(const bf16x8*)(sa + j * 2048 + fol);
+        const sp16x8 xh = *(const sp16x8*)(sa + j * 2048 + foh), xl = *(const sp16x8*)(sa + j * 2048 + fol);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh, acc16[i][j], 0, 0, 0);
-          acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl, acc16[i][j], 0, 0, 0);
-          acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh, acc16[i][j], 0, 0, 0);
+          acc16[i][j] = mfma_pair16(wh[i], xh, acc16[i][j]);
+          acc16[i][j] = mfma_pair16(wh[i], xl, acc16[i][j]);
+          acc16[i][j] = mfma_pair16(wl[i], xh, acc16[i][j]);
         }
-      }
-    }
-  } else {
-    // ---- MFMA role, 32x32x16: fragment kk of a K-step = channels 16 (kk & 1) .. +15 of the group, hi (kk < 2) or lo ----
-    int foff[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 128 + (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
-    for (int ks = 0; ks < nk; ++ks) {
-      __builtin_amdgcn_s_barrier();
-      const char* sa = smem + (ks % STAGES) * STAGE + wm * (32 * TJ) * 128;
-      const char* sb = smem + (ks % STAGES) * STAGE + (BM + wn * 64) * 128;
-#pragma unroll
-      for (int sh = 0; sh < 2; ++sh) {
-        bf16x8 xh[TJ], xl[TJ], wh[2], wl[2];
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) { xh[j] = *(const bf16x8*)(sa + j * 4096 + foff[sh]); xl[j] = *(const bf16x8*)(sa + j * 4096 + foff[sh + 2]); }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { wh[i] = *(const bf16x8*)(sb + i * 4096 + foff[sh]); wl[i] = *(const bf16x8*)(sb + i * 4096 + foff[sh + 2]); }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[i], xh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[i], xl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[i], xh[j], acc[i][j], 0, 0, 0);
-          }
       }
     }
   }
@@ -1575,38 +928,27 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_ker
 
   // every accumulator group = 4 consecutive channels (cl..cl+3 inside the tile) of one pixel (row pl of the tile)
   auto for_each_group = [&](auto&& f) {
-    if constexpr (M16) {
-      const int r16 = lane & 15, c4 = lane >> 4;
+    const int r16 = lane & 15, c4 = lane >> 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2 * TJ; ++j) f(wn * 64 + 16 * i + 4 * c4, wm * (32 * TJ) + 16 * j + r16, acc16[i][j]);
-    } else {
-      const int h = lane >> 5;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j)
-            f(wn * 64 + i * 32 + 8 * q + 4 * h, wm * (32 * TJ) + j * 32 + (lane & 31), f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]});
-    }
+      for (int j = 0; j < 2 * TJ; ++j) f(wn * 64 + 16 * i + 4 * c4, wm * (32 * TJ) + 16 * j + r16, acc16[i][j]);
   };
   if (a.y_split && a.res_mode == RES_NONE) {
-    // bias + activation + hi/lo split on the accumulators, the tile's BF16X2 rows through LDS, plain copy-out
+    // bias + activation + hi/lo split on the accumulators, the tile's F16X2 rows through LDS, plain copy-out
     constexpr int SLB = 2 * BN + 8;
-    bf16* sb = (bf16*)smem;
+    sp16* sb = (sp16*)smem;
     if (!loader) {
       dispatch_act(a.act, [&](auto actc) {
         constexpr int ACT = decltype(actc)::value;
         for_each_group([&](int cl, int pl, const f32x4& v) {
           const f32x4 bv = *(const f32x4*)(a.bias + n0 + cl);
-          bf16x4 oh, ol;
+          sp16x4 oh, ol;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { bf16 hi, lo; split2(act_c<ACT>(v[e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
-          bf16* d = sb + pl * SLB + ((cl >> 5) << 6) + (cl & 31);
-          *(bf16x4*)d = oh;
-          *(bf16x4*)(d + SPLIT_GROUP) = ol;
+          for (int e = 0; e < 4; ++e) { sp16 hi, lo; split2(act_c<ACT>(v[e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
+          sp16* d = sb + pl * SLB + ((cl >> 5) << 6) + (cl & 31);
+          *(sp16x4*)d = oh;
+          *(sp16x4*)(d + SPLIT_GROUP) = ol;
         });
       });
     }
@@ -1622,7 +964,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_ker
 
 
 // ------------------------------------------------------------------------------------------------
-// v4f: the BF16X2 kernel on a tile of FLEXIBLE height: MT pixel tiles of 16 rows (MT = 4 .. 13: 64 .. 208 pixels) x BN channels.
+// v4f: the F16X2 kernel on a tile of FLEXIBLE height: MT pixel tiles of 16 rows (MT = 4 .. 13: 64 .. 208 pixels) x BN channels.
 // The MFMA-bound layers lose ~20 % to tile-count quantization with fixed 128 x 128 tiles (3x3 256 -> 256 at 80^2 = 800 tiles takes as long
 // as 1014 tiles would: tools/conv_bench.py --only quant; 40^2 maps give 200 tiles for 256 CUs, 20^2 maps 100).  Here the host picks the
 // tile height so that the grid is close to a whole number of rounds of the chip (launch_conv_split), e.g. 208 x 128 for 80^2 x 256
@@ -1710,7 +1052,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsf_ker
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
     // K order: channel group outer, taps inner (the filter keeps its tap-major layout, only the walk changes).  With taps outer a pixel's 128-byte
     // group slice is re-read by the nine taps eight K-steps apart - 8 MB of other slices per XCD in between, more than its L2 holds: the 3x3 layers
-    // at 80^2 fetched their input 4-6 times from beyond L2.  Every BF16X2 tile kernel walks K the same way (one summation order per output).
+    // at 80^2 fetched their input 4-6 times from beyond L2.  Every F16X2 tile kernel walks K the same way (one summation order per output).
     // (one walk only: offered both at run time, hipcc merges the two mirror-image counters by selecting a POINTER to kh / kw / c0 and
     // keeps them in scratch memory - the loaders then run a scratch round trip per K-step and every layer is 40-60 % slower)
     const int nk_main = a.x2 ? a.k2_start / BK : nk;
@@ -1718,7 +1060,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsf_ker
     auto issue = [&](int buf) __attribute__((always_inline)) {      // (called twice: left to the inliner's budget, its captures live in scratch)
       if (g.probe & 4) return;
       char* sa = smem + buf * STAGE + w4 * 1024;
-      int kf;                                                   // filter column of this K-step (bf16 elements)
+      int kf;                                                   // filter column of this K-step (sp16 elements)
       if (ksi >= nk_main) {
         const int d2 = (ksi - nk_main) * BK * 2;
         kf = a.k2_start + (ksi - nk_main) * BK;
@@ -1762,22 +1104,22 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsf_ker
       __builtin_amdgcn_s_barrier();
       const char* sa = smem + (ks % STAGES) * STAGE;
       const char* sb = sa + (AROWS + w4 * (BN / 4)) * 128;
-      bf16x8 wh[CT], wl[CT];
+      sp16x8 wh[CT], wl[CT];
 #pragma unroll
-      for (int i = 0; i < CT; ++i) { wh[i] = *(const bf16x8*)(sb + i * 2048 + foh); wl[i] = *(const bf16x8*)(sb + i * 2048 + fol); }
+      for (int i = 0; i < CT; ++i) { wh[i] = *(const sp16x8*)(sb + i * 2048 + foh); wl[i] = *(const sp16x8*)(sb + i * 2048 + fol); }
       // pixel fragments of tile j + 1 are read while the MFMAs of tile j issue (pinned: with one MFMA wave per SIMD an LDS round trip in
       // front of every tile's MFMAs idles the matrix pipe)
-      bf16x8 xh[2], xl[2];
-      xh[0] = *(const bf16x8*)(sa + foh); xl[0] = *(const bf16x8*)(sa + fol);
+      sp16x8 xh[2], xl[2];
+      xh[0] = *(const sp16x8*)(sa + foh); xl[0] = *(const sp16x8*)(sa + fol);
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
-        if (j + 1 < MT) { xh[(j + 1) & 1] = *(const bf16x8*)(sa + (j + 1) * 2048 + foh); xl[(j + 1) & 1] = *(const bf16x8*)(sa + (j + 1) * 2048 + fol); }
+        if (j + 1 < MT) { xh[(j + 1) & 1] = *(const sp16x8*)(sa + (j + 1) * 2048 + foh); xl[(j + 1) & 1] = *(const sp16x8*)(sa + (j + 1) * 2048 + fol); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh[j & 1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl[j & 1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh[j & 1], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_pair16(wh[i], xh[j & 1], acc[i][j]);
+          acc[i][j] = mfma_pair16(wh[i], xl[j & 1], acc[i][j]);
+          acc[i][j] = mfma_pair16(wl[i], xh[j & 1], acc[i][j]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1793,18 +1135,18 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsf_ker
       for (int j = 0; j < MT; ++j) f(w4 * (BN / 4) + 16 * i + 4 * c4, 16 * j + r16, acc[i][j]);
   };
   if (a.y_split && a.res_mode == RES_NONE) {
-    bf16* sb = (bf16*)smem;
+    sp16* sb = (sp16*)smem;
     if (!loader) {
       dispatch_act(a.act, [&](auto actc) {
         constexpr int ACT = decltype(actc)::value;
         for_each_group([&](int cl, int pl, const f32x4& v) {
           const f32x4 bv = *(const f32x4*)(a.bias + n0 + cl);
-          bf16x4 oh, ol;
+          sp16x4 oh, ol;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { bf16 hi, lo; split2(act_c<ACT>(v[e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
-          bf16* d = sb + pl * SLB + ((cl >> 5) << 6) + (cl & 31);
-          *(bf16x4*)d = oh;
-          *(bf16x4*)(d + SPLIT_GROUP) = ol;
+          for (int e = 0; e < 4; ++e) { sp16 hi, lo; split2(act_c<ACT>(v[e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
+          sp16* d = sb + pl * SLB + ((cl >> 5) << 6) + (cl & 31);
+          *(sp16x4*)d = oh;
+          *(sp16x4*)(d + SPLIT_GROUP) = ol;
         });
       });
     }
@@ -1816,307 +1158,6 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsf_ker
   if (!loader) for_each_group([&](int cl, int pl, const f32x4& v) { *(f32x4*)(&st[pl * SLD + cl]) = v; });
   __syncthreads();
   dispatch_act(a.act, [&](auto actc) { ws_copy_out_sp<CITERS, decltype(actc)::value, BN, BM>(a, st, SLD, tid, m0, n0, yoff); });
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// v4p: PERSISTENT BF16X2 kernel with three wave roles.  A block of the fixed-tile kernels lives ~16 us for a short K loop (1x1 convs
-// with K = 256: 8 K-steps = 2.4 us of matrix-pipe time): the first DMA's round trip, the accumulator staging, the copy-out and the
-// block turnover are serial per block, and two co-resident blocks only overlap part of it (tools/conv_bench.py --only kfix: 800 tiles
-// cost 15 us + 1.6 us per K-step; the value projection, 6300 tiles, ran at 30 % matrix-pipe duty).  Here ONE block per CU walks a
-// contiguous range of tiles (112 pixels x 128 channels, the grid's tiles divided evenly over 256 blocks) and nothing is serial:
-//   loader waves (4)  run the flattened (tile, K-step) sequence through a 3-stage ring, two stages ahead, straight across tile
-//                     boundaries - the next tile's first stages are in flight while the current tile finishes;
-//   MFMA waves (4)    1 x 4 layout (all 7 pixel tiles x 32 channels each, v_mfma_f32_16x16x32_bf16, hi*hi + hi*lo + lo*hi); after a tile's
-//                     last K-step they drop the RAW fp32 accumulators into a staging tile (56 ds_write_b128 each) and start the next tile;
-//   store waves (4)   turn the previous tile's staging into output - bias, residual, activation, hi/lo split, 16-byte stores - in
-//                     slices between the K-step barriers of the tile the MFMA waves are computing (VALU and memory work beside MFMA work).
-// One s_barrier per K-step orders all three roles.  The store waves finish reading a staging tile before they arrive at the barrier of
-// the following tile's LAST K-step; the MFMA waves overwrite it only after that barrier.  K loops need >= 2 steps.
-template <int MT>
-__global__ __launch_bounds__(768, 3) void conv_igemm_wsp_kernel(const ConvG g, int total_tiles) {
-  const ConvK& a = g.k;
-  constexpr int BN = 128, STAGES = 3, AHEAD = 2, BK = 64;
-  constexpr int BM = MT * 16;
-  constexpr int AROWS = (BM + 31) / 32 * 32;
-  constexpr int NAI = AROWS / 32, NBI = BN / 32, PPT = NAI + NBI, CT = BN / 64;
-  constexpr int STAGE = (AROWS + BN) * 128;
-  constexpr int SLD = BN + 4;
-  constexpr int RING = STAGES * STAGE;
-  constexpr int SMEM = RING + BM * SLD * 4;
-  static_assert(SMEM + 256 <= 160 * 1024 && NAI <= 8, "LDS");
-  __shared__ __attribute__((aligned(16))) char smem[SMEM + 256];
-  float* const st = (float*)(smem + RING);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int role = wv >> 2, w4 = wv & 3;            // 0 MFMA, 1 loader, 2 store
-  const int nk = a.Kpad / BK;
-  const int t0 = (int)((long long)blockIdx.x * total_tiles / gridDim.x), t1 = (int)((long long)(blockIdx.x + 1) * total_tiles / gridDim.x);
-  const int nloc = t1 - t0;
-  const int total = nloc * nk;                      // flattened (tile, K-step) sequence of this block
-
-  if (role == 1) {
-    // ---- loader waves ---------------------------------------------------------------------------------
-    const int lrow = w4 * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((w4 * 4 + (lane >> 4)) & 7);
-    int a_off[NAI], a_iy0[NAI], a_ix0[NAI], b_off[NBI];
-    unsigned a2_off[8];
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x), 0, a.x2 ? g.x2_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
-    int k0 = 0, kh = 0, kw = 0, c0 = 0, iks = 0, itile = t0, istep = 0, cur_mt = -1;
-    auto setup = [&](int tile) {
-      const int nt = tile % a.ntn, mt = tile / a.ntn;
-      const int n0 = nt * BN;
-#pragma unroll
-      for (int i = 0; i < NBI; ++i) b_off[i] = (n0 + i * 32 + lrow) * a.Kpad * 2 + chunk * 16;
-      if (mt == cur_mt) return;                     // same pixels as the previous tile: only the filter rows move
-      cur_mt = mt;
-      const int m0 = mt * BM;
-#pragma unroll
-      for (int i = 0; i < NAI; ++i) {
-        const int row = i * 32 + lrow;
-        const int m = m0 + row;
-        a2_off[i] = 0x80000000u;
-        if (m < a.M && row < BM) {
-          const int b = m / a.OHW;
-          const int r = m - b * a.OHW;
-          const int oy = r / a.OW;
-          const int ox = r - oy * a.OW;
-          a_iy0[i] = oy * a.stride - a.pad;
-          a_ix0[i] = ox * a.stride - a.pad;
-          a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)a_iy0[i] * a.W + a_ix0[i]) * a.ldx) * 2) + chunk * 16;
-          if (a.x_up2) a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)(oy >> 1) * (a.W >> 1) + (ox >> 1)) * a.ldx) * 2) + chunk * 16;
-          if (a.x2) a2_off[i] = (unsigned)(((long long)b * a.x2_bstride + (long long)r * a.ldx2) * 2) + chunk * 16;
-        } else {
-          a_iy0[i] = -(1 << 28);
-          a_ix0[i] = -(1 << 28);
-          a_off[i] = 0;
-        }
-      }
-    };
-    auto issue_next = [&]() {
-      if (iks == 0) { setup(itile); k0 = 0; kh = 0; kw = 0; c0 = 0; }
-      if (!(g.probe & 4)) {
-        char* sa = smem + (istep % STAGES) * STAGE + w4 * 1024;
-        if (a.x2 && k0 >= a.k2_start) {
-          const int d2 = (k0 - a.k2_start) * 2;
-#pragma unroll
-          for (int i = 0; i < NAI; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, (lds_ptr_t)(sa + i * 4096), 16, a2_off[i] + ((a2_off[i] >> 31) ? 0u : (unsigned)d2), 0, 0, 0);
-        } else {
-          const int delta = ((kh * a.W + kw) * (int)a.ldx + c0) * 2;
-#pragma unroll
-          for (int i = 0; i < NAI; ++i) {
-            const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned vo = ok ? (unsigned)(a_off[i] + delta) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 4096), 16, vo, 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < NBI; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sa + AROWS * 128 + i * 4096), 16, (unsigned)(b_off[i] + k0 * 2), 0, 0, 0);
-      }
-      k0 += BK;
-      c0 += BK;
-      if (c0 >= a.Cin) {
-        c0 = 0;
-        if (++kw == a.KW) { kw = 0; ++kh; }
-      }
-      ++istep;
-      if (++iks == nk) { iks = 0; ++itile; }
-    };
-    for (int t = 0; t < AHEAD && t < total; ++t) issue_next();
-    for (int sidx = 0; sidx < total; ++sidx) {
-      // two stages ahead: when step sidx is needed, only step sidx + 1 (if it exists) may still be in flight
-      if (total - 1 - sidx >= 1) wait_vmcnt<PPT>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      if (sidx + AHEAD < total) issue_next();
-    }
-    __builtin_amdgcn_s_barrier();                   // F: the last tile is staged
-  } else if (role == 0) {
-    // ---- MFMA waves -----------------------------------------------------------------------------------
-    prefetch_share(a, blockIdx.x, gridDim.x, tid, 256, smem + SMEM);
-    const int r16 = lane & 15, c4 = lane >> 4;
-    const int sw = (r16 >> 1) & 7;
-    const int foh = r16 * 128 + ((c4 ^ sw) << 4), fol = r16 * 128 + (((c4 + 4) ^ sw) << 4);
-    int sidx = 0;
-    for (int i = 0; i < nloc; ++i) {
-      f32x4 acc[CT][MT];
-#pragma unroll
-      for (int ci = 0; ci < CT; ++ci)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) acc[ci][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int ks = 0; ks < nk; ++ks, ++sidx) {
-        __builtin_amdgcn_s_barrier();
-        if (g.probe & 128) continue;                                // probe: barriers only
-        const char* sa = smem + (sidx % STAGES) * STAGE;
-        const char* sb = sa + (AROWS + w4 * (BN / 4)) * 128;
-        bf16x8 wh[CT], wl[CT];
-#pragma unroll
-        for (int ci = 0; ci < CT; ++ci) { wh[ci] = *(const bf16x8*)(sb + ci * 2048 + foh); wl[ci] = *(const bf16x8*)(sb + ci * 2048 + fol); }
-        bf16x8 xh[2], xl[2];
-        xh[0] = *(const bf16x8*)(sa + foh); xl[0] = *(const bf16x8*)(sa + fol);
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-          if (j + 1 < MT) { xh[(j + 1) & 1] = *(const bf16x8*)(sa + (j + 1) * 2048 + foh); xl[(j + 1) & 1] = *(const bf16x8*)(sa + (j + 1) * 2048 + fol); }
-          __builtin_amdgcn_sched_barrier(0);
-          if (!(g.probe & 16)) {
-#pragma unroll
-          for (int ci = 0; ci < CT; ++ci) {
-            acc[ci][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ci], xh[j & 1], acc[ci][j], 0, 0, 0);
-            acc[ci][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ci], xl[j & 1], acc[ci][j], 0, 0, 0);
-            acc[ci][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ci], xh[j & 1], acc[ci][j], 0, 0, 0);
-          }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      // raw accumulators -> staging (the previous tile's staging was read out before the barrier of this tile's last K-step)
-#pragma unroll
-      for (int ci = 0; ci < CT; ++ci)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) *(f32x4*)(&st[(16 * j + r16) * SLD + w4 * (BN / 4) + 16 * ci + 4 * c4]) = acc[ci][j];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                   // F
-  } else {
-    // ---- store waves ----------------------------------------------------------------------------------
-    // Tile T is turned into output while the MFMA waves compute tile T + 1: pass q (16 rows; a thread owns 8 channels of one row per pass)
-    // runs in barrier interval q of that tile (several passes per interval when the K loop has fewer than MT + 1 steps).  Nothing in an
-    // interval waits for global memory: the tile's bias slice and the first pass' residual are requested one tile / one interval ahead.
-    const int ts = tid - 512;                       // 0..255: row ts / 16 (+ 16 per pass), 8-channel chunk ts % 16
-    const int c8 = ts & 15, r0 = ts >> 4;
-    dispatch_act(a.act, [&](auto actc) {
-      constexpr int ACT = decltype(actc)::value;
-      f32x4 bc0 = {0.f, 0.f, 0.f, 0.f}, bc1 = bc0, bn0 = bc0, bn1 = bc0;      // bias of the tile being copied / of the tile being computed
-      float rpre[8];                                 // residual of the next pass to run
-      bool rpre_ok = false;
-      long long rpre_y = 0;
-      // Tile geometry is CARRIED, not divided out per pass (an integer division is ~50 VALU instructions; four per pass cost more than the
-      // pass itself): `cp` describes the tile being copied, `nx` the tile being computed; advancing to the next tile of the block's
-      // contiguous range is an increment of the channel tile, or a step of BM pixels with the (image, pixel) pair wrapped.
-      struct TileGeo { int nt, mt, b, p; };          // p: pixel index (inside image b) of this thread's row r0 of pass 0
-      auto geo_init = [&](int tile) {
-        TileGeo t;
-        t.nt = tile % a.ntn; t.mt = tile / a.ntn;
-        const int m = min(t.mt * BM + r0, a.M - 1);
-        t.b = m / a.OHW; t.p = m - t.b * a.OHW;
-        return t;
-      };
-      auto geo_next = [&](TileGeo& t) {
-        if (++t.nt == a.ntn) {
-          t.nt = 0; ++t.mt; t.p += BM;
-          while (t.p >= a.OHW) { t.p -= a.OHW; ++t.b; }
-        }
-      };
-      TileGeo nx = geo_init(t0), cp = nx;
-      auto geom = [&](const TileGeo& t, int pass, long long& ypix, long long& rpix) -> bool {
-        const int m = t.mt * BM + pass * 16 + r0;
-        const bool ok = m < a.M && t.nt * BN + c8 * 8 < a.N;
-        int b = t.b, p = t.p + pass * 16;
-        while (p >= a.OHW) { p -= a.OHW; ++b; }
-        ypix = (long long)b * a.y_bstride + (long long)p * a.ldy;
-        rpix = (long long)b * a.r_bstride + (long long)p * a.ldr;
-        return ok;
-      };
-      auto res_load = [&](const TileGeo& t, int pass, float (&rv)[8], bool& ok, long long& ypix) {
-        long long rpix;
-        ok = geom(t, pass, ypix, rpix);
-        const int c = t.nt * BN + c8 * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) rv[e] = 0.f;
-        if (a.res_mode != RES_NONE && ok) {
-          if (a.res_split) {
-            split_load8((const bf16*)a.res, rpix, c, rv);
-          } else {
-            const f32x4 q0 = *(const f32x4*)((const float*)a.res + rpix + c), q1 = *(const f32x4*)((const float*)a.res + rpix + c + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { rv[e] = q0[e]; rv[4 + e] = q1[e]; }
-          }
-        }
-      };
-      auto finish = [&](const TileGeo& t, int pass, const float (&rv)[8], bool ok, long long ypix) {       // staging row + bias (+ residual) -> activation -> store
-        if (!ok || (g.probe & 8)) return;
-        const int c = t.nt * BN + c8 * 8;
-        const float* srow = st + (pass * 16 + r0) * SLD + c8 * 8;
-        const f32x4 s0 = *(const f32x4*)(srow), s1 = *(const f32x4*)(srow + 4);
-        float v[8] = {s0[0] + bc0[0], s0[1] + bc0[1], s0[2] + bc0[2], s0[3] + bc0[3], s1[0] + bc1[0], s1[1] + bc1[1], s1[2] + bc1[2], s1[3] + bc1[3]};
-        if (a.res_mode == RES_PRE) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rv[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = act_c<ACT>(v[e]);
-        if (a.res_mode == RES_POST) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rv[e];
-        }
-        if (a.y_split) {
-          split_store8((bf16*)a.y, ypix, c, v);
-        } else {
-          *(f32x4*)((float*)a.y + ypix + c) = f32x4{v[0], v[1], v[2], v[3]};
-          *(f32x4*)((float*)a.y + ypix + c + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        }
-      };
-      auto bias_load = [&](const TileGeo& t, f32x4& d0, f32x4& d1) {
-        const int c = t.nt * BN + c8 * 8;
-        if (c < a.N) { d0 = *(const f32x4*)(a.bias + c); d1 = *(const f32x4*)(a.bias + c + 4); }
-      };
-      // passes of interval ks: [pb(ks), pb(ks + 1)) with pb(k) = min(MT, k * ppi), ppi = passes per interval
-      const int slots = nk - 1;
-      const int ppi = (MT + slots - 1) / slots;
-      for (int i = 0; i < nloc; ++i) {
-        for (int ks = 0; ks < nk; ++ks) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's staging reads are in registers before anyone may overwrite the tile
-          __builtin_amdgcn_s_barrier();
-          if (g.probe & 64) continue;                               // probe: barriers only
-          if (ks == 0) bias_load(nx, bn0, bn1);                      // tile t0 + i: used one tile later
-          if (i > 0 && ks < slots) {                                 // tile t0 + i - 1 = cp
-            const int p0 = min(MT, ks * ppi), p1 = min(MT, p0 + ppi);
-            for (int ps = p0; ps < p1; ++ps) {
-              float rv[8];
-              bool ok;
-              long long ypix;
-              if (ps == p0) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) rv[e] = rpre[e];
-                ok = rpre_ok; ypix = rpre_y;
-              } else {
-                res_load(cp, ps, rv, ok, ypix);
-              }
-              if (ps + 1 == p1 && p1 < MT) res_load(cp, p1, rpre, rpre_ok, rpre_y);      // first pass of the next interval
-              finish(cp, ps, rv, ok, ypix);
-            }
-          }
-          if (ks == nk - 1) {                                        // tile t0 + i is staged after this interval: it becomes the tile to copy
-            bc0 = bn0; bc1 = bn1;
-            cp = nx;
-            geo_next(nx);
-            res_load(cp, 0, rpre, rpre_ok, rpre_y);
-          }
-        }
-      }
-      __builtin_amdgcn_s_barrier();                 // F
-      for (int ps = 0; ps < MT; ++ps) {
-        float rv[8];
-        bool ok;
-        long long ypix;
-        if (ps == 0) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) rv[e] = rpre[e];
-          ok = rpre_ok; ypix = rpre_y;
-        } else {
-          res_load(cp, ps, rv, ok, ypix);
-        }
-        finish(cp, ps, rv, ok, ypix);
-      }
-    });
-  }
 }
 
 
@@ -2500,80 +1541,64 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wsa_kernel(const ConvG g, i
 int conv_kpad(int K) { return (K + 63) / 64 * 64; }
 int conv_npad(int N) { return (N + 127) / 128 * 128; }
 
-static int g_glds_min_blocks = 4;     // bf16: the wave-specialised LDS-DMA tile beats the register-staged kernels down to a handful of tiles (bs 1: 3.03 -> 2.36 ms per frame vs the old threshold of 40); fp32 GEMMs: 512
-// In-launch split-K is implemented and correct (op tests run it) but OFF: on R50 bs8 it made every 100-200 tile layer
-// 1.3-2x SLOWER (tools/profile_layers.py --ab splitk: 28 -> 56 us on the 3x3 256ch convs): publishing a 64 KiB fp32 slab per
-// block behind an agent-scope release costs more than the shorter K loop saves (MI355X guide: splitk-seam 5-13 us).
-static int g_splitk_enable = 0;       // rtd_debug_option "splitk": 0 off (default), 1 auto (tiny grids with long K only: -3 % bs-1 latency, but a frame's
-                                      // results then depend on the batch size it ran in beyond bf16 noise), 2 aggressive (every grid < 512 tiles)
-static int g_glds_drop = 0;           // timing-only probe: 1 = x descriptor has 0 records, 2 = w, 3 = both (results wrong)
-static int g_conv_mode = 0;   // 0 auto, 1 = v1 only, 2 = v1 + v2 (no LDS-DMA path)
-static int g_force_v1 = 0;   // test / A-B hook (rtd_debug_option "conv_v1"): keep every layer on the v1 kernels
-void conv_set_force_v1(int v) { g_force_v1 = v; }
-void conv_set_glds_min_blocks(int v) { g_glds_min_blocks = v; }
-void conv_set_glds_drop(int v) { g_glds_drop = v; }
-void conv_set_splitk(int v) { g_splitk_enable = v; }
-void conv_set_mode(int v) { g_conv_mode = v; g_force_v1 = (v == 1); }
-static int g_ws256_min_blocks = 0;   // auto dispatch: 256-pixel tiles from this many blocks on (0 = never); rtd_debug_option "ws256_min_blocks"
-void conv_set_ws256_min_blocks(int v) { g_ws256_min_blocks = v; }
-static int g_glds_min_n = 128;   // 64 measured slower on the stage-0 reduce convs (45 vs 42 us)
-void conv_set_glds_min_n(int v) { g_glds_min_n = v; }
-static int g_wsa_min_ntn = 8;   // A-stationary kernel from this many channel tiles on (0 = never; 4 was slower on the 4-tile s1 shortcut); "wsa_min_ntn"
-void conv_set_wsa_min_ntn(int v) { g_wsa_min_ntn = v; }
-static int g_ws2_min_blocks = 257;   // grids that do not fit one block per CU run the 2-stage kernel at 2 blocks per CU (A/B: 512 was 2 % slower; "ws2_min_blocks")
-void conv_set_ws2_min_blocks(int v) { g_ws2_min_blocks = v; }
-static int g_reg_epilogue = 1;
-void conv_set_reg_epilogue(int v) { g_reg_epilogue = v; }
-static int g_ws64_max_blocks = 160;   // A/B hook: 128 x 128-tile grids below this take the 128 x 64 tile (0 = never)
-void conv_set_ws64_max_blocks(int v) { g_ws64_max_blocks = v; }
-static int g_prefetch = 1;    // A/B hook (rtd_debug_option "prefetch"): 0 = no next-layer filter prefetch
-void conv_set_prefetch(int v) { g_prefetch = v; }
+static ConvOpts g_conv_opts;
+ConvOpts& conv_opts_template() { return g_conv_opts; }
+bool conv_set_option(const char* name, int value) {
+  ConvOpts& o = g_conv_opts;
+  const struct { const char* n; int* p; } table[] = {
+      {"conv_mode", &o.conv_mode}, {"glds_min_blocks", &o.glds_min_blocks}, {"glds_min_n", &o.glds_min_n}, {"wsa_min_ntn", &o.wsa_min_ntn},
+      {"ws2_min_blocks", &o.ws2_min_blocks}, {"ws64_max_blocks", &o.ws64_max_blocks}, {"ws256_min_blocks", &o.ws256_min_blocks},
+      {"reg_epilogue", &o.reg_epilogue}, {"conv_reg", &o.conv_reg}, {"conv_stream", &o.conv_stream}, {"stream_min_tiles", &o.stream_min_tiles},
+      {"stream2", &o.stream2}, {"stream2_max_n", &o.stream2_max_n}, {"stream_slab", &o.stream_slab}, {"prefetch", &o.prefetch},
+      {"glds_drop", &o.glds_drop}, {"split_ws2_min_blocks", &o.split_ws2_min_blocks}, {"split_ws64_max_blocks", &o.split_ws64_max_blocks},
+      {"split_flex", &o.split_flex}, {"split_flex_min_nk", &o.split_flex_min_nk}, {"split_flex_small_max", &o.split_flex_small_max},
+      {"split_sx", &o.split_sx}, {"split_k2", &o.split_k2},
+  };
+  for (const auto& t : table)
+    if (strcmp(name, t.n) == 0) { *t.p = value; return true; }
+  return false;
+}
+static inline const ConvOpts& opts_of(const ConvArgs& a) { return a.opts ? *a.opts : g_conv_opts; }
+
+// LDS-DMA tile kernels on bf16 / fp32 operands; returns true when the launch was taken
 template <typename T>
-static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long w_bytes, unsigned y_bytes, unsigned x2_bytes, const ConvWorkspace& ws, hipStream_t s) {
-  if (!ok || ((g_conv_mode == 1 || g_conv_mode == 2) && !k.x2)) return false;
-  static_assert(sizeof(T) == 2 || sizeof(T) == 4, "bf16 / fp32");     // 5 = single-role LDS-DMA kernels (v3) for A/B
+static bool dispatch_glds(const ConvOpts& o, const ConvK& k, bool ok, bool prefer256, long long x_bytes, long long w_bytes, unsigned y_bytes, unsigned x2_bytes,
+                          const ConvWorkspace& ws, hipStream_t s) {
+  if (!ok || (o.conv_mode == 1 && !k.x2)) return false;
+  static_assert(sizeof(T) == 2 || sizeof(T) == 4, "bf16 / fp32");
   const long long mt = (k.M + 127) / 128, ntn = (k.N + 127) / 128;
-  // fp32 GEMMs (query-selection heads) may use a partly empty N tile: N >= 64 still beats the small-tile kernel
   // N >= 64 may use a partly empty N tile (the filter is padded to 128 rows): the N = 64 reduce convs of stage 0 are HBM-bound,
-  // and the LDS-DMA pipeline (2 blocks per CU) streams their input faster than the register-staged kernel (rtd_debug_option
-  // "glds_min_n" = 128 restores the old rule for A/B)
-  if (k.N < (sizeof(T) == 2 ? g_glds_min_n : 64) || mt * ntn < (sizeof(T) == 2 ? g_glds_min_blocks : 512) || x_bytes >= (1ll << 31) || w_bytes >= (1ll << 31)) return false;
+  // and the LDS-DMA pipeline (2 blocks per CU) streams their input faster than the register-staged kernel
+  if (k.N < (sizeof(T) == 2 ? o.glds_min_n : 64) || mt * ntn < (sizeof(T) == 2 ? o.glds_min_blocks : 512) || x_bytes >= (1ll << 31) || w_bytes >= (1ll << 31)) return false;
   ConvG g;
   g.k = k;
   g.k.ntn = (int)ntn;
-  g.probe = g_glds_drop;
-  g.splitk = 1; g.slab = nullptr; g.cnt = nullptr; g.y_bytes = 0;
-  g.x_bytes = (g_glds_drop & 1) ? 0u : (unsigned)x_bytes;
-  g.w_bytes = (g_glds_drop & 2) ? 0u : (unsigned)w_bytes;
+  g.probe = o.glds_drop;
+  g.splitk = 1; g.slab = (o.glds_drop & 32) ? ws.slab : nullptr; g.y_bytes = 0;
+  g.x_bytes = (o.glds_drop & 1) ? 0u : (unsigned)x_bytes;
+  g.w_bytes = (o.glds_drop & 2) ? 0u : (unsigned)w_bytes;
   g.x2_bytes = x2_bytes;
-  // small grids: 128 x 64 tiles double the blocks (rtd_debug_option "ws64_max_blocks": grids below this many 128 x 128 tiles; conv_mode 10
-  // forces it everywhere for the tests)
-  // (latency profile only: with other batches in flight the idle CUs are taken anyway and the narrower tile stages 1.5x the bytes per
-  // MFMA - measured +1.4 % for one handle, -1 % for three)
-  if ((g_conv_mode == 0 && !k.prefer256 && mt * ntn < g_ws64_max_blocks && k.N > 64) || g_conv_mode == 10) {
+  // small grids: 128 x 64 tiles double the blocks (latency profile only: with other batches in flight the idle CUs are taken anyway and
+  // the narrower tile stages 1.5x the bytes per MFMA - measured +1.4 % for one handle, -1 % for three); conv_mode 10 forces it for the tests
+  if ((o.conv_mode == 0 && !prefer256 && mt * ntn < o.ws64_max_blocks && k.N > 64) || o.conv_mode == 10) {
     const long long ntn64 = (k.N + 63) / 64;
     g.k.ntn = (int)ntn64;
-    g.slab = ws.slab;
-    hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, false, 64>), dim3((unsigned)(mt * ntn64)), dim3(512), 0, s, g);
+    hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 64>), dim3((unsigned)(mt * ntn64)), dim3(512), 0, s, g);
     return true;
   }
   if (k.x2) {
     // dual-input launches exist in the wave-specialised kernel only (every conv_mode): 4 stages on small grids, 2 above
-    g.slab = ws.slab;
-    if (mt * ntn < g_ws2_min_blocks) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+    if (mt * ntn < o.ws2_min_blocks) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
     else hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
     return true;
   }
-  // grids that fill every CU twice run 2 blocks/CU with a 2-deep pipeline; smaller grids get the
-  // whole LDS for one block and a 4-deep pipeline
-  if (sizeof(T) == 2 && g_wsa_min_ntn > 0 && (g_conv_mode == 0 || g_conv_mode == 8) && k.KH == 1 && k.KW == 1 && k.stride == 1 && k.pad == 0 &&
-      k.Kpad <= 256 && k.res_mode == RES_NONE && !k.y_f32 && y_bytes > 0 && ntn >= (g_conv_mode == 8 ? 1 : g_wsa_min_ntn)) {
+  if (sizeof(T) == 2 && o.wsa_min_ntn > 0 && (o.conv_mode == 0 || o.conv_mode == 8) && k.KH == 1 && k.KW == 1 && k.stride == 1 && k.pad == 0 &&
+      k.Kpad <= 256 && k.res_mode == RES_NONE && !k.y_f32 && y_bytes > 0 && ntn >= (o.conv_mode == 8 ? 1 : o.wsa_min_ntn)) {
     // channel tiles per block: keep >= ~1000 blocks when the grid allows (two rounds of one block per CU ... four), never more than 8
     int npb = (int)std::min<long long>(8, std::max<long long>(1, (mt * ntn) / 1024));
     npb = std::max(npb, std::min<int>((int)ntn, 3));
     npb = std::min<int>(npb, (int)ntn);
     const long long groups = (ntn + npb - 1) / npb;
-    g.slab = ws.slab;
     const dim3 grid((unsigned)(mt * groups));
     g.y_bytes = y_bytes;
     switch (k.Kpad / (128 / (int)sizeof(T))) {
@@ -2585,44 +1610,17 @@ static bool dispatch_glds(const ConvK& k, bool ok, long long x_bytes, long long 
   }
   {
     const long long mt256 = (k.M + 255) / 256;
-    const int min256 = k.prefer256 ? 100 : g_ws256_min_blocks;
-    if (g_conv_mode == 7 || (g_conv_mode == 0 && min256 > 0 && mt256 * ntn >= min256)) {
-      g.slab = ws.slab;
+    const int min256 = prefer256 ? 100 : o.ws256_min_blocks;
+    if (o.conv_mode == 7 || (o.conv_mode == 0 && min256 > 0 && mt256 * ntn >= min256)) {
       hipLaunchKernelGGL((conv_igemm_ws256_kernel<T>), dim3((unsigned)(mt256 * ntn)), dim3(512), 0, s, g);
       return true;
     }
   }
-  if (g_conv_mode == 3 || g_conv_mode == 4 || g_conv_mode == 6) {   // A/B: one wave-specialised variant everywhere (3 = 4 stages, 4 = 2 stages at 2 blocks/CU, 6 = DEEP)
-    if (g_conv_mode == 3) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
-    else if (g_conv_mode == 6) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, true>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
-    else hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
-    return true;
-  }
-  // measured (tools/profile_layers.py --ab conv_mode): loader/MFMA wave roles win at every grid size; >= 512 tiles run
-  // 2 blocks per CU with 2 stages, smaller grids 1 block per CU with 4 stages (3 tiles of DMA in flight)
-  if (g_conv_mode == 0) {
-    const long long tiles = mt * ntn;
-    const int nk = k.Kpad / (128 / (int)sizeof(T));
-    // small grids leave CUs idle and run long serial K loops: split K so that ~600 blocks exist (>= 4 K-steps per slice)
-    int sk = 1;
-    if (g_splitk_enable && ws.slab && tiles < 512) {
-      if (g_splitk_enable == 2) {                 // aggressive (tests / A-B): ~600 blocks, >= 4 K-steps per slice
-        sk = (int)((600 + tiles - 1) / tiles);
-        sk = std::min(sk, std::min(8, nk / 4));
-      } else if (tiles <= 32 && nk >= 16) {       // auto: only the handful-of-tiles, long-K layers of bs 1-2 (s3 3x3: 16 tiles x 72 steps)
-        sk = std::min(8, std::min((int)(192 / tiles), nk / 8));
-      }
-      sk = std::max(sk, 1);
-      if ((size_t)tiles * sk * (128 * 128 * 4) > ws.slab_bytes || (size_t)tiles > ws.cnt_entries) sk = 1;
-    }
-    g.splitk = sk; g.slab = ws.slab; g.cnt = ws.cnt;
-    const long long blocks = tiles * sk;
-    if (blocks < g_ws2_min_blocks) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)blocks), dim3(512), 0, s, g);
-    else hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)blocks), dim3(512), 0, s, g);
-    return true;
-  }
-  if (mt * ntn >= 512) hipLaunchKernelGGL((conv_igemm_glds_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((conv_igemm_glds_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(256), 0, s, g);
+  // loader / MFMA wave roles win at every grid size (tools/profile_layers.py): grids beyond one block per CU run 2 blocks per CU with
+  // 2 stages, smaller grids 1 block per CU with 4 stages (3 tiles of DMA in flight); conv_mode 3 / 4 force either
+  const bool four = o.conv_mode == 3 || (o.conv_mode != 4 && mt * ntn < o.ws2_min_blocks);
+  if (four) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+  else hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
   return true;
 }
 
@@ -2822,11 +1820,11 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv3x3_reg_kernel(const Conv
   }
 }
 
-// BF16X2 form of the direct 3x3 kernel for 32 input channels (stem.1 32 -> 32, stem.2 32 -> 64 at 320^2): a pixel's 128 bytes are
-// [32 hi | 32 lo], so the patch, its LDS-DMA and its swizzle are the bf16 kernel's CIN = 64 case; each wave keeps the hi AND the lo filter
+// F16X2 form of the direct 3x3 kernel for 32 input channels (stem.1 32 -> 32, stem.2 32 -> 64 at 320^2): a pixel's 128 bytes are
+// [32 hi | 32 lo], so the patch, its LDS-DMA and its swizzle are the sp16 kernel's CIN = 64 case; each wave keeps the hi AND the lo filter
 // of its 32 output channels in registers (36 fragments = 144 VGPRs) and runs hi*hi + hi*lo + lo*hi per tap (6 MFMAs per tap and row).
 // 8 waves per block, one block per CU (two 43 KiB patch buffers): COG channel groups x (8 / COG) waves, each wave 8 / (8 / COG) rows.
-// The epilogue writes the row's BF16X2 pixels ([32 hi | 32 lo] per 32-channel group) through the wave's slab, 16-byte stores.
+// The epilogue writes the row's F16X2 pixels ([32 hi | 32 lo] per 32-channel group) through the wave's slab, 16-byte stores.
 template <int COG>   // output channel groups of 32 (1 or 2)
 __global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a, unsigned x_bytes, unsigned y_bytes, int tiles_x, int tiles_y, int ntiles) {
   constexpr int NW = 8, NT_ = 512, WPG = NW / COG, RPW = 8 / WPG;    // waves per channel group, rows per wave
@@ -2846,20 +1844,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a
   const int nbase = grp * 32;
   const int h = lane >> 5;
 
-  bf16x8 wf[9][4];                                  // [tap][kc]: kc 0, 1 = hi channels 0-15 / 16-31, kc 2, 3 = lo
+  sp16x8 wf[9][4];                                  // [tap][kc]: kc 0, 1 = hi channels 0-15 / 16-31, kc 2, 3 = lo
   {
-    const bf16* wg = (const bf16*)a.w;
+    const sp16* wg = (const sp16*)a.w;
     constexpr int CPR = 9 * 64 / 8;
     for (int e = tid; e < 32 * COG * CPR; e += NT_) {
       const int row = e / CPR, ch = e - row * CPR;
-      *(bf16x8*)(patch + row * WROW + ch * 16) = *(const bf16x8*)(wg + (size_t)row * a.Kpad + ch * 8);
+      *(sp16x8*)(patch + row * WROW + ch * 16) = *(const sp16x8*)(wg + (size_t)row * a.Kpad + ch * 8);
     }
     __syncthreads();
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc)
-        wf[tap][kc] = *(const bf16x8*)(patch + (nbase + (lane & 31)) * WROW + (tap * 64 + kc * 16 + 8 * h) * 2);
+        wf[tap][kc] = *(const sp16x8*)(patch + (nbase + (lane & 31)) * WROW + (tap * 64 + kc * 16 + 8 * h) * 2);
     __syncthreads();
   }
 
@@ -2878,7 +1876,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a
       const int iy = y0 - 1 + py, ix = x0 - 1 + px;
       const bool ok = pi < NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
       const int src_chunk = (lane % CPP) ^ swz(pi);
-      const unsigned vo = ok ? (unsigned)(((long long)b * a.x_bstride + ((long long)iy * a.W + ix) * a.ldx) * 2 + src_chunk * 16) : 0x80000000u;   // ldx: bf16 elements
+      const unsigned vo = ok ? (unsigned)(((long long)b * a.x_bstride + ((long long)iy * a.W + ix) * a.ldx) * 2 + src_chunk * 16) : 0x80000000u;   // ldx: sp16 elements
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(patch + buf * PBUF + j * 1024), 16, vo, 0, 0, 0);
     }
   };
@@ -2906,14 +1904,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      bf16x8 xf[2][4];
-      auto read_tap = [&](bf16x8 (&dst)[4], int tap) {
+      sp16x8 xf[2][4];
+      auto read_tap = [&](sp16x8 (&dst)[4], int tap) {
         const int kh = tap / 3, kw = tap - kh * 3;
         const int pi = (r + kh) * PW + kw + (lane & 31);
         const int sw = swz(pi);
         const char* prow = pbuf + pi * ROWB;
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) dst[kc] = *(const bf16x8*)(prow + (((2 * kc + h) ^ sw) << 4));
+        for (int kc = 0; kc < 4; ++kc) dst[kc] = *(const sp16x8*)(prow + (((2 * kc + h) ^ sw) << 4));
       };
       read_tap(xf[0], 0);
 #pragma unroll
@@ -2922,9 +1920,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c], xf[tap & 1][c], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c], xf[tap & 1][c + 2], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c + 2], xf[tap & 1][c], acc, 0, 0, 0);
+          acc = mfma_pair32(wf[tap][c], xf[tap & 1][c], acc);
+          acc = mfma_pair32(wf[tap][c], xf[tap & 1][c + 2], acc);
+          acc = mfma_pair32(wf[tap][c + 2], xf[tap & 1][c], acc);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -2936,11 +1934,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 bv = *(const f32x4*)(a.bias + nbase + 8 * q + 4 * h);
-          bf16x4 oh, ol;
+          sp16x4 oh, ol;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { bf16 hi, lo; split2(act_c<ACT>(acc[4 * q + e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
-          *(bf16x4*)(sw_ + (lane & 31) * ROWO + (8 * q + 4 * h) * 2) = oh;
-          *(bf16x4*)(sw_ + (lane & 31) * ROWO + 64 + (8 * q + 4 * h) * 2) = ol;
+          for (int e = 0; e < 4; ++e) { sp16 hi, lo; split2(act_c<ACT>(acc[4 * q + e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
+          *(sp16x4*)(sw_ + (lane & 31) * ROWO + (8 * q + 4 * h) * 2) = oh;
+          *(sp16x4*)(sw_ + (lane & 31) * ROWO + 64 + (8 * q + 4 * h) * 2) = ol;
         }
       });
       __builtin_amdgcn_wave_barrier();
@@ -2968,7 +1966,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a
 //   * wave = (16-channel group, row half): its 16 x 576 filter slice, hi and lo, lives in 144 VGPRs as v_mfma_f32_16x16x32_bf16 A operands;
 //   * a patch-row fragment (one ds_read_b128 pair: hi, lo) serves up to three output rows (kh = patch row - output row): 72 fragment reads for
 //     216 MFMAs per wave and tile - the loop is MFMA-bound, not LDS-bound;
-//   * the tile's 128 x 64 outputs are collected in LDS as BF16X2 rows and stored row-shaped (16 lanes = one pixel's 256-byte run).
+//   * the tile's 128 x 64 outputs are collected in LDS as F16X2 rows and stored row-shaped (16 lanes = one pixel's 256-byte run).
 // Per output: taps in (kh, kw) order, channel groups inside a tap, lo-terms first - fixed per pixel, so batch size does not change a frame's bits.
 __global__ __launch_bounds__(512, 1) void conv3x3_reg_split64_kernel(const ConvK a, unsigned x_bytes, unsigned y_bytes, int tiles_x, int tiles_y, int ntiles) {
   constexpr int NW = 8;
@@ -2985,15 +1983,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_reg_split64_kernel(const ConvK
   const int cgp = wv & 3, rh = wv >> 2;           // 16-channel group, row half (output rows 4 rh .. 4 rh + 3)
   const int r16 = lane & 15, kq = lane >> 4;
 
-  bf16x8 wf[9][2][2];                             // [tap][32-channel group][hi / lo]
+  sp16x8 wf[9][2][2];                             // [tap][32-channel group][hi / lo]
   {
-    const bf16* wr = (const bf16*)a.w + (size_t)(16 * cgp + r16) * a.Kpad + 8 * kq;
+    const sp16* wr = (const sp16*)a.w + (size_t)(16 * cgp + r16) * a.Kpad + 8 * kq;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        wf[tap][c][0] = *(const bf16x8*)(wr + (tap * 2 + c) * 64);
-        wf[tap][c][1] = *(const bf16x8*)(wr + (tap * 2 + c) * 64 + 32);
+        wf[tap][c][0] = *(const sp16x8*)(wr + (tap * 2 + c) * 64);
+        wf[tap][c][1] = *(const sp16x8*)(wr + (tap * 2 + c) * 64 + 32);
       }
   }
   const f32x4 bv = *(const f32x4*)(a.bias + 16 * cgp + 4 * kq);
@@ -3012,7 +2010,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_reg_split64_kernel(const ConvK
       const int iy = y0 - 1 + py, ix = x0 - 1 + px;
       const bool ok = pi < NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
       const int src_chunk = (lane & 15) ^ (pi & 15);
-      const unsigned vo = ok ? (unsigned)(((long long)b * a.x_bstride + ((long long)iy * a.W + ix) * a.ldx) * 2 + src_chunk * 16) : 0x80000000u;   // ldx: bf16 elements
+      const unsigned vo = ok ? (unsigned)(((long long)b * a.x_bstride + ((long long)iy * a.W + ix) * a.ldx) * 2 + src_chunk * 16) : 0x80000000u;   // ldx: sp16 elements
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(patch + buf * PBUF + j * 1024), 16, vo, 0, 0, 0);
     }
   };
@@ -3036,17 +2034,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_reg_split64_kernel(const ConvK
     f32x4 acc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 xf[2][2][2];                             // [parity][group][hi / lo]
+    sp16x8 xf[2][2][2];                             // [parity][group][hi / lo]
     // fragment addresses are tile-invariant; recomputed per tile behind an opaque copy (hoisted out of the tile loop they cost 70 VGPRs and spill)
     int q0 = 4 * rh * PW + r16;
     asm volatile("" : "+v"(q0));
-    auto read_px = [&](bf16x8 (&dst)[2][2], int pr, int kw) {
+    auto read_px = [&](sp16x8 (&dst)[2][2], int pr, int kw) {
       const int pi = q0 + pr * PW + kw;
       const unsigned a0 = (unsigned)(pi << 8) | (unsigned)(((pi & 15) ^ kq) << 4);     // chunk kq of group 0, hi; the others differ in slot bits 2, 3
-      dst[0][0] = *(const bf16x8*)(pbuf + a0);
-      dst[0][1] = *(const bf16x8*)(pbuf + (a0 ^ 0x40));
-      dst[1][0] = *(const bf16x8*)(pbuf + (a0 ^ 0x80));
-      dst[1][1] = *(const bf16x8*)(pbuf + (a0 ^ 0xC0));
+      dst[0][0] = *(const sp16x8*)(pbuf + a0);
+      dst[0][1] = *(const sp16x8*)(pbuf + (a0 ^ 0x40));
+      dst[1][0] = *(const sp16x8*)(pbuf + (a0 ^ 0x80));
+      dst[1][1] = *(const sp16x8*)(pbuf + (a0 ^ 0xC0));
     };
     read_px(xf[0], 0, 0);
 #pragma unroll
@@ -3060,25 +2058,25 @@ __global__ __launch_bounds__(512, 1) void conv3x3_reg_split64_kernel(const ConvK
         if (kh >= 0 && kh <= 2) {
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
-            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh * 3 + kw][c][0], xf[s & 1][c][1], acc[r], 0, 0, 0);
-            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh * 3 + kw][c][1], xf[s & 1][c][0], acc[r], 0, 0, 0);
-            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh * 3 + kw][c][0], xf[s & 1][c][0], acc[r], 0, 0, 0);
+            acc[r] = mfma_pair16(wf[kh * 3 + kw][c][0], xf[s & 1][c][1], acc[r]);
+            acc[r] = mfma_pair16(wf[kh * 3 + kw][c][1], xf[s & 1][c][0], acc[r]);
+            acc[r] = mfma_pair16(wf[kh * 3 + kw][c][0], xf[s & 1][c][0], acc[r]);
           }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- epilogue: lane = pixel r16 of each of the wave's 4 rows, channels 16 cgp + 4 kq + (0..3) -> BF16X2 rows in LDS ----
+    // ---- epilogue: lane = pixel r16 of each of the wave's 4 rows, channels 16 cgp + 4 kq + (0..3) -> F16X2 rows in LDS ----
     dispatch_act(a.act, [&](auto actc) {
       constexpr int ACT = decltype(actc)::value;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        bf16x4 oh, ol;
+        sp16x4 oh, ol;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { bf16 hi, lo; split2(act_c<ACT>(acc[r][e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
+        for (int e = 0; e < 4; ++e) { sp16 hi, lo; split2(act_c<ACT>(acc[r][e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
         char* q = stage + ((4 * rh + r) * TW + r16) * SROWB + (cgp >> 1) * 128 + (16 * (cgp & 1) + 4 * kq) * 2;
-        *(bf16x4*)q = oh;
-        *(bf16x4*)(q + 64) = ol;
+        *(sp16x4*)q = oh;
+        *(sp16x4*)(q + 64) = ol;
       }
     });
     __syncthreads();
@@ -3094,12 +2092,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_reg_split64_kernel(const ConvK
   }
 }
 
-static int g_conv_reg = 3;    // A/B hook (rtd_debug_option "conv_reg"; bit 1: the 64-channel split kernel): 0 = narrow 3x3 layers stay on the implicit-GEMM kernels
-void conv_set_reg(int v) { g_conv_reg = v; }
-
 // returns true when the launch was taken by the direct kernel
-static bool dispatch_reg(const ConvK& k, const ConvArgs& a, long long x_bytes, hipStream_t s) {
-  if (!g_conv_reg || g_force_v1 || g_conv_mode != 0) return false;
+static bool dispatch_reg(const ConvOpts& o, const ConvK& k, const ConvArgs& a, long long x_bytes, hipStream_t s) {
+  if (!o.conv_reg || o.conv_mode != 0) return false;
   const Tensor& x = a.x;
   const Tensor& y = a.y;
   if (x.dt != BF16 || y.dt != BF16 || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1) return false;
@@ -3464,28 +2459,17 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 : 3) void conv1x1_strea
   });
 }
 
-static int g_conv_stream = 1;    // A/B hook (rtd_debug_option "conv_stream"): 0 = the thin 1x1 layers stay on the tiled kernels
-static int g_stream_min_tiles = 2048;
-static int g_stream2_max_n = 2048;   // A/B hook (rtd_debug_option "stream2_max_n"): widest layer the LDS-filter streaming kernel takes
-void conv_set_stream2_max_n(int v) { g_stream2_max_n = v; }
-static int g_stream2 = 1;        // A/B hook (rtd_debug_option "stream2"): 0 = the reducing 1x1 layers (K = 256) stay on the tiled kernels
-void conv_set_stream2(int v) { g_stream2 = v; }
-static int g_stream_slab = 1;    // A/B hook (rtd_debug_option "stream_slab"): 0 = accumulator-shaped global accesses
-void conv_set_stream_slab(int v) { g_stream_slab = v; }
-void conv_set_stream(int v) { g_conv_stream = v; }
-void conv_set_stream_min_tiles(int v) { g_stream_min_tiles = v; }
-
 // returns true when the launch was taken by the streaming kernel
-static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes, long long x2_bytes, hipStream_t s) {
+static bool dispatch_stream(const ConvOpts& o, const ConvK& k, const ConvArgs& a, long long x_bytes, long long x2_bytes, hipStream_t s) {
   const bool next = a.next_y.p != nullptr;                      // a fused following conv exists in this kernel only: no A/B switch applies
-  if (!next && (!g_conv_stream || g_force_v1 || (g_conv_mode != 0 && g_conv_mode != 9))) return false;
+  if (!next && (!o.conv_stream || (o.conv_mode != 0 && o.conv_mode != 9))) return false;
   const Tensor& x = a.x;
   const Tensor& y = a.y;
   const bool dual = a.x2.p != nullptr;
   if (a.x_up2 || x.dt != BF16 || y.dt != BF16 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0) return false;
   if (a.res_mode != RES_NONE && a.res.dt != BF16) return false;
   if (dual && !(x.c == 64 && a.x2.c == 64)) return false;
-  if (!dual && x.c == 256 && a.Kpad == 256 && (y.c == 64 || y.c % 128 == 0) && y.c <= g_stream2_max_n && g_stream2) {
+  if (!dual && x.c == 256 && a.Kpad == 256 && (y.c == 64 || y.c % 128 == 0) && y.c <= o.stream2_max_n && o.stream2) {
     // reducing layers: filter in LDS, a wave owns all channels of its pixels
     if (x.ld % 8 || y.ld % 8 || ((uintptr_t)y.p & 15)) return false;
     if (a.res_mode != RES_NONE && (a.res.ld % 8 || ((uintptr_t)a.res.p & 15))) return false;
@@ -3495,7 +2479,7 @@ static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes
     if (x_bytes >= (1ll << 31) || y_bytes >= (1ll << 31) || r_bytes >= (1ll << 31)) return false;
     const long long ntiles = ((long long)k.M + 31) / 32;
     const int ny = y.c <= 128 ? 1 : y.c / 128;                  // expanding layers (stage-2 c3: 256 -> 1024): 128 channels per block
-    if ((ntiles * ny < g_stream_min_tiles && g_conv_mode != 9) || ntiles >= (1ll << 30)) return false;
+    if ((ntiles * ny < o.stream_min_tiles && o.conv_mode != 9) || ntiles >= (1ll << 30)) return false;
     if (ny > 1) {
       // one 8-wave block per CU; whole rounds of wave tiles, so that no wave of a block has one tile more than another
       const long long rounds = (ntiles * ny + 2047) / 2048;
@@ -3527,7 +2511,7 @@ static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes
   const int NW = CG == 8 ? 8 : 4;
   const int PG = NW / CG;
   const long long ntiles = ((long long)k.M + 32 * PG - 1) / (32 * PG);
-  if ((ntiles * NW < g_stream_min_tiles && g_conv_mode != 9 && !next) || ntiles >= (1ll << 30)) return false;
+  if ((ntiles * NW < o.stream_min_tiles && o.conv_mode != 9 && !next) || ntiles >= (1ll << 30)) return false;
   if (next) {
     const long long yn_bytes = ((long long)(a.next_y.n - 1) * a.next_y.bstride + ((long long)a.next_y.h * a.next_y.w - 1) * a.next_y.ld + a.next_y.c) * 2;
     if (yn_bytes >= (1ll << 31)) return false;
@@ -3542,10 +2526,10 @@ static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes
   }
   // persistent blocks, as many as the register budget keeps resident (K = 64: 3 waves per SIMD, K = 128: 2)
   // (the slab variant of K = 64 needs 128 VGPRs: 4 waves per SIMD)
-  const unsigned gx = (unsigned)std::min<long long>(ntiles, K == 64 ? (NW == 8 ? 256 : (g_stream_slab ? 1024 : 768)) : (NW == 8 ? 256 : 512));
+  const unsigned gx = (unsigned)std::min<long long>(ntiles, K == 64 ? (NW == 8 ? 256 : (o.stream_slab ? 1024 : 768)) : (NW == 8 ? 256 : 512));
 #define RTD_STREAM(NKK, THREADS, DUAL)                                                                                                \
   do {                                                                                                                                \
-    if (g_stream_slab)                                                                                                                \
+    if (o.stream_slab)                                                                                                                \
       hipLaunchKernelGGL((conv1x1_stream_kernel<NKK, THREADS, DUAL, true>), dim3(gx), dim3(THREADS), 0, s, k, (unsigned)x_bytes,      \
                          (unsigned)r_bytes, (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles);                                  \
     else                                                                                                                              \
@@ -3566,29 +2550,7 @@ static bool dispatch_stream(const ConvK& k, const ConvArgs& a, long long x_bytes
   return true;
 }
 
-template <typename T>
-static bool dispatch_v2(const ConvK& k, bool v2_ok, hipStream_t s) {
-  if (!v2_ok || g_force_v1) return false;
-  const long long mt = (k.M + 127) / 128;
-  ConvK kk = k;
-  if (g_conv_mode == 0 || g_conv_mode >= 3) {
-    // measured on R50 bs8 (tools/profile_layers.py): the 128-pixel register-staged tile only pays with
-    // >= 2 blocks per CU slot; smaller grids run faster on v1's 64x64 tiles (more, shorter blocks)
-    if (!(k.N >= 128 && mt * ((k.N + 127) / 128) >= 512)) return false;
-  }
-  if (k.N >= 128 && mt * ((k.N + 127) / 128) >= 200) {
-    kk.ntn = (k.N + 127) / 128;
-    hipLaunchKernelGGL((conv_igemm_v2_kernel<T, 128>), dim3((unsigned)(mt * kk.ntn)), dim3(256), 0, s, kk);
-    return true;
-  }
-  if (mt * ((k.N + 63) / 64) >= 200) {
-    kk.ntn = (k.N + 63) / 64;
-    hipLaunchKernelGGL((conv_igemm_v2_kernel<T, 64>), dim3((unsigned)(mt * kk.ntn)), dim3(256), 0, s, kk);
-    return true;
-  }
-  return false;
-}
-
+// register-staged fallback: every shape (small channel counts, grids below the LDS-DMA kernels' thresholds)
 template <typename T>
 static void dispatch(const ConvK& k, bool smallc, hipStream_t s) {
   const long long b128 = (long long)((k.M + 127) / 128);
@@ -3614,6 +2576,7 @@ static void dispatch(const ConvK& k, bool smallc, hipStream_t s) {
 // The second input exists in the wave-specialised LDS-DMA kernel (and, for 64 + 64 channels, the streaming kernel): the shapes
 // dispatch_glds accepts, a K-step-aligned split point and whole K-steps of x2.
 bool conv_dual_supported(const ConvArgs& a) {
+  const ConvOpts& o = opts_of(a);
   const Tensor& x = a.x;
   const Tensor& y = a.y;
   const Tensor& x2 = a.x2;
@@ -3622,18 +2585,18 @@ bool conv_dual_supported(const ConvArgs& a) {
   if (a.x_up2 && !(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0)) return false;
   const int OH = (x.h * up + 2 * a.pad - a.KH) / a.stride + 1, OW = (x.w * up + 2 * a.pad - a.KW) / a.stride + 1;
   if (x2.n != x.n || x2.h != OH || x2.w != OW) return false;
-  if (x.dt == BF16X2) {                                           // the split kernel takes every grid size
+  if (x.dt == F16X2) {                                           // the split kernel takes every grid size
     const long long xb = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * 4;
     const long long x2b = ((long long)(x2.n - 1) * x2.bstride + ((long long)x2.h * x2.w - 1) * x2.ld + x2.c) * 4;
     return conv_split_supported(a) && xb < (1ll << 31) && x2b < (1ll << 31);
   }
   const int es = (int)dtype_size(x.dt), bk = 128 / es, epc = 16 / es;
   if ((a.KH * a.KW * x.c) % bk || x2.c % bk || x.c % bk || x2.ld % epc || ((uintptr_t)x2.p & 15)) return false;
-  if (!(y.c % 8 == 0 && y.ld % 8 == 0 && ((uintptr_t)y.p & 15) == 0)) return false;                       // v2_ok
+  if (!(y.c % 8 == 0 && y.ld % 8 == 0 && ((uintptr_t)y.p & 15) == 0)) return false;                       // tile_ok
   if (a.res_mode != RES_NONE && !(a.res.ld % 8 == 0 && ((uintptr_t)a.res.p & 15) == 0)) return false;
   const long long M = (long long)x.n * OH * OW;
   const long long mt = (M + 127) / 128, ntn = (y.c + 127) / 128;
-  if (y.c < (es == 2 ? g_glds_min_n : 64) || mt * ntn < (es == 2 ? g_glds_min_blocks : 512)) return false;
+  if (y.c < (es == 2 ? o.glds_min_n : 64) || mt * ntn < (es == 2 ? o.glds_min_blocks : 512)) return false;
   const long long x_bytes = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * es;
   const long long x2_bytes = ((long long)(x2.n - 1) * x2.bstride + ((long long)x2.h * x2.w - 1) * x2.ld + x2.c) * es;
   const long long w_bytes = (long long)conv_npad(y.c) * conv_kpad(a.KH * a.KW * x.c + x2.c) * es;
@@ -3645,53 +2608,32 @@ bool conv_dual_supported(const ConvArgs& a) {
 // give bit-identical outputs, so plans of different batch sizes may differ.
 static bool sx_shape_ok(const ConvArgs& a);
 bool conv_next_supported(const ConvArgs& a) {
+  const ConvOpts& o = opts_of(a);
   const Tensor& x = a.x;
   const Tensor& y = a.y;
   const bool dual = a.x2.p != nullptr;
-  if (x.dt == BF16X2)
-    return sx_shape_ok(a) && y.c == 256 && (a.next_y.c == 64 || a.next_y.c == 128) && a.next_y.dt == BF16X2 && a.next_y.ld % SPLIT_GROUP == 0 && y.ld % SPLIT_GROUP == 0;
-  if (!g_conv_stream || !g_stream_slab || x.dt != BF16 || y.dt != BF16 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.x_up2) return false;
+  if (x.dt == F16X2)
+    return sx_shape_ok(a) && y.c == 256 && (a.next_y.c == 64 || a.next_y.c == 128) && a.next_y.dt == F16X2 && a.next_y.ld % SPLIT_GROUP == 0 && y.ld % SPLIT_GROUP == 0;
+  if (!o.conv_stream || !o.stream_slab || x.dt != BF16 || y.dt != BF16 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.x_up2) return false;
   if (a.res_mode != RES_NONE && (a.res.dt != BF16 || a.res.ld % 8)) return false;
   if (dual && !(x.c == 64 && a.x2.c == 64 && y.c == 256)) return false;
   if (!dual && !((x.c == 64 && y.c == 256) || (x.c == 128 && y.c == 512))) return false;
   if (x.ld % 8 || y.ld % 8 || a.next_y.c != y.c / 4 || a.next_y.dt != BF16 || a.next_y.ld % 4) return false;
   const long long ntiles = ((long long)y.n * y.h * y.w + 31) / 32;
-  return ntiles * (y.c / 64) >= g_stream_min_tiles;
+  return ntiles * (y.c / 64) >= o.stream_min_tiles;
 }
 
-// BF16X2 operands: the wave-specialised LDS-DMA kernel's SPLIT instantiation is the one kernel of this precision (conv_igemm_ws_kernel).
-// Shapes: Cin (and C2) multiples of 32 - one channel group per K-step; output BF16X2 (N % 32 == 0) or fp32; residual BF16X2 or fp32.
-int conv_kpad_split(int K) { return 2 * ((K + SPLIT_GROUP - 1) / SPLIT_GROUP * SPLIT_GROUP); }   // bf16 elements of a filter row
-static int g_split_ws2_min_blocks = 257;   // A/B hook (rtd_debug_option "split_ws2_min_blocks")
-void conv_set_split_ws2_min_blocks(int v) { g_split_ws2_min_blocks = v; }
-static int g_split_ws64_max_blocks = 160;  // A/B hook (rtd_debug_option "split_ws64_max_blocks")
-// rtd_debug_option "split_kernel": 0 conv_igemm_ws_kernel<SPLIT>, 1 conv_igemm_wsx_kernel on 32x32x16 MFMAs, 2 on 16x16x32 (default: same-box A/B on
-// R50 bs 8, random frames: 1530 / 1550 / 1584 frames/s - the MFMA-bound layers run 5-8 % faster on the 16x16x32 shape, whose loop holds a higher clock)
-static int g_split_kernel = 2;
-void conv_set_split_kernel(int v) { g_split_kernel = v; }
-// rtd_debug_option "split_flex": flexible tile heights (conv_igemm_wsf_kernel) on long K loops - 0 never, 1 every grid, 2 (default) only grids
-// of <= split_flex_small_max 128 x 128 tiles (20^2 maps at batch 8, most layers at batch 1: R50 bs-1 latency 2.49 -> 2.36 ms, bs 8 unchanged)
-static int g_split_flex = 2;
-// Measured on R50 bs 8 with random frames inside the network (same box, tools/gpu_chain ab_p*): fixed 128 x 128 / 128 x 64 tiles 5529 us of
-// kernels per step, + flexible tile heights 5578, + persistent kernel 5740.  On zero-filled microbenchmarks the flexible tiles win 10-15 % on
-// the 80^2 maps (quantization) - inside the network, at the clocks random data allows and with cold operands, they do not; the persistent
-// kernel's store waves compete with the MFMA waves for the SIMDs' vector issue slots (a 16x16x32 MFMA blocks 8 of its 16 cycles) and the
-// epilogue's VALU work is as large as a K = 256 tile's MFMA work.  Both stay available (and tested) behind these switches, off by default.
-static int g_split_persist = 0;            // rtd_debug_option "split_persist": 1 = persistent three-role kernel on wide grids (2: also short K loops with a residual)
-static int g_split_persist_min_tiles = 384;   // persistent kernel from this many 112 x 128 tiles on ("split_persist_min_tiles")
-void conv_set_split_persist(int v) { g_split_persist = v; }
-void conv_set_split_persist_min_tiles(int v) { g_split_persist_min_tiles = v; }
-static int g_split_flex_small_max = 200;   // "split_flex_small_max" (same-box sweep on R50 bs 8 after the K-walk change: 128 / 200 / 256 / 400 -> 4.816 / 4.776 / 4.779 / 4.777 ms per step)
-void conv_set_split_flex_small_max(int v) { g_split_flex_small_max = v; }
-static int g_split_flex_force = 0;
-void conv_set_split_flex_force(int v) { g_split_flex_force = v; }
-static int g_split_flex_min_nk = 4;        // flexible tiles from this many K-steps on; "split_flex_min_nk" (same-box sweep, R50 bs 8: 16 / 8 / 4 / 2 -> 4.884 / 4.878 / 4.854 / 4.866 ms)
-void conv_set_split_flex(int v) { g_split_flex = v; }
-void conv_set_split_flex_min_nk(int v) { g_split_flex_min_nk = v; }
-void conv_set_split_ws64_max_blocks(int v) { g_split_ws64_max_blocks = v; }
+// ------------------------------------------------------------------------------------------------
+// Pair operands (F16X2 tensors, common.h).  Shapes: Cin (and C2) multiples of 32 - one channel group per K-step; output F16X2 (N % 32 == 0)
+// or fp32; residual F16X2 or fp32.  Measured inside the network (R50 bs 8, random frames, same box): flexible tile heights on EVERY grid lose to
+// fixed 128 x 128 / 128 x 64 tiles (5578 vs 5529 us of kernels per step; on zero-filled microbenchmarks they win 10-15 % on the 80^2 maps -
+// at the clocks random data allows and with cold operands they do not), a persistent three-role kernel lost more (5740 us: its store waves
+// compete with the MFMA waves for the SIMDs' issue slots) - both were removed in round 3; flexible heights stay on the small grids where
+// they fill idle CUs (ConvOpts::split_flex).
+int conv_kpad_split(int K) { return 2 * ((K + SPLIT_GROUP - 1) / SPLIT_GROUP * SPLIT_GROUP); }   // 16-bit elements of a filter row
 
 // ------------------------------------------------------------------------------------------------
-// Streaming 1x1 convolution on BF16X2 operands for the thin, very wide-grid expand convs of the first backbone stages
+// Streaming 1x1 convolution on F16X2 operands for the thin, very wide-grid expand convs of the first backbone stages
 // (stage-0 c3: 64 [+ 64 shortcut] -> 256 channels at 160^2, stage-1 c3: 128 -> 512 at 80^2): 0.3-0.5 GB per launch and 7-13 GFLOP, i.e.
 // HBM-bound, and the tiled kernels pay a prologue, an LDS staging round trip and a barrier-separated epilogue per 128-pixel
 // block for ONE or two K-steps.  Same scheme as conv1x1_stream_kernel (no LDS tile, no role split), on hi/lo pairs:
@@ -3704,7 +2646,7 @@ void conv_set_split_ws64_max_blocks(int v) { g_split_ws64_max_blocks = v; }
 //     channels of its pixel; residual and output cross a wave-private slab (32 rows x 128 bytes + skew) so that their global
 //     accesses are row-shaped (8 lanes x 16 bytes = one pixel's 128-byte run);
 //   * NEXTN (N == 256): the following 256 -> NEXTN reduce conv (the next block's c1) runs on the tile while the eight slabs
-//     hold y as hi/lo bf16 = exactly what that conv would read back from HBM: wave w takes 16 output channels (NEXTN = 64: of one
+//     hold y as hi/lo sp16 = exactly what that conv would read back from HBM: wave w takes 16 output channels (NEXTN = 64: of one
 //     16-pixel half) with 8 x 3 v_mfma_f32_16x16x32_bf16, its 16 x 256 filter slice (hi and lo) in registers, between two block
 //     barriers.  The c1 launch and its read of the 4-bytes-per-channel y tensor (R50 bs 8 stage 0: 210 MB) disappear.
 // Arithmetic per output: K chunks in order into a zero accumulator (lo-terms first inside a chunk), + bias, + residual (hi + lo),
@@ -3735,25 +2677,25 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
   const int cb = (cy * 8 + wv) * 32;                             // this wave's output channel group
   if (tid < 256) sbias[tid] = a.bias[cy * 256 + tid];
 
-  bf16x8 wfh[NKK], wfl[NKK];
+  sp16x8 wfh[NKK], wfl[NKK];
   {
     const int ch = cb + 16 * ((pl >> 2) & 1) + 4 * (pl >> 3) + (pl & 3);
-    const bf16* wr = (const bf16*)a.w + (size_t)ch * a.Kpad + 8 * h;
+    const sp16* wr = (const sp16*)a.w + (size_t)ch * a.Kpad + 8 * h;
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) {
-      wfh[kk] = *(const bf16x8*)(wr + (kk >> 1) * 64 + 16 * (kk & 1));
-      wfl[kk] = *(const bf16x8*)(wr + (kk >> 1) * 64 + 16 * (kk & 1) + 32);
+      wfh[kk] = *(const sp16x8*)(wr + (kk >> 1) * 64 + 16 * (kk & 1));
+      wfl[kk] = *(const sp16x8*)(wr + (kk >> 1) * 64 + 16 * (kk & 1) + 32);
     }
   }
   // NEXTN: this wave's 16 x 256 slice of the following filter as 16x16x32 A operands (row lane & 15, k 32 s + 8 (lane >> 4) ..)
   constexpr int NS = NEXTN ? 8 : 1;
-  bf16x8 w1h[NS], w1l[NS];
+  sp16x8 w1h[NS], w1l[NS];
   f32x4 b1v = {0.f, 0.f, 0.f, 0.f};
   const int slice = NEXTN == 64 ? (wv & 3) : wv;
   if (NEXTN) {
-    const bf16* w1 = (const bf16*)a.next_w + (size_t)(16 * slice + (lane & 15)) * a.next_kpad + 8 * (lane >> 4);
+    const sp16* w1 = (const sp16*)a.next_w + (size_t)(16 * slice + (lane & 15)) * a.next_kpad + 8 * (lane >> 4);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { w1h[s] = *(const bf16x8*)(w1 + 64 * s); w1l[s] = *(const bf16x8*)(w1 + 64 * s + 32); }
+    for (int s = 0; s < NS; ++s) { w1h[s] = *(const sp16x8*)(w1 + 64 * s); w1l[s] = *(const sp16x8*)(w1 + 64 * s + 32); }
     b1v = *(const f32x4*)(a.next_bias + 16 * slice + 4 * (lane >> 4));
   }
   __syncthreads();
@@ -3802,7 +2744,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
       int b = b0, p = p0 + px;
       if (p >= a.OHW) { p -= a.OHW; ++b; }
       const bool ok2 = m0 + px < a.M;
-      yrow[j] = ok2 ? (unsigned)(((long long)b * a.y_bstride + (long long)p * a.ldy + cb) * 4 + (lane & 7) * 16) : 0x80000000u;   // channels: 4 bytes each in a BF16X2 row
+      yrow[j] = ok2 ? (unsigned)(((long long)b * a.y_bstride + (long long)p * a.ldy + cb) * 4 + (lane & 7) * 16) : 0x80000000u;   // channels: 4 bytes each in a F16X2 row
       if (RES) rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rr, ok2 ? (unsigned)(((long long)b * a.r_bstride + (long long)p * a.ldr + cb) * 4 + (lane & 7) * 16) : 0x80000000u, 0, 0);
     }
   };
@@ -3837,17 +2779,17 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
-        const bf16x8 fh = *(const bf16x8*)(xf + (kk >> 1) * 128 + 32 * (kk & 1)), fl = *(const bf16x8*)(xf + (kk >> 1) * 128 + 32 * (kk & 1) + 64);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfh[kk], fl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfl[kk], fh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfh[kk], fh, acc, 0, 0, 0);
+        const sp16x8 fh = *(const sp16x8*)(xf + (kk >> 1) * 128 + 32 * (kk & 1)), fl = *(const sp16x8*)(xf + (kk >> 1) * 128 + 32 * (kk & 1) + 64);
+        acc = mfma_pair32(wfh[kk], fl, acc);
+        acc = mfma_pair32(wfl[kk], fh, acc);
+        acc = mfma_pair32(wfh[kk], fh, acc);
       }
       float r[16];
       if (RES) {                                                 // residual: row shape -> slab -> accumulator shape
 #pragma unroll
         for (int j = 0; j < 4; ++j) *(u32x4_*)(sl_row + j * 8 * SROW) = rv[j];
         __builtin_amdgcn_wave_barrier();
-        const bf16x8 h0 = *(const bf16x8*)sl_acc, h1 = *(const bf16x8*)(sl_acc + 16), l0 = *(const bf16x8*)(sl_acc + 64), l1 = *(const bf16x8*)(sl_acc + 80);
+        const sp16x8 h0 = *(const sp16x8*)sl_acc, h1 = *(const sp16x8*)(sl_acc + 16), l0 = *(const sp16x8*)(sl_acc + 64), l1 = *(const sp16x8*)(sl_acc + 80);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int e = 0; e < 8; ++e) { r[e] = (float)h0[e] + (float)l0[e]; r[8 + e] = (float)h1[e] + (float)l1[e]; }
@@ -3862,18 +2804,18 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
           *(f32x4*)(sf + 16 * q) = o;
         }
       } else {
-      bf16x8 oh[2], ol[2];
+      sp16x8 oh[2], ol[2];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         float v = acc[e] + bl[e];
         if (RES && a.res_mode == RES_PRE) v += r[e];
         v = act_c<ACT>(v);
         if (RES && a.res_mode == RES_POST) v += r[e];
-        bf16 hi, lo;
+        sp16 hi, lo;
         split2(v, hi, lo);
         oh[e >> 3][e & 7] = hi; ol[e >> 3][e & 7] = lo;
       }
-      *(bf16x8*)sl_acc = oh[0]; *(bf16x8*)(sl_acc + 16) = oh[1]; *(bf16x8*)(sl_acc + 64) = ol[0]; *(bf16x8*)(sl_acc + 80) = ol[1];
+      *(sp16x8*)sl_acc = oh[0]; *(sp16x8*)(sl_acc + 16) = oh[1]; *(sp16x8*)(sl_acc + 64) = ol[0]; *(sp16x8*)(sl_acc + 80) = ol[1];
       }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -3888,23 +2830,23 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
 #pragma unroll
           for (int s = 0; s < NS; ++s) {
             const char* sb = slabs[s] + (16 * half + r16) * SROW + kq * 16;
-            const bf16x8 ph = *(const bf16x8*)sb, pq = *(const bf16x8*)(sb + 64);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h[s], pq, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1l[s], ph, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h[s], ph, c, 0, 0, 0);
+            const sp16x8 ph = *(const sp16x8*)sb, pq = *(const sp16x8*)(sb + 64);
+            c = mfma_pair16(w1h[s], pq, c);
+            c = mfma_pair16(w1l[s], ph, c);
+            c = mfma_pair16(w1h[s], ph, c);
           }
-          bf16x4 vh, vl;
+          sp16x4 vh, vl;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = c[e] + b1v[e];
             if (a.next_act == ACT_RELU) v = fmaxf(v, 0.f);
-            bf16 hi, lo;
+            sp16 hi, lo;
             split2(v, hi, lo);
             vh[e] = hi; vl[e] = lo;
           }
           char* yq = y1s + (16 * half + r16) * YROW + (slice >> 1) * 128 + (16 * (slice & 1) + 4 * kq) * 2;
-          *(bf16x4*)yq = vh;
-          *(bf16x4*)(yq + 64) = vl;
+          *(sp16x4*)yq = vh;
+          *(sp16x4*)(yq + 64) = vl;
         }
         __syncthreads();                                         // every wave has read the slabs: the next tile may overwrite them; y1s is complete
         {
@@ -3927,23 +2869,21 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
   });
 }
 
-static int g_split_sx = 3;   // rtd_debug_option "split_sx": 0 = off, 1 = only K = 64 (+ 64) -> 256 (stage 0), 2 = also K = 128 -> N % 256 == 0 (stage 1), 3 = also K = 256 -> N >= 1024 without
-                             // a residual (value projection), 4 = also with a residual from 40^2 maps on (stage-2 expand convs: 51.5 vs 39.5 us on the tiled kernel - off)
-void conv_set_split_sx(int v) { g_split_sx = v; }
-// shapes the streaming split kernel takes; per-IMAGE extents only (see the kernel comment)
+// shapes the streaming pair kernel takes (ConvOpts::split_sx); per-IMAGE extents only (see the kernel comment)
 static bool sx_shape_ok(const ConvArgs& a) {
+  const int g_split_sx = opts_of(a).split_sx;
   const Tensor& x = a.x;
   const Tensor& y = a.y;
   const bool dual = a.x2.p != nullptr;
-  if (!g_split_sx || x.dt != BF16X2 || !(y.dt == BF16X2 || y.dt == F32) || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.x_up2) return false;
-  if (a.res_mode != RES_NONE && (a.res.dt != BF16X2 || dual)) return false;
+  if (!g_split_sx || x.dt != F16X2 || !(y.dt == F16X2 || y.dt == F32) || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.x_up2) return false;
+  if (a.res_mode != RES_NONE && (a.res.dt != F16X2 || dual)) return false;
   if (y.c % 256) return false;
   // K = 256 (value projection 256 -> 1536 fp32; split_sx 4: stage-2 expand convs 256 -> 1024 + residual at 40^2): either output type
   // (N >= 1024 only: with one or two channel blocks per pixel tile the tiled kernel is faster - decoder input projection 36 vs 46 us)
-  if (x.c == 256) return g_split_sx >= 3 && y.c >= 1024 && !dual && a.next_y.p == nullptr && (a.res_mode == RES_NONE || (g_split_sx >= 4 && y.dt == BF16X2)) &&
+  if (x.c == 256) return g_split_sx >= 3 && y.c >= 1024 && !dual && a.next_y.p == nullptr && (a.res_mode == RES_NONE || (g_split_sx >= 4 && y.dt == F16X2)) &&
                          (long long)y.h * y.w >= (g_split_sx >= 4 ? 1600 : 6400);
   if ((long long)y.h * y.w < 6400) return false;
-  if (y.dt != BF16X2) return false;
+  if (y.dt != F16X2) return false;
   if (dual) return x.c == 64 && a.x2.c == 64 && y.c == 256;
   if (x.c == 64) return true;
   return x.c == 128 && g_split_sx >= 2 && a.next_y.p == nullptr;
@@ -3956,7 +2896,7 @@ static bool dispatch_sx(const ConvK& k, const ConvArgs& a, long long x_bytes, lo
   long long r_bytes = 0, yn_bytes = 0;
   if (res) r_bytes = ((long long)(a.res.n - 1) * a.res.bstride + ((long long)a.res.h * a.res.w - 1) * a.res.ld + a.res.c) * 4;
   if (next) {
-    if (!(y.c == 256 && (a.next_y.c == 64 || a.next_y.c == 128) && a.next_y.dt == BF16X2 && a.next_y.ld % SPLIT_GROUP == 0 && ((uintptr_t)a.next_y.p & 15) == 0 &&
+    if (!(y.c == 256 && (a.next_y.c == 64 || a.next_y.c == 128) && a.next_y.dt == F16X2 && a.next_y.ld % SPLIT_GROUP == 0 && ((uintptr_t)a.next_y.p & 15) == 0 &&
           a.next_kpad == conv_kpad_split(256) && a.next_w && a.next_bias && (a.next_act == ACT_RELU || a.next_act == ACT_NONE))) return false;
     yn_bytes = ((long long)(a.next_y.n - 1) * a.next_y.bstride + ((long long)a.next_y.h * a.next_y.w - 1) * a.next_y.ld + a.next_y.c) * 4;
   }
@@ -4005,7 +2945,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const ConvK a, const floa
   float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (a.res_mode != RES_NONE) {
     const long long rpix = (long long)b * a.r_bstride + (long long)p * a.ldr;
-    if (a.res_split) split_load8((const bf16*)a.res, rpix, c, rv);
+    if (a.res_split) split_load8((const sp16*)a.res, rpix, c, rv);
     else {
       const f32x4 t0 = *(const f32x4*)((const float*)a.res + rpix + c), t1 = *(const f32x4*)((const float*)a.res + rpix + c + 4);
 #pragma unroll
@@ -4018,36 +2958,56 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const ConvK a, const floa
     v[e] = act_fn(v[e], a.act);
     if (a.res_mode == RES_POST) v[e] += rv[e];
   }
-  if (a.y_split) split_store8((bf16*)a.y, ypix, c, v);
+  if (a.y_split) split_store8((sp16*)a.y, ypix, c, v);
   else {
     *(f32x4*)((float*)a.y + ypix + c) = f32x4{v[0], v[1], v[2], v[3]};
     *(f32x4*)((float*)a.y + ypix + c + 4) = f32x4{v[4], v[5], v[6], v[7]};
   }
 }
-// rtd_debug_option "split_k2": two-pass split-K on long-K layers whose per-IMAGE tile count is small (stage 3, the 20^2 PAN level, enc.proj.2 at 640 px;
-// most layers at smaller inputs).  The slice count depends on per-image extents and K only: every batch size runs the same arithmetic.
-static int g_split_k2 = 1;
-void conv_set_split_k2(int v) { g_split_k2 = v; }
 bool conv_split_supported(const ConvArgs& a) {
   const Tensor& x = a.x;
   const Tensor& y = a.y;
-  if (x.dt != BF16X2 || !(y.dt == BF16X2 || y.dt == F32)) return false;
+  if (x.dt != F16X2 || !(y.dt == F16X2 || y.dt == F32)) return false;
   if (x.c % SPLIT_GROUP || x.ld % SPLIT_GROUP || ((uintptr_t)x.p & 15) || ((uintptr_t)a.w & 15)) return false;
-  if (a.x2.p && (a.x2.dt != BF16X2 || a.x2.c % SPLIT_GROUP || a.x2.ld % SPLIT_GROUP || ((uintptr_t)a.x2.p & 15))) return false;
+  if (a.x2.p && (a.x2.dt != F16X2 || a.x2.c % SPLIT_GROUP || a.x2.ld % SPLIT_GROUP || ((uintptr_t)a.x2.p & 15))) return false;
   if (a.x_up2 && !(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.x2.p)) return false;
-  if (y.dt == BF16X2 && (y.c % SPLIT_GROUP || y.ld % SPLIT_GROUP)) return false;
+  if (y.dt == F16X2 && (y.c % SPLIT_GROUP || y.ld % SPLIT_GROUP)) return false;
   if (y.c % 8 || y.ld % 4 || ((uintptr_t)y.p & 15)) return false;
   if (a.res_mode != RES_NONE) {
     const Tensor& r = a.res;
-    if (!(r.dt == BF16X2 || r.dt == F32) || !r.p || ((uintptr_t)r.p & 15) || r.ld % 4) return false;
-    if (r.dt == BF16X2 && r.ld % SPLIT_GROUP) return false;
+    if (!(r.dt == F16X2 || r.dt == F32) || !r.p || ((uintptr_t)r.p & 15) || r.ld % 4) return false;
+    if (r.dt == F16X2 && r.ld % SPLIT_GROUP) return false;
   }
   return a.next_y.p == nullptr || sx_shape_ok(a);
 }
+// Two-pass split-K (ConvOpts::split_k2) on long-K layers whose per-IMAGE tile count is small (stage 3, the 20^2 PAN level, enc.proj.2 at
+// 640 px; most layers at smaller inputs).  The slice count depends on per-image extents and K only: every batch size runs the same
+// arithmetic (the plan builder sizes the workspace from conv_split_slab_bytes() for its own batch).  Measured on R50 640^2 (stage-3 3x3,
+// K = 4608: 144 K-steps): batch 1 54 -> 35 us per layer (16 blocks -> 32), batch 8 57 -> 62 us; shorter K loops (stage-3 1x1, the 20^2 PAN
+// level) lose at batch 8 and gain nothing at batch 1, hence the 128-step floor.
+static int split_k2_slices(const ConvOpts& o, const ConvArgs& a, int OH, int OW) {
+  const bool dual = a.x2.p != nullptr;
+  if (!o.split_k2 || dual || a.x_up2 || a.y.c % 8 || a.next_y.p) return 1;
+  if (sx_shape_ok(a)) return 1;
+  const long long tiles_img = (((long long)OH * OW + 127) / 128) * ((a.y.c + 127) / 128);
+  const int groups = a.x.c / SPLIT_GROUP, nk_total = a.KH * a.KW * groups;
+  if (nk_total >= 128 && tiles_img <= 8 && groups % 4 == 0) return 4;
+  if (nk_total >= 128 && tiles_img <= 16 && groups % 2 == 0) return 2;
+  return 1;
+}
+size_t conv_split_slab_bytes(const ConvArgs& a) {
+  if (a.x.dt != F16X2) return 0;
+  const int up = a.x_up2 ? 2 : 1;
+  const int OH = (a.x.h * up + 2 * a.pad - a.KH) / a.stride + 1, OW = (a.x.w * up + 2 * a.pad - a.KW) / a.stride + 1;
+  const int S = split_k2_slices(opts_of(a), a, OH, OW);
+  return S > 1 ? (size_t)S * (size_t)a.x.n * OH * OW * a.y.c * 4 : 0;
+}
+
 static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
+  const ConvOpts& o = opts_of(a);
   const Tensor& x = a.x;
   const Tensor& y = a.y;
-  RTD_CHECK(conv_split_supported(a), 1, "conv (bf16x3): shape / layout not supported by the split kernel (channels % 32, 16-byte alignment)");
+  RTD_CHECK(conv_split_supported(a), 1, "conv (f16x3): shape / layout not supported by the pair kernels (channels % 32, 16-byte alignment)");
   const int up = a.x_up2 ? 2 : 1;
   const int OH = (x.h * up + 2 * a.pad - a.KH) / a.stride + 1;
   const int OW = (x.w * up + 2 * a.pad - a.KW) / a.stride + 1;
@@ -4055,28 +3015,28 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
   const bool dual = a.x2.p != nullptr;
   if (dual) RTD_CHECK(a.x2.n == x.n && a.x2.h == OH && a.x2.w == OW, 1, "conv: second input shape");
   const int K = a.KH * a.KW * x.c + (dual ? a.x2.c : 0);
-  RTD_CHECK(a.Kpad == conv_kpad_split(K) && a.Npad >= y.c && a.Npad % 128 == 0, 1, "conv: split filter padding");
+  RTD_CHECK(a.Kpad == conv_kpad_split(K) && a.Npad >= y.c && a.Npad % 128 == 0, 1, "conv: pair filter padding");
   RTD_CHECK((long long)x.n * OH * OW < (1ll << 31), 1, "conv: M overflow");
   ConvG g;
   ConvK& k = g.k;
   k.x = x.p; k.w = a.w; k.bias = a.bias; k.y = y.p;
   k.res = a.res_mode != RES_NONE ? a.res.p : nullptr;
   k.M = x.n * OH * OW; k.H = x.h * up; k.W = x.w * up;
-  k.Cin = 2 * x.c; k.ldx = 2 * x.ld; k.x_bstride = 2 * x.bstride;                    // bf16 elements
+  k.Cin = 2 * x.c; k.ldx = 2 * x.ld; k.x_bstride = 2 * x.bstride;                    // 16-bit elements
   k.x_up2 = a.x_up2;
   k.next_w = a.next_w; k.next_bias = a.next_bias; k.next_y = a.next_y.p; k.next_ldy = a.next_y.ld; k.next_y_bstride = a.next_y.bstride;   // channels
   k.next_kpad = a.next_kpad; k.next_act = a.next_act;
   k.OH = OH; k.OW = OW; k.OHW = OH * OW;
   k.N = y.c; k.Kreal = 2 * K; k.Kpad = a.Kpad;
   k.KH = a.KH; k.KW = a.KW; k.stride = a.stride; k.pad = a.pad;
-  k.ldy = y.ld; k.y_bstride = y.bstride;                                            // channels (fp32 or BF16X2 alike)
+  k.ldy = y.ld; k.y_bstride = y.bstride;                                            // channels (fp32 or F16X2 alike)
   k.ldr = 0; k.r_bstride = 0; k.res_f32 = 0;
   if (a.res_mode != RES_NONE) {
     RTD_CHECK(a.res.n == y.n && a.res.h == y.h && a.res.w == y.w && a.res.c == y.c, 1, "conv: residual shape");
     k.ldr = a.res.ld; k.r_bstride = a.res.bstride; k.res_f32 = a.res.dt == F32;
   }
   k.act = a.act; k.res_mode = a.res_mode; k.y_f32 = y.dt == F32;
-  k.split = 1; k.y_split = y.dt == BF16X2; k.res_split = a.res_mode != RES_NONE && a.res.dt == BF16X2;
+  k.split = 1; k.y_split = y.dt == F16X2; k.res_split = a.res_mode != RES_NONE && a.res.dt == F16X2;
   k.x2 = nullptr; k.ldx2 = 0; k.x2_bstride = 0; k.k2_start = 0;
   long long x2_bytes = 0;
   if (dual) {
@@ -4085,23 +3045,24 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
   }
   k.reg_epi = 1;
   k.prefer256 = 0;
-  k.pf = g_prefetch ? a.pf : nullptr;
-  k.pf_bytes = (g_prefetch && a.pf && a.pf_bytes < (1ull << 31)) ? (unsigned)a.pf_bytes : 0u;
+  k.pf = o.prefetch ? a.pf : nullptr;
+  k.pf_bytes = (o.prefetch && a.pf && a.pf_bytes < (1ull << 31)) ? (unsigned)a.pf_bytes : 0u;
   const long long x_bytes = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * 4;
   const long long w_bytes = (long long)a.Npad * a.Kpad * 2;
-  RTD_CHECK(x_bytes < (1ll << 31) && x2_bytes < (1ll << 31) && w_bytes < (1ll << 31), 1, "conv (bf16x3): operand larger than a buffer descriptor (2 GiB)");
-  g.probe = g_glds_drop & ~32; g.splitk = 1; g.slab = nullptr; g.cnt = nullptr; g.y_bytes = 0;      // timing-only probes (rtd_debug_option "glds_drop")
-  g.x_bytes = (g_glds_drop & 1) ? 0u : (unsigned)x_bytes; g.w_bytes = (g_glds_drop & 2) ? 0u : (unsigned)w_bytes; g.x2_bytes = (unsigned)x2_bytes;
+  RTD_CHECK(x_bytes < (1ll << 31) && x2_bytes < (1ll << 31) && w_bytes < (1ll << 31), 1, "conv (f16x3): operand larger than a buffer descriptor (2 GiB)");
+  g.probe = o.glds_drop & ~32; g.splitk = 1; g.slab = nullptr; g.y_bytes = 0;      // timing-only probes (rtd_debug_option "glds_drop")
+  g.x_bytes = (o.glds_drop & 1) ? 0u : (unsigned)x_bytes; g.w_bytes = (o.glds_drop & 2) ? 0u : (unsigned)w_bytes; g.x2_bytes = (unsigned)x2_bytes;
   // thin 1x1 expand convs on wide grids (stage-0 / stage-1 c3): the streaming kernel, with the next block's reduce conv riding on it
   if (dispatch_sx(k, a, x_bytes, x2_bytes, s)) { HIP_CHECK(hipGetLastError()); return; }
-  RTD_CHECK(a.next_y.p == nullptr, 1, "conv (bf16x3): a fused following conv exists in the streaming kernel only");
-  // narrow 3x3 layers on wide grids (stem.1, stem.2): the direct kernel stages every input pixel once instead of nine times
-  if (g_conv_reg && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !dual && a.res_mode == RES_NONE && x.c == 32 && (y.c == 32 || y.c == 64) &&
-      y.dt == BF16X2) {
+  RTD_CHECK(a.next_y.p == nullptr, 1, "conv (f16x3): a fused following conv exists in the streaming kernel only");
+  // Direct 3x3 kernels for the narrow layers on wide maps.  Chosen on the per-IMAGE tile count: every batch size runs the same arithmetic
+  // (batch invariance is bit-exact).  32 input channels (stem.1, stem.2): every input pixel is staged once instead of nine times
+  if (o.conv_reg && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !dual && a.res_mode == RES_NONE && x.c == 32 && (y.c == 32 || y.c == 64) &&
+      y.dt == F16X2) {
     const long long y_bytes = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * 4;
     const int tiles_x = (x.w + 31) / 32, tiles_y = (x.h + 7) / 8;
     const long long ntiles = (long long)x.n * tiles_x * tiles_y;
-    if (ntiles >= 256 && ntiles < (1ll << 30) && y_bytes < (1ll << 31)) {
+    if (tiles_x * tiles_y >= 32 && ntiles < (1ll << 30) && y_bytes < (1ll << 31)) {
       const unsigned gx = (unsigned)std::min<long long>(ntiles, 256);        // persistent, one block per CU
       if (y.c == 32) hipLaunchKernelGGL((conv3x3_reg_split_kernel<1>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles);
       else hipLaunchKernelGGL((conv3x3_reg_split_kernel<2>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles);
@@ -4109,9 +3070,8 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
       return;
     }
   }
-  // 64 -> 64 channel 3x3 on wide maps (stage-0 c2): direct kernel on 8 x 16 tiles.  Chosen on the per-IMAGE tile count: every batch size runs the
-  // same arithmetic (batch invariance is bit-exact)
-  if ((g_conv_reg & 2) && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !dual && a.res_mode == RES_NONE && x.c == 64 && y.c == 64 && y.dt == BF16X2) {
+  // 64 -> 64 channels (stage-0 c2): direct kernel on 8 x 16 tiles
+  if ((o.conv_reg & 2) && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !dual && a.res_mode == RES_NONE && x.c == 64 && y.c == 64 && y.dt == F16X2) {
     const long long y_bytes = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * 4;
     const int tiles_x = (x.w + 15) / 16, tiles_y = (x.h + 7) / 8;
     const long long ntiles = (long long)x.n * tiles_x * tiles_y;
@@ -4123,16 +3083,9 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
     }
   }
   // ---- two-pass split-K: S slices of the channel groups, bare fp32 partial sums into the workspace slab, k_splitk_reduce finishes
-  int S = 1;
-  if (g_split_k2 && g_split_kernel == 2 && !dual && !a.x_up2 && a.ws.slab && k.N % 8 == 0) {
-    const long long tiles_img = (((long long)OH * OW + 127) / 128) * ((k.N + 127) / 128);
-    const int groups = x.c / SPLIT_GROUP, nk_total = a.KH * a.KW * groups;
-    // measured on R50 640^2 (stage-3 3x3, K = 4608: 144 K-steps): batch 1 54 -> 35 us per layer (16 blocks -> 32), batch 8 57 -> 62 us; shorter K
-    // loops (stage-3 1x1, the 20^2 PAN level) lose at batch 8 and gain nothing at batch 1, hence the 128-step floor
-    if (nk_total >= 128 && tiles_img <= 8 && groups % 4 == 0) S = 4;
-    else if (nk_total >= 128 && tiles_img <= 16 && groups % 2 == 0) S = 2;
-    if ((size_t)S * (size_t)k.M * (size_t)k.N * 4 > a.ws.slab_bytes) S = 1;
-  }
+  const int S = split_k2_slices(o, a, OH, OW);
+  if (S > 1) RTD_CHECK(a.ws.slab && (size_t)S * (size_t)k.M * (size_t)k.N * 4 <= a.ws.slab_bytes, 1,
+                       "conv (f16x3): the launch needs a split-K workspace of conv_split_slab_bytes() bytes (ConvArgs::ws)");
   const ConvK korig = k;
   if (S > 1) {
     k.raw = 1; k.act = ACT_NONE; k.res_mode = RES_NONE; k.res = nullptr; k.y = a.ws.slab; k.y_f32 = 1; k.y_split = 0; k.res_split = 0;
@@ -4147,28 +3100,11 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
     }
   };
   const long long mt = (k.M + 127) / 128, ntn = (k.N + 127) / 128, ntn64 = (k.N + 63) / 64;
-  // ---- persistent three-role kernel (conv_igemm_wsp_kernel): grids with several tiles per CU
-  if (S == 1 && g_split_persist && g_split_kernel == 2 && k.N >= 128 && k.Kpad / 64 >= 2 && (k.Kpad / 64 >= 8 || k.res_mode == RES_NONE || g_split_persist == 2)) {
-    constexpr int PMT = 7;
-    const long long mtl = (k.M + 16 * PMT - 1) / (16 * PMT), ntb = (k.N + 127) / 128;
-    const long long tiles = mtl * ntb;
-    if (tiles >= g_split_persist_min_tiles && tiles < (1ll << 30)) {
-      k.ntn = (int)ntb;
-      const unsigned gx = (unsigned)std::min<long long>(tiles, 256);
-      hipLaunchKernelGGL((conv_igemm_wsp_kernel<PMT>), dim3(gx), dim3(768), 0, s, g, (int)tiles);
-      HIP_CHECK(hipGetLastError());
-      return;
-    }
-  }
-  // ---- flexible tile height (conv_igemm_wsf_kernel): MFMA-bound layers (>= 16 K-steps) pick the tile whose grid fills whole rounds of the chip
-  // split_flex 2: only grids that leave CUs idle with 128-pixel tiles (20^2 maps at batch 8, most layers at batch 1)
-  if (g_split_flex && g_split_kernel == 2 && k.Kpad / 64 / S >= g_split_flex_min_nk && k.N >= 64 &&
-      (g_split_flex != 2 || ((k.M + 127) / 128) * ((k.N + 127) / 128) * S <= g_split_flex_small_max)) {
+  // ---- flexible tile height (conv_igemm_wsf_kernel) on grids that leave CUs idle with 128-pixel tiles (20^2 maps at batch 8, most layers at
+  // batch 1: R50 bs-1 latency 2.49 -> 2.36 ms): the tile whose grid fills whole rounds of the chip
+  if (o.split_flex && k.Kpad / 64 / S >= o.split_flex_min_nk && k.N >= 64 && mt * ntn * S <= o.split_flex_small_max) {
     int best_mt = 0, best_bn = 0, best_st = 0;
     double best = 1e30;
-    if (g_split_flex_force) {                      // sweeps (tools/conv_bench.py --opt split_flex_force): mt + 100 * (bn == 64) + 1000 * stages
-      best_mt = g_split_flex_force % 100; best_bn = (g_split_flex_force / 100) % 10 ? 64 : 128; best_st = g_split_flex_force / 1000; best = 0.0;
-    }
     for (int bn = (k.N > 64 ? 128 : 64); bn >= 64; bn -= 64) {
       const long long ntb = (k.N + bn - 1) / bn;
       for (int mtc = 4; mtc <= 13; ++mtc) {
@@ -4206,49 +3142,26 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
     if (launched) { finish(); return; }
     k.ntn = 1;
   }
-  if (g_split_kernel != 0) {                      // the dedicated split kernel: 1 = 32x32x16 MFMAs, 2 = 16x16x32
-    const bool n64 = k.N <= 64 || (mt * ntn < g_split_ws64_max_blocks && ntn64 > ntn);
-    k.ntn = (int)(n64 ? ntn64 : ntn);
-    const long long blocks = mt * k.ntn * S;
-    const bool four = blocks < g_split_ws2_min_blocks;
-    const dim3 grid((unsigned)blocks), blk(512);
-#define RTD_WSX(ST, BNN) do { if (g_split_kernel == 2) hipLaunchKernelGGL((conv_igemm_wsx_kernel<ST, BNN, true>), grid, blk, 0, s, g); \
-                              else hipLaunchKernelGGL((conv_igemm_wsx_kernel<ST, BNN, false>), grid, blk, 0, s, g); } while (0)
-    if (n64) { if (four) RTD_WSX(4, 64); else RTD_WSX(2, 64); }
-    else { if (four) RTD_WSX(4, 128); else RTD_WSX(2, 128); }
-#undef RTD_WSX
-    finish();
-    return;
-  }
-  RTD_CHECK(S == 1, 1, "conv (bf16x3): split-K needs the dedicated split kernels");
-  if (k.N <= 64 || (mt * ntn < g_split_ws64_max_blocks && ntn64 > ntn)) {
-    k.ntn = (int)ntn64;
-    // wide grids (stage-0 c1 / c2 at 160^2: 1600 tiles): 2 stages, two blocks per CU - one block's prologue and copy-out run under the other's
-    // K loop (with 4 stages and one block per CU the 64-channel layers took 7 serial rounds of ~11 us: 80 us for 30 us of traffic)
-    if (mt * ntn64 < g_split_ws2_min_blocks) hipLaunchKernelGGL((conv_igemm_ws_kernel<bf16, 4, false, 64, true>), dim3((unsigned)(mt * ntn64)), dim3(512), 0, s, g);
-    else hipLaunchKernelGGL((conv_igemm_ws_kernel<bf16, 2, false, 64, true>), dim3((unsigned)(mt * ntn64)), dim3(512), 0, s, g);
-  } else {
-    k.ntn = (int)ntn;
-    if (mt * ntn < g_split_ws2_min_blocks) hipLaunchKernelGGL((conv_igemm_ws_kernel<bf16, 4, false, 128, true>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
-    else hipLaunchKernelGGL((conv_igemm_ws_kernel<bf16, 2, false, 128, true>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
-  }
-  HIP_CHECK(hipGetLastError());
-}
-
-void conv_reset_options() {
-  g_glds_min_blocks = 4; g_splitk_enable = 0; g_glds_drop = 0; g_conv_mode = 0; g_force_v1 = 0; g_ws256_min_blocks = 0; g_glds_min_n = 128;
-  g_wsa_min_ntn = 8; g_ws2_min_blocks = 257; g_reg_epilogue = 1; g_ws64_max_blocks = 160; g_prefetch = 1; g_conv_reg = 3; g_conv_stream = 1;
-  g_stream_min_tiles = 2048; g_stream2_max_n = 2048; g_stream2 = 1; g_stream_slab = 1; g_split_ws2_min_blocks = 257; g_split_ws64_max_blocks = 160; g_split_kernel = 2; g_split_flex = 2; g_split_flex_min_nk = 4; g_split_flex_force = 0; g_split_persist = 0; g_split_persist_min_tiles = 384; g_split_flex_small_max = 200; g_split_sx = 3; g_split_k2 = 1;
+  // ---- fixed 128 x 128 / 128 x 64 tiles (conv_igemm_wsx_kernel): 4 stages at one block per CU below split_ws2_min_blocks blocks, 2 stages from there
+  const bool n64 = k.N <= 64 || (mt * ntn < o.split_ws64_max_blocks && ntn64 > ntn);
+  k.ntn = (int)(n64 ? ntn64 : ntn);
+  const long long blocks = mt * k.ntn * S;
+  const bool four = blocks < o.split_ws2_min_blocks;
+  const dim3 grid((unsigned)blocks), blk(512);
+  if (n64) { if (four) hipLaunchKernelGGL((conv_igemm_wsx_kernel<4, 64>), grid, blk, 0, s, g); else hipLaunchKernelGGL((conv_igemm_wsx_kernel<2, 64>), grid, blk, 0, s, g); }
+  else { if (four) hipLaunchKernelGGL((conv_igemm_wsx_kernel<4, 128>), grid, blk, 0, s, g); else hipLaunchKernelGGL((conv_igemm_wsx_kernel<2, 128>), grid, blk, 0, s, g); }
+  finish();
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t s) {
   const Tensor& x = a.x;
   const Tensor& y = a.y;
-  if (x.dt == BF16X2) { launch_conv_split(a, s); return; }
+  if (x.dt == F16X2) { launch_conv_split(a, s); return; }
+  const ConvOpts& o = opts_of(a);
   RTD_CHECK(x.dt == BF16 || x.dt == F32, 1, "conv: input dtype");
-  RTD_CHECK(y.dt == BF16 || y.dt == F32 || (y.dt == BF16X2 && x.dt == F32), 1, "conv: output dtype");
-  if (y.dt == BF16X2) RTD_CHECK(y.c % SPLIT_GROUP == 0 && y.ld % SPLIT_GROUP == 0 && a.res_mode == RES_NONE && !a.x2.p && !a.next_y.p && ((uintptr_t)y.p & 15) == 0, 1,
-                                "conv: fp32 -> BF16X2 output needs 32-channel groups and no residual / second input");
+  RTD_CHECK(y.dt == BF16 || y.dt == F32 || (y.dt == F16X2 && x.dt == F32), 1, "conv: output dtype");
+  if (y.dt == F16X2) RTD_CHECK(y.c % SPLIT_GROUP == 0 && y.ld % SPLIT_GROUP == 0 && a.res_mode == RES_NONE && !a.x2.p && !a.next_y.p && ((uintptr_t)y.p & 15) == 0, 1,
+                                "conv: fp32 -> F16X2 output needs 32-channel groups and no residual / second input");
   const int epc = x.dt == BF16 ? 8 : 4;
   const int up = a.x_up2 ? 2 : 1;
   if (a.x_up2) RTD_CHECK(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.x2.p, 1, "conv: x_up2 needs a 1x1 conv with a second input");
@@ -4284,7 +3197,7 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     k.ldr = a.res.ld; k.r_bstride = a.res.bstride; k.res_f32 = a.res.dt == F32;
   }
   k.act = a.act; k.res_mode = a.res_mode; k.y_f32 = y.dt == F32;
-  k.y_split = y.dt == BF16X2;
+  k.y_split = y.dt == F16X2;
   k.x2 = nullptr; k.ldx2 = 0; k.x2_bstride = 0; k.k2_start = 0;
   long long x2_bytes = 0;
   if (dual) {
@@ -4292,16 +3205,16 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     x2_bytes = ((long long)(a.x2.n - 1) * a.x2.bstride + ((long long)a.x2.h * a.x2.w - 1) * a.x2.ld + a.x2.c) * (long long)dtype_size(x.dt);
   }
   k.ntn = 1;
-  k.reg_epi = g_reg_epilogue;
+  k.reg_epi = o.reg_epilogue;
   k.prefer256 = a.prefer256;
-  k.pf = g_prefetch ? a.pf : nullptr;
-  k.pf_bytes = (g_prefetch && a.pf && a.pf_bytes < (1ull << 31)) ? (unsigned)a.pf_bytes : 0u;
+  k.pf = o.prefetch ? a.pf : nullptr;
+  k.pf_bytes = (o.prefetch && a.pf && a.pf_bytes < (1ull << 31)) ? (unsigned)a.pf_bytes : 0u;
   const bool smallc = (x.c % 32) != 0;
   const int bk2 = x.dt == BF16 ? 64 : 32;
-  bool v2_ok = (x.c % bk2 == 0) && (y.c % 8 == 0) && (y.ld % 8 == 0) && (((uintptr_t)y.p & 15) == 0);
-  if (a.res_mode != RES_NONE) v2_ok = v2_ok && (a.res.ld % 8 == 0) && (((uintptr_t)a.res.p & 15) == 0);
+  bool tile_ok = (x.c % bk2 == 0) && (y.c % 8 == 0) && (y.ld % 8 == 0) && (((uintptr_t)y.p & 15) == 0);
+  if (a.res_mode != RES_NONE) tile_ok = tile_ok && (a.res.ld % 8 == 0) && (((uintptr_t)a.res.p & 15) == 0);
   bool done = false;
-  if (k.y_split) {                        // fp32 input, BF16X2 output (the split engine's stem.0): the register-staged kernel's epilogue writes it
+  if (k.y_split) {                        // fp32 input, F16X2 output (the split engine's stem.0): the register-staged kernel's epilogue writes it
     dispatch<float>(k, smallc, s);
     HIP_CHECK(hipGetLastError());
     return;
@@ -4310,22 +3223,18 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     const long long es = (long long)dtype_size(x.dt);
     const long long x_bytes = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * es;
     const long long w_bytes = (long long)a.Npad * a.Kpad * es;
-    done = !dual && !a.next_y.p && dispatch_reg(k, a, x_bytes, s);
-    if (!done) done = dispatch_stream(k, a, x_bytes, x2_bytes, s);
+    done = !dual && !a.next_y.p && dispatch_reg(o, k, a, x_bytes, s);
+    if (!done) done = dispatch_stream(o, k, a, x_bytes, x2_bytes, s);
     RTD_CHECK(done || !a.next_y.p, 1, "conv: the fused following conv needs the streaming kernel (see conv_next_supported)");
     if (!done) {
       const long long yb = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * (long long)dtype_size(y.dt);
       const unsigned y_bytes = yb < (1ll << 31) ? (unsigned)yb : 0u;
-      if (x.dt == BF16) done = dispatch_glds<bf16>(k, v2_ok, x_bytes, w_bytes, y_bytes, (unsigned)x2_bytes, a.ws, s);
-      else done = dispatch_glds<float>(k, v2_ok, x_bytes, w_bytes, y_bytes, (unsigned)x2_bytes, a.ws, s);
+      if (x.dt == BF16) done = dispatch_glds<bf16>(o, k, tile_ok, a.prefer256 != 0, x_bytes, w_bytes, y_bytes, (unsigned)x2_bytes, a.ws, s);
+      else done = dispatch_glds<float>(o, k, tile_ok, a.prefer256 != 0, x_bytes, w_bytes, y_bytes, (unsigned)x2_bytes, a.ws, s);
     }
   }
   RTD_CHECK(done || !dual, 1, "conv: no kernel took the dual-input launch");
   RTD_CHECK(done || !a.next_y.p, 1, "conv: no kernel took the launch with a fused following conv (see conv_next_supported)");
-  if (!done) {
-    if (x.dt == BF16) done = dispatch_v2<bf16>(k, v2_ok, s);
-    else done = dispatch_v2<float>(k, v2_ok, s);
-  }
   if (!done) {
     if (x.dt == BF16) dispatch<bf16>(k, smallc, s);
     else dispatch<float>(k, smallc, s);

@@ -111,24 +111,22 @@ __device__ void row_gemm(const float* Xs, int ldx, const DecLin& L, float* Ys, i
   }
 }
 
-typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
-
-// fp32 rows in LDS -> bf16 hi / lo rows in LDS (x = hi + lo to ~2^-17 relative), K % 8 == 0
-__device__ __forceinline__ void split_rows(const float* Xs, int ldx, int K, bf16* Xh, bf16* Xl, int ldb, int tid) {
+// fp32 rows in LDS -> fp16 hi / lo rows in LDS (x = hi + lo to 2^-22 relative / 2^-25 absolute, common.h sp16), K % 8 == 0
+__device__ __forceinline__ void split_rows(const float* Xs, int ldx, int K, sp16* Xh, sp16* Xl, int ldb, int tid) {
   const int k8 = K >> 3;
   for (int e = tid; e < DR * k8; e += NT) {
     const int r = e / k8, c = (e - r * k8) << 3;
     const f32x4_ v0 = *(const f32x4_*)(Xs + r * ldx + c), v1 = *(const f32x4_*)(Xs + r * ldx + c + 4);
-    bf16x8_ h, l;
+    sp16x8 h, l;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float x = j < 4 ? v0[j] : v1[j - 4];
-      const bf16 hi = (bf16)x;
+      const sp16 hi = (sp16)x;
       h[j] = hi;
-      l[j] = (bf16)(x - (float)hi);
+      l[j] = (sp16)(x - (float)hi);
     }
-    *(bf16x8_*)(Xh + r * ldb + c) = h;
-    *(bf16x8_*)(Xl + r * ldb + c) = l;
+    *(sp16x8*)(Xh + r * ldb + c) = h;
+    *(sp16x8*)(Xl + r * ldb + c) = l;
   }
 }
 
@@ -136,13 +134,14 @@ __device__ __forceinline__ void split_rows(const float* Xs, int ldx, int K, bf16
 // v_mfma_f32_16x16x32_bf16 per 32-deep chunk (lo*hi, hi*lo, hi*hi; fp32 accumulate) instead of 8 v_mfma_f32_16x16x4_f32:
 // 5x less MFMA time for the same filter bytes, products exact to ~2^-17.  A lane's fragments: A[row = lane & 15][32c + 8 (lane >> 4) .. +7],
 // W[n0 + (lane & 15)][same k].  Output: fp32 Ys and / or a hi/lo split (Yh, Yl) for a following GEMM.
-template <int ACT, bool WLO = true, int PF = 2>   // WLO = false: the filter's lo half is neither loaded nor multiplied (bf16 filter, split activations)
-__device__ void row_gemm_split(const bf16* Ah, const bf16* Al, int lda, const DecLin& L, float* Ys, int ldy, const float* Rs, int ldr,
-                               bf16* Yh, bf16* Yl, int ldyb, int wave, int lane, int rot, size_t wmask = ~(size_t)0) {
+template <int ACT, bool WLO = true>   // WLO = false: the filter's lo half is neither loaded nor multiplied (hi-only filter, split activations)
+__device__ void row_gemm_split(const sp16* Ah, const sp16* Al, int lda, const DecLin& L, float* Ys, int ldy, const float* Rs, int ldr,
+                               sp16* Yh, sp16* Yl, int ldyb, int wave, int lane, int rot) {
+  constexpr int PF = 2;   // K steps of filter fragments in flight per wave (3 changed nothing: measured in round 2)
   const int ntiles = (L.N + 15) >> 4;
   const int r16 = lane & 15, q = lane >> 4;
-  const bf16* ah = Ah + r16 * lda + 8 * q;
-  const bf16* al = Al + r16 * lda + 8 * q;
+  const sp16* ah = Ah + r16 * lda + 8 * q;
+  const sp16* al = Al + r16 * lda + 8 * q;
   const int kc = L.K >> 5;                                     // 32-deep chunks per tile, 2 KiB each (hi 1 KiB | lo 1 KiB)
   const int nsteps = L.K >> 6;
   const int npass = (ntiles - wave + 2 * NW - 1) / (2 * NW);
@@ -150,40 +149,40 @@ __device__ void row_gemm_split(const bf16* Ah, const bf16* Al, int lda, const De
     const int t = wave + 2 * NW * ((ps + rot) % npass);
     const bool has2 = t + NW < ntiles;                          // wave-uniform
     const int n0 = t << 4, n1 = has2 ? (t + NW) << 4 : n0;
-    const char* w0 = (const char*)L.w + (((size_t)t * kc * 2048) & wmask) + lane * 16;
-    const char* w1 = (const char*)L.w + (((size_t)(has2 ? t + NW : t) * kc * 2048) & wmask) + lane * 16;
+    const char* w0 = (const char*)L.w + (size_t)t * kc * 2048 + lane * 16;
+    const char* w1 = (const char*)L.w + (size_t)(has2 ? t + NW : t) * kc * 2048 + lane * 16;
     f32x4_ acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     // the pass's two bias values are requested with its first filter fragments (read in the epilogue they cost an exposed L2 round trip per pass)
     const float bias0 = (n0 + r16 < L.N) ? L.b[n0 + r16] : 0.f, bias1 = (n1 + r16 < L.N) ? L.b[n1 + r16] : 0.f;
     asm volatile("" ::: "memory");                              // (keeps the two loads up here: hipcc sinks a load to its use otherwise)
     // PF register sets, each one 64-deep K step of both tiles (8 x 16-byte loads per lane); a set is reloaded with the step PF
     // ahead right after its MFMAs were issued, so 8 PF loads per wave stay in flight (the loop is L2-latency bound: one step in
-    // flight per wave was 0.9 us per step; rtd_debug_option "dec_pf" picks 2 or 3).
-    bf16x8_ wh0[PF][2], wl0[PF][2], wh1[PF][2], wl1[PF][2];
+    // flight per wave was 0.9 us per step).
+    sp16x8 wh0[PF][2], wl0[PF][2], wh1[PF][2], wl1[PF][2];
     int st = (rot + ps) % nsteps;
     auto nxt = [&](int v) { return v + 1 == nsteps ? 0 : v + 1; };
-    auto load = [&](bf16x8_ (&h0)[2], bf16x8_ (&l0)[2], bf16x8_ (&h1)[2], bf16x8_ (&l1)[2], int step) {
+    auto load = [&](sp16x8 (&h0)[2], sp16x8 (&l0)[2], sp16x8 (&h1)[2], sp16x8 (&l1)[2], int step) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        h0[j] = *(const bf16x8_*)(w0 + (step << 1) * 2048 + 2048 * j);
-        if (WLO) l0[j] = *(const bf16x8_*)(w0 + (step << 1) * 2048 + 2048 * j + 1024);
-        h1[j] = *(const bf16x8_*)(w1 + (step << 1) * 2048 + 2048 * j);
-        if (WLO) l1[j] = *(const bf16x8_*)(w1 + (step << 1) * 2048 + 2048 * j + 1024);
+        h0[j] = *(const sp16x8*)(w0 + (step << 1) * 2048 + 2048 * j);
+        if (WLO) l0[j] = *(const sp16x8*)(w0 + (step << 1) * 2048 + 2048 * j + 1024);
+        h1[j] = *(const sp16x8*)(w1 + (step << 1) * 2048 + 2048 * j);
+        if (WLO) l1[j] = *(const sp16x8*)(w1 + (step << 1) * 2048 + 2048 * j + 1024);
       }
     };
-    auto mma = [&](const bf16x8_ (&h0)[2], const bf16x8_ (&l0)[2], const bf16x8_ (&h1)[2], const bf16x8_ (&l1)[2], int step) {
+    auto mma = [&](const sp16x8 (&h0)[2], const sp16x8 (&l0)[2], const sp16x8 (&h1)[2], const sp16x8 (&l1)[2], int step) {
       const int k0 = step << 6;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const bf16x8_ xh = *(const bf16x8_*)(ah + k0 + 32 * j), xl = *(const bf16x8_*)(al + k0 + 32 * j);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, h0[j], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, h1[j], acc1, 0, 0, 0);
+        const sp16x8 xh = *(const sp16x8*)(ah + k0 + 32 * j), xl = *(const sp16x8*)(al + k0 + 32 * j);
+        acc0 = mfma_pair16(xl, h0[j], acc0);
+        acc1 = mfma_pair16(xl, h1[j], acc1);
         if (WLO) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, l0[j], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, l1[j], acc1, 0, 0, 0);
+          acc0 = mfma_pair16(xh, l0[j], acc0);
+          acc1 = mfma_pair16(xh, l1[j], acc1);
         }
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, h0[j], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, h1[j], acc1, 0, 0, 0);
+        acc0 = mfma_pair16(xh, h0[j], acc0);
+        acc1 = mfma_pair16(xh, h1[j], acc1);
       }
     };
     int cur = st, pf = st;                                       // step of the next MFMA group / of the next load
@@ -218,9 +217,9 @@ __device__ void row_gemm_split(const bf16* Ah, const bf16* Al, int lda, const De
           if (ACT == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
           if (Ys) Ys[row * ldy + col] = v;
           if (Yh) {
-            const bf16 hi = (bf16)v;
+            const sp16 hi = (sp16)v;
             Yh[row * ldyb + col] = hi;
-            Yl[row * ldyb + col] = (bf16)(v - (float)hi);
+            Yl[row * ldyb + col] = (sp16)(v - (float)hi);
           }
         }
       }
@@ -422,15 +421,15 @@ __device__ void self_attention_rows_split(const DecArgs& a, const float* sQ, int
   const int head = wave;
   const int r16 = lane & 15, q = lane >> 4;
   const float scale = rsqrtf(32.f);
-  bf16x8_ qh, ql;                                               // Q[query r16][32 head + 8 q + j] * scale
+  sp16x8 qh, ql;                                               // Q[query r16][32 head + 8 q + j] * scale
   {
     const f32x4_ q0 = *(const f32x4_*)(sQ + r16 * ldq + head * 32 + 8 * q), q1 = *(const f32x4_*)(sQ + r16 * ldq + head * 32 + 8 * q + 4);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float x = (j < 4 ? q0[j] : q1[j - 4]) * scale;
-      const bf16 hi = (bf16)x;
+      const sp16 hi = (sp16)x;
       qh[j] = hi;
-      ql[j] = (bf16)(x - (float)hi);
+      ql[j] = (sp16)(x - (float)hi);
     }
   }
   float m = -INFINITY, l = 0.f;
@@ -438,15 +437,15 @@ __device__ void self_attention_rows_split(const DecArgs& a, const float* sQ, int
   const int tp = (tiles + 1) & ~1, npairs = tp >> 1;
   const char* kb = (const char*)a.kfrag_in + ((size_t)(b * a.heads + head) * tp) * 2048 + lane * 16;
   const char* vb = (const char*)a.vfrag_in + ((size_t)(b * a.heads + head) * tp) * 2048 + lane * 16;
-  bf16x8_ kc[2][2], vc[2][2], kn[2][2], vn[2][2];               // K: [tile of the pair][hi, lo]; V: [d][hi, lo]
-  auto ld = [&](bf16x8_ (&k)[2][2], bf16x8_ (&v)[2][2], int pr) {
+  sp16x8 kc[2][2], vc[2][2], kn[2][2], vn[2][2];               // K: [tile of the pair][hi, lo]; V: [d][hi, lo]
+  auto ld = [&](sp16x8 (&k)[2][2], sp16x8 (&v)[2][2], int pr) {
     const int t1 = min(2 * pr + 1, tiles - 1);                  // odd tile count: the second K of the last pair re-reads the last tile (masked)
 #pragma unroll
     for (int hl = 0; hl < 2; ++hl) {
-      k[0][hl] = *(const bf16x8_*)(kb + (size_t)(2 * pr) * 2048 + hl * 1024);
-      k[1][hl] = *(const bf16x8_*)(kb + (size_t)t1 * 2048 + hl * 1024);
+      k[0][hl] = *(const sp16x8*)(kb + (size_t)(2 * pr) * 2048 + hl * 1024);
+      k[1][hl] = *(const sp16x8*)(kb + (size_t)t1 * 2048 + hl * 1024);
 #pragma unroll
-      for (int d = 0; d < 2; ++d) v[d][hl] = *(const bf16x8_*)(vb + (size_t)pr * 4096 + (d * 2 + hl) * 1024);
+      for (int d = 0; d < 2; ++d) v[d][hl] = *(const sp16x8*)(vb + (size_t)pr * 4096 + (d * 2 + hl) * 1024);
     }
   };
   ld(kc, vc, 0);
@@ -456,9 +455,9 @@ __device__ void self_attention_rows_split(const DecArgs& a, const float* sQ, int
     f32x4_ S[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      S[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[e][1], qh, S[e], 0, 0, 0);
-      S[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[e][0], ql, S[e], 0, 0, 0);
-      S[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[e][0], qh, S[e], 0, 0, 0);
+      S[e] = mfma_pair16(kc[e][1], qh, S[e]);
+      S[e] = mfma_pair16(kc[e][0], ql, S[e]);
+      S[e] = mfma_pair16(kc[e][0], qh, S[e]);
     }
     float sv[2][4];
     float mx = -INFINITY;
@@ -473,7 +472,7 @@ __device__ void self_attention_rows_split(const DecArgs& a, const float* sQ, int
     mx = rows4_max(mx);
     const float mn = fmaxf(m, mx);
     const float alpha = __expf(m - mn);
-    bf16x8_ ph, pl;
+    sp16x8 ph, pl;
     float rs = 0.f;
 #pragma unroll
     for (int e = 0; e < 2; ++e)
@@ -481,9 +480,9 @@ __device__ void self_attention_rows_split(const DecArgs& a, const float* sQ, int
       for (int r = 0; r < 4; ++r) {
         const float pv = __expf(sv[e][r] - mn);
         rs += pv;
-        const bf16 hi = (bf16)pv;
+        const sp16 hi = (sp16)pv;
         ph[4 * e + r] = hi;
-        pl[4 * e + r] = (bf16)(pv - (float)hi);
+        pl[4 * e + r] = (sp16)(pv - (float)hi);
       }
     rs = rows4_sum(rs);
     l = l * alpha + rs;
@@ -492,9 +491,9 @@ __device__ void self_attention_rows_split(const DecArgs& a, const float* sQ, int
     for (int d = 0; d < 2; ++d) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) O[d][r] *= alpha;
-      O[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc[d][1], ph, O[d], 0, 0, 0);
-      O[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc[d][0], pl, O[d], 0, 0, 0);
-      O[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc[d][0], ph, O[d], 0, 0, 0);
+      O[d] = mfma_pair16(vc[d][1], ph, O[d]);
+      O[d] = mfma_pair16(vc[d][0], pl, O[d]);
+      O[d] = mfma_pair16(vc[d][0], ph, O[d]);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -532,28 +531,27 @@ __device__ __forceinline__ void touch_weights(const DecLin& L, int part, int npa
 // SPLIT: the linear layers take hi/lo bf16 splits of their operands (row_gemm_split); every fp32 A operand of K <= 256 is split
 // into the sXh/sXl staging rows right before its GEMM, the two wide ones (FFN hidden 1024, qpos hidden 512) are written as
 // splits by the producing GEMM straight into the sF region (same bytes as the fp32 rows they replace).
-template <int SPLIT, int DPF = 2>   // DPF: K steps of filter fragments each wave keeps in flight in the split GEMMs
+template <int SPLIT>
 __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
   // LDS (floats).  Row strides are (cols + 4): ds_read_b128 of 16 rows x 4 k-groups is conflict-free.
   constexpr int LDH = 260, LDF = 1028, LDQ = 516, LDO = 292, LDR = 68;
-  constexpr int LDX = 264, LDFB = 1032, LDQB = 520;             // bf16 row strides (16-byte rows, 4-bank skew per row)
+  constexpr int LDX = 264, LDFB = 1032, LDQB = 520;             // sp16 row strides (16-byte rows, 4-bank skew per row)
   __shared__ __attribute__((aligned(16))) float sH[DR * LDH];   // hs / running activation x
   __shared__ __attribute__((aligned(16))) float sP[DR * LDH];   // query_pos of this layer, later of the next
   __shared__ __attribute__((aligned(16))) float sA[DR * LDH];   // attention out / sampled values / scratch
-  __shared__ __attribute__((aligned(16))) float sF[DR * LDF + 64];   // FFN hidden (1024); SPLIT: bf16 hi rows | lo rows
-  __shared__ __attribute__((aligned(16))) bf16 sXh[SPLIT ? DR * LDX : 8], sXl[SPLIT ? DR * LDX : 8];
+  __shared__ __attribute__((aligned(16))) float sF[DR * LDF + 64];   // FFN hidden (1024); SPLIT: sp16 hi rows | lo rows
+  __shared__ __attribute__((aligned(16))) sp16 sXh[SPLIT ? DR * LDX : 8], sXl[SPLIT ? DR * LDX : 8];
   __shared__ __attribute__((aligned(16))) char sDummy[256];     // touch_weights target
   float* const sT = sF;                                         // 512-wide scratch (bbox hidden, qpos hidden, q|k): live only while sF is dead
-  bf16* const sFh = (bf16*)sF;
-  bf16* const sFl = sFh + DR * LDFB;
-  bf16* const sQh = (bf16*)sF;                                  // qpos hidden (512) as a split, live between qp0 and qp1
-  bf16* const sQl = sQh + DR * LDQB;
+  sp16* const sFh = (sp16*)sF;
+  sp16* const sFl = sFh + DR * LDFB;
+  sp16* const sQh = (sp16*)sF;                                  // qpos hidden (512) as a split, live between qp0 and qp1
+  sp16* const sQl = sQh + DR * LDQB;
   static_assert(2 * DR * LDFB * 2 <= (DR * LDF + 64) * 4, "split FFN hidden must fit the fp32 region");
   __shared__ __attribute__((aligned(16))) float sO[DR * LDO];   // sampling offsets | attention logits
   __shared__ __attribute__((aligned(16))) float sR[DR * LDR];   // ref boxes (cols 0..3), zero padded to 64 (K of qpos.0)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const size_t wmask = (a.probe & 1) ? (size_t)0xFFFF : ~(size_t)0;
   // Y[16][N] = act(X[16][K] W^T + b (+ R)); X fp32 rows in LDS.  SPLIT: X is first split into sXh/sXl (all waves must have
   // left the previous GEMM: every call site below sits behind a __syncthreads()).
 #define DEC_TOUCH(LW) touch_weights(LW, rot, tiles, tid, sDummy)
@@ -562,7 +560,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (SPLIT) {                                                                                             \
       split_rows(X, LDXS, (LW).K, sXh, sXl, LDX, tid);                                                       \
       __syncthreads();                                                                                       \
-      row_gemm_split<ACT, (SPLIT != 2), DPF>(sXh, sXl, LDX, LW, Y, LDY, R, LDRS, nullptr, nullptr, 0, wave, lane, rot, wmask);         \
+      row_gemm_split<ACT, (SPLIT != 2) >(sXh, sXl, LDX, LW, Y, LDY, R, LDRS, nullptr, nullptr, 0, wave, lane, rot);         \
     } else {                                                                                                 \
       row_gemm<ACT>(X, LDXS, LW, Y, LDY, R, LDRS, wave, lane, rot);                                          \
     }                                                                                                        \
@@ -659,8 +657,8 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (SPLIT) {
       split_rows(sH, LDH, a.fc1.K, sXh, sXl, LDX, tid);
       __syncthreads();
-      if (a.mode == 4) row_gemm_split<ACT_GELU, (SPLIT != 2), DPF>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot, wmask);
-      else row_gemm_split<ACT_RELU, (SPLIT != 2), DPF>(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot, wmask);
+      if (a.mode == 4) row_gemm_split<ACT_GELU, (SPLIT != 2) >(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
+      else row_gemm_split<ACT_RELU, (SPLIT != 2) >(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
     } else {
       if (a.mode == 4) row_gemm<ACT_GELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane, rot);
       else row_gemm<ACT_RELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane, rot);
@@ -668,7 +666,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     DEC_TOUCH(a.bb0);
     __syncthreads();
     DEC_STAMP(6);   // fc1
-    if (SPLIT) row_gemm_split<ACT_NONE, (SPLIT != 2), DPF>(sFh, sFl, LDFB, a.fc2, sH, LDH, sH, LDH, nullptr, nullptr, 0, wave, lane, rot, wmask);
+    if (SPLIT) row_gemm_split<ACT_NONE, (SPLIT != 2) >(sFh, sFl, LDFB, a.fc2, sH, LDH, sH, LDH, nullptr, nullptr, 0, wave, lane, rot);
     else row_gemm<ACT_NONE>(sF, LDF, a.fc2, sH, LDH, sH, LDH, wave, lane, rot);
     DEC_TOUCH(a.bb1);
     __syncthreads();
@@ -744,10 +742,10 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (SPLIT) {
       split_rows(sR, LDR, a.qp0.K, sXh, sXl, LDX, tid);
       __syncthreads();
-      row_gemm_split<ACT_RELU, (SPLIT != 2), DPF>(sXh, sXl, LDX, a.qp0, nullptr, 0, nullptr, 0, sQh, sQl, LDQB, wave, lane, rot, wmask);
+      row_gemm_split<ACT_RELU, (SPLIT != 2) >(sXh, sXl, LDX, a.qp0, nullptr, 0, nullptr, 0, sQh, sQl, LDQB, wave, lane, rot);
       DEC_TOUCH(a.v);
       __syncthreads();
-      row_gemm_split<ACT_NONE, (SPLIT != 2), DPF>(sQh, sQl, LDQB, a.qp1, sP, LDH, nullptr, 0, nullptr, nullptr, 0, wave, lane, rot, wmask);
+      row_gemm_split<ACT_NONE, (SPLIT != 2) >(sQh, sQl, LDQB, a.qp1, sP, LDH, nullptr, 0, nullptr, nullptr, 0, wave, lane, rot);
     } else {
       row_gemm<ACT_RELU>(sR, LDR, a.qp0, sT, LDQ, nullptr, 0, wave, lane, rot);
       DEC_TOUCH(a.v);
@@ -781,29 +779,28 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     for (int e = tid; e < a.heads * 128; e += NT) {              // K: one 16-byte piece per (head, hi/lo, lane)
       const int h = e >> 7, hl = (e >> 6) & 1, ln = e & 63;
       const int kr = ln & 15;
-      bf16x8_ o;
+      sp16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float x = kr < nvalid ? sT[kr * LDQ + D + h * 32 + 8 * (ln >> 4) + j] : 0.f;
-        const bf16 hi = (bf16)x;
-        o[j] = hl ? (bf16)(x - (float)hi) : hi;
+        const sp16 hi = (sp16)x;
+        o[j] = hl ? (sp16)(x - (float)hi) : hi;
       }
-      *(bf16x8_*)((char*)a.kfrag_out + ((size_t)(b * a.heads + h) * tp + tile) * 2048 + hl * 1024 + ln * 16) = o;
+      *(sp16x8*)((char*)a.kfrag_out + ((size_t)(b * a.heads + h) * tp + tile) * 2048 + hl * 1024 + ln * 16) = o;
     }
-    typedef __bf16 bf16x4_d __attribute__((ext_vector_type(4)));
     for (int e = tid; e < a.heads * 256; e += NT) {              // V: one 8-byte piece per (head, d, hi/lo, lane)
       const int h = e >> 8, d = (e >> 7) & 1, hl = (e >> 6) & 1, ln = e & 63;
-      bf16x4_d o;
+      sp16x4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int vr = 4 * (ln >> 4) + r;
         const float x = vr < nvalid ? sO[vr * LDO + h * 32 + 16 * d + (ln & 15)] : 0.f;
-        const bf16 hi = (bf16)x;
-        o[r] = hl ? (bf16)(x - (float)hi) : hi;
+        const sp16 hi = (sp16)x;
+        o[r] = hl ? (sp16)(x - (float)hi) : hi;
       }
       char* dst = (char*)a.vfrag_out + ((size_t)(b * a.heads + h) * tp + 2 * pr) * 2048 + (d * 2 + hl) * 1024 + ln * 16;
-      *(bf16x4_d*)(dst + eh * 8) = o;
-      if (zero_partner) *(bf16x4_d*)(dst + 8) = bf16x4_d{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+      *(sp16x4*)(dst + eh * 8) = o;
+      if (zero_partner) *(sp16x4*)(dst + 8) = sp16x4{(sp16)0.f, (sp16)0.f, (sp16)0.f, (sp16)0.f};
     }
   } else {
     const int tile = q0 / DR;
@@ -945,17 +942,11 @@ void launch_gather_ln(const float* x, int64_t ldx, int rows_per_image, const int
   HIP_CHECK(hipGetLastError());
 }
 
-static int g_dec_probe = 0; // dec_pf += 16: DecArgs::probe bit 0
-static int g_dec_pf = 2;    // A/B hook (rtd_debug_option "dec_pf"): filter K steps in flight per wave in the split GEMMs (2 or 3)
-void dec_set_pf(int v) { g_dec_pf = v & 15; g_dec_probe = v >> 4; }
-void launch_dec_layer(const DecArgs& a_in, hipStream_t s) {
-  DecArgs a = a_in;
-  a.probe = g_dec_probe;
+void launch_dec_layer(const DecArgs& a, hipStream_t s) {
   RTD_CHECK(a.D == 256 && a.D / a.heads == 32 && a.ffn <= 1024 && a.C <= 512, 1, "fused decoder: d_model 256, head dim 32, ffn <= 1024");
   RTD_CHECK(a.n_levels == 3 && a.n_points == 4 && a.heads == NW, 1, "fused decoder: 3 levels x 4 points, 8 heads");
   const int tiles = (a.Q + DR - 1) / DR;
   if (a.split == 2) hipLaunchKernelGGL(dec_layer_kernel<2>, dim3(a.B * tiles), dim3(NT), 0, s, a);
-  else if (a.split && g_dec_pf == 3) hipLaunchKernelGGL((dec_layer_kernel<1, 3>), dim3(a.B * tiles), dim3(NT), 0, s, a);
   else if (a.split) hipLaunchKernelGGL(dec_layer_kernel<1>, dim3(a.B * tiles), dim3(NT), 0, s, a);
   else hipLaunchKernelGGL(dec_layer_kernel<0>, dim3(a.B * tiles), dim3(NT), 0, s, a);
   HIP_CHECK(hipGetLastError());

@@ -30,7 +30,7 @@ thread_local std::string g_create_error;
 // test - cannot change a live handle.
 struct PlanOpts {
   int dec_stamps = 0;   // record per-phase stamps of decoder layer 2 into debug tensor "dec_stamps"
-  int dec_split = 1;    // bf16 / bf16x3 engines run the fused decoder / AIFI linears as bf16 hi/lo splits (0: fp32 MFMA, 2: bf16 filters)
+  int dec_split = 1;    // bf16 / f16x3 engines run the fused decoder / AIFI linears as bf16 hi/lo splits (0: fp32 MFMA, 2: bf16 filters)
   int sc_fold = 1;      // fold a block's projection shortcut into its last conv (ConvArgs::x2)
   int c1_fuse = 1;      // bf16 plans run a stage-0 block's reduce conv inside the previous block's last conv
   // self-attention on hi/lo bf16 MFMAs - bit 0 AIFI, bit 1 decoder.  Default: decoder only (logits agree with the fp32-MFMA attention
@@ -40,7 +40,7 @@ struct PlanOpts {
   int up_fold = 1;      // read the FPN's upsampled lateral straight from the half-size tensor (ConvArgs::x_up2)
   int arena_reuse = 1;  // backbone stages recycle their activation buffers
   int stem_fused = 0;   // bf16 engine runs backbone.stem.0 straight from the uint8 frames (measured neutral -> off, kept tested)
-  int stem_fused_split = 1;   // the same for the bf16x3 engine (hi/lo pairs made on the fly from the bytes): on
+  int stem_fused_split = 1;   // the same for the f16x3 engine (hi/lo pairs made on the fly from the bytes): on
   int sel_fused = 1;    // LayerNorm + score head + class max of the query selection in one launch
   int dec_fused = 1;    // 0 = one launch per decoder op
   int side_stream = 3;  // bit 0: the query-selection chain runs on a second stream beside the value projection; bit 1: the decoder input
@@ -102,6 +102,7 @@ struct ResizeTables {
 struct rtd_engine {
   rtd_config cfg;
   PlanOpts opts;           // snapshot of g_opts at rtd_create
+  ConvOpts conv_opts;      // snapshot of the conv dispatch switches at rtd_create (every launch of this handle's plans points here)
   bool force_used = false; // rtd_debug_force_topk was called on this handle: plans include the (debug-only) index override launch
   std::mutex mu;
   std::string err;
@@ -129,7 +130,6 @@ struct rtd_engine {
   float* anchors_dev = nullptr; int32_t* invalid_rows_dev = nullptr; int n_invalid = 0;
   int32_t* lvl_dev = nullptr;
   float* pos_dev = nullptr;
-  ConvWorkspace conv_ws;
   int last_n = 0;
 
   void* dmalloc(size_t bytes) {
@@ -182,9 +182,9 @@ const HostTensor& host_tensor(rtd_engine* e, const std::string& name) {
   return it->second;
 }
 
-// host [Npad][Kcols] fp32 (zero padded) -> device filter in dt: fp32 as is, bf16 rounded, BF16X2 as [32 hi | 32 lo] groups along K
+// host [Npad][Kcols] fp32 (zero padded) -> device filter in dt: fp32 as is, bf16 rounded, F16X2 as [32 hi | 32 lo] groups along K
 // (Kcols % 32 == 0: a row has 2 * Kcols bf16 elements, the layout of an activation pixel with Kcols channels)
-static const char* dt_tag(int dt) { return dt == BF16 ? "#bf16" : (dt == BF16X2 ? "#bf16x2" : "#f32"); }
+static const char* dt_tag(int dt) { return dt == BF16 ? "#bf16" : (dt == F16X2 ? "#f16x2" : "#f32"); }
 static void* upload_filter(rtd_engine* e, const std::vector<float>& pad, int Npad, int Kcols, int dt) {
   float* tmp = nullptr;
   void* out = nullptr;
@@ -196,7 +196,7 @@ static void* upload_filter(rtd_engine* e, const std::vector<float>& pad, int Npa
         out = tmp;
         e->allocs.push_back(tmp);
         tmp = nullptr;
-      } else if (dt == BF16X2) {
+      } else if (dt == F16X2) {
         out = e->dmalloc(pad.size() * 4);
         launch_f32_to_split(tmp, Kcols, out, Kcols, Npad, Kcols, e->stream);
         er = hipStreamSynchronize(e->stream);
@@ -225,8 +225,8 @@ DevWeight get_weight(rtd_engine* e, const std::string& name, int dt, int N, int 
   RTD_CHECK(!w.shape.empty() && w.shape[0] == N && w.numel() == (int64_t)N * K, RTD_E_WEIGHTS, "weight shape mismatch: " + name);
   RTD_CHECK(b.numel() == N, RTD_E_WEIGHTS, "bias shape mismatch: " + name);
   DevWeight d;
-  d.N = N; d.K = K; d.Kpad = dt == BF16X2 ? conv_kpad_split(K) : conv_kpad(K); d.Npad = conv_npad(N); d.dt = dt;
-  const int kcols = dt == BF16X2 ? d.Kpad / 2 : d.Kpad;
+  d.N = N; d.K = K; d.Kpad = dt == F16X2 ? conv_kpad_split(K) : conv_kpad(K); d.Npad = conv_npad(N); d.dt = dt;
+  const int kcols = dt == F16X2 ? d.Kpad / 2 : d.Kpad;
   std::vector<float> pad((size_t)d.Npad * kcols, 0.f);
   for (int r = 0; r < N; ++r) memcpy(&pad[(size_t)r * kcols], w.data + (size_t)r * K, (size_t)K * 4);
   d.w = upload_filter(e, pad, d.Npad, kcols, dt);
@@ -251,8 +251,8 @@ DevWeight get_weight_cat(rtd_engine* e, const std::string& n1, const std::string
   RTD_CHECK(w1.numel() == (int64_t)N * K1 && w2.numel() == (int64_t)N * K2 && b1.numel() == N && b2.numel() == N, RTD_E_WEIGHTS,
             "weight shape mismatch: " + n1 + " + " + n2);
   DevWeight d;
-  d.N = N; d.K = K1 + K2; d.Kpad = dt == BF16X2 ? conv_kpad_split(d.K) : conv_kpad(d.K); d.Npad = conv_npad(N); d.dt = dt;
-  const int kcols = dt == BF16X2 ? d.Kpad / 2 : d.Kpad;
+  d.N = N; d.K = K1 + K2; d.Kpad = dt == F16X2 ? conv_kpad_split(d.K) : conv_kpad(d.K); d.Npad = conv_npad(N); d.dt = dt;
+  const int kcols = dt == F16X2 ? d.Kpad / 2 : d.Kpad;
   std::vector<float> pad((size_t)d.Npad * kcols, 0.f);
   for (int r = 0; r < N; ++r) {
     memcpy(&pad[(size_t)r * kcols], w1.data + (size_t)r * K1, (size_t)K1 * 4);
@@ -268,18 +268,18 @@ DevWeight get_weight_cat(rtd_engine* e, const std::string& n1, const std::string
 }
 
 // fp32 filter [N][K] -> fragment-major layout of decoder.hip's row_gemm (K padded to Kuse, N to 8 tiles)
-static inline uint16_t f2bf_rne(float f) {
-  uint32_t u;
-  memcpy(&u, &f, 4);
-  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);     // inf / nan: truncate
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+// host-side fp16 round-to-nearest-even (subnormals kept, saturating like common.h split2) through the compiler's _Float16
+static inline uint16_t f2h_rne(float f) {
+  f = f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f);
+  const _Float16 h = (_Float16)f;
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
 }
-static inline float bf2f(uint16_t h) {
-  const uint32_t u = (uint32_t)h << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
+static inline float h2f(uint16_t u) {
+  _Float16 h;
+  memcpy(&h, &u, 2);
+  return (float)h;
 }
 
 DevWeight get_weight_packed(rtd_engine* e, const std::string& name, int N, int K, int Kuse, bool split = false) {
@@ -303,8 +303,8 @@ DevWeight get_weight_packed(rtd_engine* e, const std::string& name, int N, int K
           if (n < N && k < K) pk[(((size_t)t * kc + c) * 64 + lane) * 4 + j] = w.data[(size_t)n * K + k];
         }
   if (split) {
-    // W = hi + lo (two bf16, round-to-nearest-even each): decoder.hip row_gemm_split multiplies both against a hi/lo split of
-    // the activations with 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi); the dropped lo*lo term is ~2^-18 relative
+    // W = hi + lo (two fp16, round-to-nearest-even each): decoder.hip row_gemm_split multiplies both against a hi/lo split of
+    // the activations with 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi); the dropped lo*lo term is ~2^-22 relative
     const int kc32 = Kuse / 32;
     std::vector<uint16_t> ps((size_t)ntiles * kc32 * 2 * 512, 0);
     for (int t = 0; t < ntiles; ++t)
@@ -314,8 +314,8 @@ DevWeight get_weight_packed(rtd_engine* e, const std::string& name, int N, int K
             const int n = t * 16 + (lane & 15), k = c * 32 + 8 * (lane >> 4) + j;
             if (n < N && k < K) {
               const float v = w.data[(size_t)n * K + k];
-              const uint16_t hi = f2bf_rne(v);
-              const uint16_t lo = f2bf_rne(v - bf2f(hi));
+              const uint16_t hi = f2h_rne(v);
+              const uint16_t lo = f2h_rne(v - h2f(hi));
               const size_t base = ((size_t)t * kc32 + c) * 1024;
               ps[base + lane * 8 + j] = hi;
               ps[base + 512 + lane * 8 + j] = lo;
@@ -483,7 +483,7 @@ struct Builder {
     DevWeight w;
     // name2 empty: `name` is already the filter over [x | x2] (a conv over a concatenation that is read from its two sources)
     if (!dry) w = (x2 && !name2.empty()) ? get_weight_cat(e, name, name2, x.dt, y.c, k * k * x.c, x2->c) : get_weight(e, name, x.dt, y.c, K);
-    else { w.Kpad = x.dt == BF16X2 ? conv_kpad_split(K) : conv_kpad(K); w.Npad = conv_npad(y.c); }
+    else { w.Kpad = x.dt == F16X2 ? conv_kpad_split(K) : conv_kpad(K); w.Npad = conv_npad(y.c); }
     ConvArgs a;
     a.x = x; a.y = y; a.w = w.w; a.bias = w.bias;
     if (x2) a.x2 = *x2;
@@ -494,11 +494,12 @@ struct Builder {
     if (next_y) {                                              // the following 1x1 conv rides on this launch (ConvArgs::next_*)
       DevWeight wn;
       if (!dry) wn = get_weight(e, next_name, x.dt, next_y->c, y.c);
-      else { wn.Kpad = x.dt == BF16X2 ? conv_kpad_split(y.c) : conv_kpad(y.c); wn.Npad = conv_npad(next_y->c); }
+      else { wn.Kpad = x.dt == F16X2 ? conv_kpad_split(y.c) : conv_kpad(y.c); wn.Npad = conv_npad(next_y->c); }
       a.next_w = wn.w; a.next_bias = wn.bias; a.next_y = *next_y; a.next_kpad = wn.Kpad; a.next_act = next_act;
     }
-    a.ws = e->conv_ws;
+    a.opts = &e->conv_opts;
     a.prefer256 = e->cfg.profile == RTD_PROFILE_THROUGHPUT;
+    slab_need = std::max(slab_need, conv_split_slab_bytes(a));
     const double M = (double)y.pixels();
     const double kreal = (double)k * k * (real_cin ? real_cin : x.c) + (x2 ? x2->c : 0);
     const double flops = 2.0 * M * y.c * kreal + (next_y ? 2.0 * M * y.c * next_y->c : 0.0);
@@ -509,25 +510,37 @@ struct Builder {
       // chain: the previous conv launch of the plan prefetches THIS filter while it runs (ConvArgs::pf)
       if (last_conv) { last_conv->pf = w.w; last_conv->pf_bytes = (size_t)w.Npad * w.Kpad * (x.dt == F32 ? 4 : 2); }
       last_conv = ap;
+      convs.push_back(ap);
     }
     push(name, "conv_igemm", flops, bytes, [ap](hipStream_t s) { launch_conv(*ap, s); });
   }
   std::shared_ptr<ConvArgs> last_conv;
+  // two-pass split-K workspace of this plan: sized for the plan's own batch (the slice count depends on per-image extents only, so every
+  // batch size up to max_batch runs the same arithmetic), allocated once every conv is known and handed to all of them
+  std::vector<std::shared_ptr<ConvArgs>> convs;
+  size_t slab_need = 0;
+  void finish_workspace() {
+    if (!slab_need) return;
+    ConvWorkspace ws;
+    ws.slab = (float*)alloc(slab_need);
+    ws.slab_bytes = slab_need;
+    for (auto& c : convs) c->ws = ws;
+  }
   Tensor linear(const std::string& name, const Tensor& x, int N, int odt, int act, const Tensor* res = nullptr,
                 const std::string& tname = "") {
     Tensor y = this->act(odt, x.n, x.h, x.w, N, tname);
     conv(name, x, y, 1, 1, 0, act, res, RES_PRE);
     return y;
   }
-  // dense fp32 rows -> BF16X2 rows (the split engine's trunk type) as its own launch
+  // dense fp32 rows -> F16X2 rows (the split engine's trunk type) as its own launch
   Tensor to_split(const std::string& name, const Tensor& x, const std::string& tname = "") {
-    Tensor y = act(BF16X2, x.n, x.h, x.w, x.c, tname);
+    Tensor y = act(F16X2, x.n, x.h, x.w, x.c, tname);
     const int64_t rows = x.pixels();
     push(name, "convert", 0.0, tbytes(x) + tbytes(y), [x, y, rows](hipStream_t s) { launch_f32_to_split((const float*)x.p, x.ld, y.p, y.ld, rows, x.c, s); });
     return y;
   }
   Tensor layernorm(const std::string& name, const Tensor& x, int odt, const std::string& tname = "") {
-    if (odt == BF16X2) return to_split(name + ".split", layernorm(name, x, F32), tname);
+    if (odt == F16X2) return to_split(name + ".split", layernorm(name, x, F32), tname);
     Tensor y = act(odt, x.n, x.h, x.w, x.c, tname);
     if (dry) return y;
     const float* g = get_vec(e, name + ".g", x.c);
@@ -541,7 +554,7 @@ struct Builder {
 void build_graph(rtd_engine* e, Builder& B, int n) {
   const rtd_config& c = e->cfg;
   const int P = e->P;
-  const bool SP = P == BF16X2;            // rtd_config.precision = RTD_PREC_BF16X3: the trunk carries hi/lo bf16 pairs
+  const bool SP = P == F16X2;            // rtd_config.precision = RTD_PREC_F16X3: the trunk carries hi/lo bf16 pairs
   const int H = c.input_h, W = c.input_w;
   Plan* plan = B.plan;
   auto nm = [](const char* fmt, int a = 0, int b = 0) {
@@ -551,12 +564,12 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   };
 
   // ---- input + stem (HF:rt_detr_resnet.py:71-114) ----------------------------------------------
-  Tensor x = B.act(SP ? F32 : P, n, H, W, 8, "input");   // split engine: fp32 pixels, stem.0 runs on fp32 MFMAs (K = 27) and writes BF16X2
+  Tensor x = B.act(SP ? F32 : P, n, H, W, 8, "input");   // split engine: fp32 pixels, stem.0 runs on fp32 MFMAs (K = 27) and writes F16X2
   plan->input = x;
   const int eh = c.embedding_size / 2;
   int h = down2(H), w = down2(W);
   Tensor s0 = B.act(P, n, h, w, eh);
-  // bf16x3: on by default - the generic form there is a 105 MB fp32 NHWC-8 image + an fp32-MFMA stem conv (30 + 180 us at R50 bs 8)
+  // f16x3: on by default - the generic form there is a 105 MB fp32 NHWC-8 image + an fp32-MFMA stem conv (30 + 180 us at R50 bs 8)
   plan->stem_fused = ((e->opts.stem_fused && P == BF16) || (SP && e->opts.stem_fused_split)) && eh == 32;
   if (plan->stem_fused) {
     // straight from the uint8 frames (ops.hip stem0_u8_kernel); `x` is only materialised on demand for rtd_debug_tensor("input")
@@ -637,6 +650,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
           // of an engine must use the same filters (the host copies are dropped after the first plan) and the same arithmetic
           // (batch invariance), and a single image has the smallest grid
           ConvArgs probe;
+          probe.opts = &e->conv_opts;
           Tensor yv; yv.dt = P; yv.n = 1; yv.h = oh; yv.w = ow; yv.c = cout; yv.ld = cout; yv.bstride = (int64_t)oh * ow * cout; yv.p = (void*)16;
           Tensor xv = yv; xv.c = xv.ld = (c.layer_type == RTD_LAYER_BOTTLENECK ? mid : cout); xv.bstride = (int64_t)oh * ow * xv.c;
           Tensor x2v = sc_in; x2v.p = (void*)16; x2v.n = 1;
@@ -659,7 +673,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
         Tensor t2 = e->opts.arena_reuse ? view(tb2, oh, ow, mid, "") : B.act(P, n, oh, ow, mid);
         B.conv(pfx + ".c2", t1, t2, 3, stride, 1, ACT_RELU);
         // fuse the NEXT block's c1 (1x1, stride 1, reads `out` at these extents) when the streaming kernel takes this conv: the next block of
-        // this stage, or (bf16x3 plans) block 0 of the next stage, whose c1 runs before that block's stride
+        // this stage, or (f16x3 plans) block 0 of the next stage, whose c1 runs before that block's stride
         const Tensor* nx = nullptr;
         std::string nx_name;
         const bool same_stage = bi + 1 < c.depths[si];
@@ -668,6 +682,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
           const int mid_n = same_stage ? mid : c.hidden_sizes[si + 1] / 4;
           Tensor t1_shape = out; t1_shape.c = t1_shape.ld = mid_n; t1_shape.bstride = (int64_t)oh * ow * mid_n;
           ConvArgs probe;                                        // this plan's shapes (fused and separate launches are bit-identical)
+          probe.opts = &e->conv_opts;
           probe.x = t2; probe.x.p = (void*)16;
           probe.y = out; probe.y.p = (void*)16;
           if (fold_sc) { probe.x2 = sc_in; probe.x2.p = (void*)16; }
@@ -784,6 +799,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     bool up_fold = false;
     if (up_src && (P == BF16 || SP) && e->opts.up_fold) {
       ConvArgs probe;                                          // shapes for ONE image, like the shortcut fold
+      probe.opts = &e->conv_opts;
       probe.x = *up_src; probe.x.p = (void*)16; probe.x.n = 1;
       probe.x2 = cat.slice_c(d, d); probe.x2.p = (void*)16; probe.x2.n = 1;
       probe.y = h12; probe.y.p = (void*)16; probe.y.n = 1;
@@ -885,6 +901,10 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   }
   int32_t* tk = (int32_t*)B.alloc((size_t)n * Q * 4);
   plan->tk_idx = tk;
+  {
+    Tensor t; t.p = tk; t.dt = I32; t.n = n; t.h = Q; t.w = 1; t.c = 1; t.ld = 1; t.bstride = Q;
+    plan->named["topk"] = t;          // the memory-token ids the decoder ran on (after rtd_debug_force_topk, the forced ones)
+  }
   {
     const int32_t* forced = e->forced_idx; const int32_t* flag = e->force_flag;
     B.push("dec.enc_topk", "topk", 0.0, (double)n * S * 4 * 6, [mx, n, S, Q, tk](hipStream_t s) { launch_topk(mx, n, S, Q, tk, nullptr, s); });
@@ -1058,6 +1078,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       launch_postprocess_gather(topv, topi, ref8, scale, n, Q, C, block6, s);
     });
   }
+  B.finish_workspace();
 }
 
 Plan* get_plan(rtd_engine* e, int n) {
@@ -1274,7 +1295,7 @@ int rtd_create(const rtd_config* cfg, rtd_handle* out) {
   if (!cfg || !out) { g_create_error = "null argument"; return RTD_E_INVALID; }
   try {
     RTD_CHECK(cfg->struct_size == (int32_t)sizeof(rtd_config), RTD_E_INVALID, "rtd_config.struct_size mismatch");
-    RTD_CHECK(cfg->precision == RTD_PREC_BF16 || cfg->precision == RTD_PREC_FP32 || cfg->precision == RTD_PREC_BF16X3, RTD_E_INVALID, "precision");
+    RTD_CHECK(cfg->precision == RTD_PREC_BF16 || cfg->precision == RTD_PREC_FP32 || cfg->precision == RTD_PREC_F16X3, RTD_E_INVALID, "precision");
     RTD_CHECK(cfg->max_batch >= 1 && cfg->max_batch <= 64, RTD_E_INVALID, "max_batch must be in [1,64]");
     RTD_CHECK(cfg->profile == RTD_PROFILE_LATENCY || cfg->profile == RTD_PROFILE_THROUGHPUT, RTD_E_INVALID, "profile");
     // the FPN concatenates a 2x-upsampled map with the next level: every level must halve exactly
@@ -1290,12 +1311,13 @@ int rtd_create(const rtd_config* cfg, rtd_handle* out) {
     rtd_engine* e = new rtd_engine();
     e->cfg = *cfg;
     e->opts = g_opts;
-    e->P = cfg->precision == RTD_PREC_BF16 ? BF16 : (cfg->precision == RTD_PREC_BF16X3 ? BF16X2 : F32);
-    if (e->P == BF16X2) {
-      // hi/lo pairs travel in 32-channel groups (common.h BF16X2): every trunk width must be whole groups
+    e->conv_opts = conv_opts_template();
+    e->P = cfg->precision == RTD_PREC_BF16 ? BF16 : (cfg->precision == RTD_PREC_F16X3 ? F16X2 : F32);
+    if (e->P == F16X2) {
+      // hi/lo pairs travel in 32-channel groups (common.h F16X2): every trunk width must be whole groups
       bool ok = (cfg->embedding_size / 2) % SPLIT_GROUP == 0 && cfg->enc_dim % SPLIT_GROUP == 0 && cfg->csp_hidden % SPLIT_GROUP == 0 && cfg->d_model % SPLIT_GROUP == 0;
       for (int i = 0; i < 4; ++i) ok = ok && cfg->hidden_sizes[i] % SPLIT_GROUP == 0 && (cfg->layer_type != RTD_LAYER_BOTTLENECK || (cfg->hidden_sizes[i] / 4) % SPLIT_GROUP == 0);
-      if (!ok) { delete e; RTD_CHECK(false, RTD_E_INVALID, "precision bf16x3 needs every trunk channel count to be a multiple of 32 (embedding_size of 64)"); }
+      if (!ok) { delete e; RTD_CHECK(false, RTD_E_INVALID, "precision f16x3 needs every trunk channel count to be a multiple of 32 (embedding_size of 64)"); }
     }
     *out = e;
     return RTD_OK;
@@ -1349,12 +1371,6 @@ int rtd_load_weights(rtd_handle h, const void* blob, size_t nbytes) {
     std::vector<float> pos = sincos_pos(e->lvl_h[2], e->lvl_w[2], c.enc_dim);
     e->pos_dev = (float*)e->dmalloc(pos.size() * 4);
     HIP_CHECK(hipMemcpy(e->pos_dev, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
-    // split-K scratch: 600 blocks x 64 KiB slabs cover every small-grid layer; tickets start (and always return to) zero
-    e->conv_ws.slab_bytes = (size_t)640 * 128 * 128 * 4;
-    e->conv_ws.slab = (float*)e->dmalloc(e->conv_ws.slab_bytes);
-    e->conv_ws.cnt_entries = 1024;
-    e->conv_ws.cnt = (unsigned*)e->dmalloc(e->conv_ws.cnt_entries * 4);
-    HIP_CHECK(hipMemset(e->conv_ws.cnt, 0, e->conv_ws.cnt_entries * 4));
     e->forced_idx = (int32_t*)e->dmalloc((size_t)c.max_batch * c.num_queries * 4);
     e->force_flag = (int32_t*)e->dmalloc(16);
     HIP_CHECK(hipMemset(e->force_flag, 0, 16));
@@ -1492,14 +1508,21 @@ int rtd_debug_tensor(rtd_handle h, const char* name, float* out, int64_t capacit
     RTD_CHECK(t.bstride == (int64_t)t.h * t.w * t.ld, RTD_E_INVALID, "debug tensor: non-dense batch stride");
     HIP_CHECK(hipSetDevice(h->cfg.device));
     const size_t es = dtype_size(t.dt);
-    if (t.dt == BF16X2) RTD_CHECK(t.c % SPLIT_GROUP == 0, RTD_E_INVALID, "debug tensor: split tensor with a partial channel group");
+    if (t.dt == I32) {                                             // index tensors: exact as fp32 (token ids < 2^24)
+      std::vector<int32_t> tmp((size_t)numel);
+      HIP_CHECK(hipStreamSynchronize(h->stream));
+      HIP_CHECK(hipMemcpy(tmp.data(), t.p, (size_t)numel * 4, hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < numel; ++i) out[i] = (float)tmp[(size_t)i];
+      return;
+    }
+    if (t.dt == F16X2) RTD_CHECK(t.c % SPLIT_GROUP == 0, RTD_E_INVALID, "debug tensor: split tensor with a partial channel group");
     void* dense = nullptr;
     float* f32 = nullptr;
     HIP_CHECK(hipMalloc(&dense, (size_t)numel * es));
     hipError_t er = hipMalloc((void**)&f32, (size_t)numel * 4);
     if (er == hipSuccess) er = hipMemcpy2DAsync(dense, (size_t)t.c * es, t.p, (size_t)t.ld * es, (size_t)t.c * es, (size_t)t.pixels(), hipMemcpyDeviceToDevice, h->stream);
     if (er == hipSuccess) {
-      if (t.dt == BF16X2) launch_split_to_f32(dense, t.c, f32, t.c, t.pixels(), t.c, h->stream);
+      if (t.dt == F16X2) launch_split_to_f32(dense, t.c, f32, t.c, t.pixels(), t.c, h->stream);
       else launch_to_f32(dense, t.dt, f32, numel, h->stream);
       er = hipMemcpyAsync(out, f32, (size_t)numel * 4, hipMemcpyDeviceToHost, h->stream);
     }
@@ -1626,56 +1649,20 @@ int rtd_debug_option(const char* name, int value) {
   if (strcmp(name, "reset") == 0) {                             // every switch back to its default (tests call this after each case)
     g_opts = PlanOpts();
     g_profile_twice = 0; g_bench_rewarm = 0;
-    conv_reset_options();
-    maxpool_set_v1(0);
-    dec_set_pf(2);
+    conv_opts_template() = ConvOpts();
     return RTD_OK;
   }
-  if (strcmp(name, "conv_v1") == 0) { conv_set_force_v1(value); return RTD_OK; }
-  if (strcmp(name, "dec_stamps") == 0) { g_opts.dec_stamps = value; return RTD_OK; }
-  if (strcmp(name, "dec_fused") == 0) { g_opts.dec_fused = value; return RTD_OK; }
-  if (strcmp(name, "side_stream") == 0) { g_opts.side_stream = value; return RTD_OK; }
-  if (strcmp(name, "sel_fused") == 0) { g_opts.sel_fused = value; return RTD_OK; }
-  if (strcmp(name, "stem_fused") == 0) { g_opts.stem_fused = value; return RTD_OK; }
-  if (strcmp(name, "stem_fused_split") == 0) { g_opts.stem_fused_split = value; return RTD_OK; }
-  if (strcmp(name, "sc_fold") == 0) { g_opts.sc_fold = value; return RTD_OK; }
-  if (strcmp(name, "maxpool_v1") == 0) { maxpool_set_v1(value); return RTD_OK; }
-  if (strcmp(name, "arena_reuse") == 0) { g_opts.arena_reuse = value; return RTD_OK; }
-  if (strcmp(name, "up_fold") == 0) { g_opts.up_fold = value; return RTD_OK; }
-  if (strcmp(name, "attn_split") == 0) { g_opts.attn_split = value; return RTD_OK; }
-  if (strcmp(name, "c1_fuse") == 0) { g_opts.c1_fuse = value; return RTD_OK; }
-  if (strcmp(name, "dec_pf") == 0) { dec_set_pf(value); return RTD_OK; }
-  if (strcmp(name, "dec_split") == 0) { g_opts.dec_split = value; return RTD_OK; }
-  if (strcmp(name, "conv_mode") == 0) { conv_set_mode(value); return RTD_OK; }
-  if (strcmp(name, "prefetch") == 0) { conv_set_prefetch(value); return RTD_OK; }
-  if (strcmp(name, "wsa_min_ntn") == 0) { conv_set_wsa_min_ntn(value); return RTD_OK; }
-  if (strcmp(name, "ws2_min_blocks") == 0) { conv_set_ws2_min_blocks(value); return RTD_OK; }
-  if (strcmp(name, "reg_epilogue") == 0) { conv_set_reg_epilogue(value); return RTD_OK; }
-  if (strcmp(name, "glds_min_n") == 0) { conv_set_glds_min_n(value); return RTD_OK; }
-  if (strcmp(name, "conv_reg") == 0) { conv_set_reg(value); return RTD_OK; }
-  if (strcmp(name, "conv_stream") == 0) { conv_set_stream(value); return RTD_OK; }
-  if (strcmp(name, "stream_min_tiles") == 0) { conv_set_stream_min_tiles(value); return RTD_OK; }
-  if (strcmp(name, "stream_slab") == 0) { conv_set_stream_slab(value); return RTD_OK; }
-  if (strcmp(name, "stream2") == 0) { conv_set_stream2(value); return RTD_OK; }
-  if (strcmp(name, "ws64_max_blocks") == 0) { conv_set_ws64_max_blocks(value); return RTD_OK; }
-  if (strcmp(name, "stream2_max_n") == 0) { conv_set_stream2_max_n(value); return RTD_OK; }
-  if (strcmp(name, "ws256_min_blocks") == 0) { conv_set_ws256_min_blocks(value); return RTD_OK; }
-  if (strcmp(name, "profile_twice") == 0) { g_profile_twice = value; return RTD_OK; }
-  if (strcmp(name, "bench_rewarm") == 0) { g_bench_rewarm = value; return RTD_OK; }
-  if (strcmp(name, "splitk") == 0) { conv_set_splitk(value); return RTD_OK; }
-  if (strcmp(name, "split_ws2_min_blocks") == 0) { conv_set_split_ws2_min_blocks(value); return RTD_OK; }
-  if (strcmp(name, "split_ws64_max_blocks") == 0) { conv_set_split_ws64_max_blocks(value); return RTD_OK; }
-  if (strcmp(name, "split_kernel") == 0) { conv_set_split_kernel(value); return RTD_OK; }
-  if (strcmp(name, "split_flex") == 0) { conv_set_split_flex(value); return RTD_OK; }
-  if (strcmp(name, "split_flex_min_nk") == 0) { conv_set_split_flex_min_nk(value); return RTD_OK; }
-  if (strcmp(name, "split_flex_force") == 0) { conv_set_split_flex_force(value); return RTD_OK; }
-  if (strcmp(name, "split_flex_small_max") == 0) { conv_set_split_flex_small_max(value); return RTD_OK; }
-  if (strcmp(name, "split_persist") == 0) { conv_set_split_persist(value); return RTD_OK; }
-  if (strcmp(name, "split_sx") == 0) { conv_set_split_sx(value); return RTD_OK; }
-  if (strcmp(name, "split_k2") == 0) { conv_set_split_k2(value); return RTD_OK; }
-  if (strcmp(name, "split_persist_min_tiles") == 0) { conv_set_split_persist_min_tiles(value); return RTD_OK; }
-  if (strcmp(name, "glds_drop") == 0) { conv_set_glds_drop(value); return RTD_OK; }
-  if (strcmp(name, "glds_min_blocks") == 0) { conv_set_glds_min_blocks(value); return RTD_OK; }
+  // plan-build and conv-dispatch switches: process-wide TEMPLATES that rtd_create snapshots into the handle - a call here changes handles
+  // created afterwards (and the kernel-level rtd_op_* / rtd_bench_* entry points), never a live handle
+  const struct { const char* n; int* p; } plan_opts[] = {
+      {"dec_stamps", &g_opts.dec_stamps}, {"dec_fused", &g_opts.dec_fused}, {"side_stream", &g_opts.side_stream}, {"sel_fused", &g_opts.sel_fused},
+      {"stem_fused", &g_opts.stem_fused}, {"stem_fused_split", &g_opts.stem_fused_split}, {"sc_fold", &g_opts.sc_fold}, {"arena_reuse", &g_opts.arena_reuse},
+      {"up_fold", &g_opts.up_fold}, {"attn_split", &g_opts.attn_split}, {"c1_fuse", &g_opts.c1_fuse}, {"dec_split", &g_opts.dec_split},
+      {"profile_twice", &g_profile_twice}, {"bench_rewarm", &g_bench_rewarm},
+  };
+  for (const auto& t : plan_opts)
+    if (strcmp(name, t.n) == 0) { *t.p = value; return RTD_OK; }
+  if (conv_set_option(name, value)) return RTD_OK;
   return RTD_E_INVALID;
 }
 
@@ -1685,8 +1672,8 @@ static int op_conv_impl(int dtype, const void* x, const void* x2, int C2, const 
   return op_guard([&] {
     RTD_CHECK(KH == KW, RTD_E_INVALID, "square filters only");
     const int K = KH * KW * Cin + (x2 ? C2 : 0), Npad = conv_npad(Cout);
-    const int Kpad = dtype == BF16X2 ? conv_kpad_split(K) : conv_kpad(K);
-    const int kcols = dtype == BF16X2 ? Kpad / 2 : Kpad;          // fp32 staging row (BF16X2: 2 bf16 per column)
+    const int Kpad = dtype == F16X2 ? conv_kpad_split(K) : conv_kpad(K);
+    const int kcols = dtype == F16X2 ? Kpad / 2 : Kpad;          // fp32 staging row (F16X2: 2 bf16 per column)
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     float* wpad = nullptr; void* wdev = nullptr; float* bpad = nullptr;
     HIP_CHECK(hipMalloc((void**)&wpad, (size_t)Npad * kcols * 4));
@@ -1698,7 +1685,7 @@ static int op_conv_impl(int dtype, const void* x, const void* x2, int C2, const 
     if (dtype == BF16) {
       HIP_CHECK(hipMalloc(&wdev, (size_t)Npad * Kpad * 2));
       launch_f32_to(wpad, wdev, BF16, (int64_t)Npad * Kpad, nullptr);
-    } else if (dtype == BF16X2) {
+    } else if (dtype == F16X2) {
       HIP_CHECK(hipMalloc(&wdev, (size_t)Npad * Kpad * 2));
       launch_f32_to_split(wpad, kcols, wdev, kcols, Npad, kcols, nullptr);
     } else wdev = wpad;
@@ -1712,8 +1699,8 @@ static int op_conv_impl(int dtype, const void* x, const void* x2, int C2, const 
     if (x2) a.x2 = mk(x2, dtype, B, OH, OW, C2);
     float* w1pad = nullptr; void* w1dev = nullptr; float* b1pad = nullptr;
     if (y1) {                                                    // a following 1x1 conv Cout -> Cnext fused into this launch (ConvArgs::next_*)
-      RTD_CHECK(dtype == BF16 || dtype == BF16X2, RTD_E_INVALID, "fused following conv: bf16 / bf16x2 only");
-      const int N1 = conv_npad(Cnext), K1 = dtype == BF16X2 ? conv_kpad_split(Cout) : conv_kpad(Cout), k1cols = dtype == BF16X2 ? K1 / 2 : K1;
+      RTD_CHECK(dtype == BF16 || dtype == F16X2, RTD_E_INVALID, "fused following conv: bf16 / f16x2 only");
+      const int N1 = conv_npad(Cnext), K1 = dtype == F16X2 ? conv_kpad_split(Cout) : conv_kpad(Cout), k1cols = dtype == F16X2 ? K1 / 2 : K1;
       HIP_CHECK(hipMalloc((void**)&w1pad, (size_t)N1 * k1cols * 4));
       HIP_CHECK(hipMemset(w1pad, 0, (size_t)N1 * k1cols * 4));
       HIP_CHECK(hipMemcpy2D(w1pad, (size_t)k1cols * 4, w1_f32, (size_t)Cout * 4, (size_t)Cout * 4, Cnext, hipMemcpyDeviceToDevice));
@@ -1727,15 +1714,12 @@ static int op_conv_impl(int dtype, const void* x, const void* x2, int C2, const 
       RTD_CHECK(conv_next_supported(a), RTD_E_INVALID, "fused following conv: shape not taken by the streaming kernels");
     }
     ConvWorkspace ws;
-    ws.slab_bytes = (size_t)640 * 128 * 128 * 4; ws.cnt_entries = 1024;
-    HIP_CHECK(hipMalloc((void**)&ws.slab, ws.slab_bytes));
-    HIP_CHECK(hipMalloc((void**)&ws.cnt, ws.cnt_entries * 4));
-    HIP_CHECK(hipMemset(ws.cnt, 0, ws.cnt_entries * 4));
+    ws.slab_bytes = conv_split_slab_bytes(a);
+    if (ws.slab_bytes) HIP_CHECK(hipMalloc((void**)&ws.slab, ws.slab_bytes));
     a.ws = ws;
     launch_conv(a, nullptr);
-    launch_conv(a, nullptr);          // a second launch must find the tickets back at zero
     HIP_CHECK(hipDeviceSynchronize());
-    (void)hipFree(ws.slab); (void)hipFree(ws.cnt);
+    if (ws.slab) (void)hipFree(ws.slab);
     HIP_CHECK(hipDeviceSynchronize());
     if (wdev != wpad) (void)hipFree(wdev);
     (void)hipFree(wpad); (void)hipFree(bpad);
@@ -1763,7 +1747,7 @@ int rtd_op_conv_next(int dtype, const void* x, const void* x2, const void* w_f32
 int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int stride, int pad, int with_res, int reps,
                    int flush_mb, float* us_out) {
   return op_guard([&] {
-    const int K = KH * KH * Cin, Kpad = dtype == BF16X2 ? conv_kpad_split(K) : conv_kpad(K), Npad = conv_npad(Cout);
+    const int K = KH * KH * Cin, Kpad = dtype == F16X2 ? conv_kpad_split(K) : conv_kpad(K), Npad = conv_npad(Cout);
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const size_t es = dtype == BF16 ? 2 : 4;
     const size_t xb = (size_t)B * H * W * Cin * es, yb = (size_t)B * OH * OW * Cout * es, wb = (size_t)Npad * Kpad * (dtype == F32 ? 4 : 2);
@@ -1778,7 +1762,7 @@ int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, in
     a.w = w; a.bias = bias; a.KH = KH; a.KW = KH; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.Npad = Npad;
     a.act = 1; a.res_mode = with_res ? RES_PRE : RES_NONE;
     if (with_res) a.res = mk(r, dtype, B, OH, OW, Cout);
-    a.ws.slab_bytes = (size_t)4096 * 8 * 8 > (size_t)64 * 48 * 8 * 8 ? (size_t)4096 * 8 * 8 : (size_t)64 * 48 * 8 * 8;
+    a.ws.slab_bytes = std::max<size_t>((size_t)4096 * 8 * 8, conv_split_slab_bytes(a));   // block stamps (glds_drop 32) / two-pass split-K
     HIP_CHECK(hipMalloc((void**)&a.ws.slab, a.ws.slab_bytes));
     HIP_CHECK(hipMemset(a.ws.slab, 0, a.ws.slab_bytes));
     hipEvent_t e0, e1;

@@ -44,8 +44,8 @@ void launch_to_f32(const void* src, int dt, float* dst, int64_t n, hipStream_t s
   HIP_CHECK(hipGetLastError());
 }
 
-// fp32 rows <-> BF16X2 rows (common.h: groups of 32 channels, [32 hi | 32 lo]); a thread moves 8 channels
-__global__ void k_f32_to_split(const float* __restrict__ src, int64_t lds_, bf16* __restrict__ dst, int64_t ldd, int64_t rows, int C) {
+// fp32 rows <-> F16X2 rows (common.h: groups of 32 channels, [32 hi | 32 lo]); a thread moves 8 channels
+__global__ void k_f32_to_split(const float* __restrict__ src, int64_t lds_, sp16* __restrict__ dst, int64_t ldd, int64_t rows, int C) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int c8 = C / 8;
   if (i >= rows * c8) return;
@@ -55,7 +55,7 @@ __global__ void k_f32_to_split(const float* __restrict__ src, int64_t lds_, bf16
   const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
   split_store8(dst, r * ldd, c, v);
 }
-__global__ void k_split_to_f32(const bf16* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd, int64_t rows, int C) {
+__global__ void k_split_to_f32(const sp16* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd, int64_t rows, int C) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int c8 = C / 8;
   if (i >= rows * c8) return;
@@ -69,13 +69,13 @@ __global__ void k_split_to_f32(const bf16* __restrict__ src, int64_t lds_, float
 void launch_f32_to_split(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows, int C, hipStream_t s) {
   if (rows == 0) return;
   RTD_CHECK(C % SPLIT_GROUP == 0 && lds_ % 4 == 0 && ldd % SPLIT_GROUP == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, 1, "f32 -> split: 32-channel groups, 16-byte rows");
-  hipLaunchKernelGGL(k_f32_to_split, dim3(blocks_for(rows * (C / 8), 256)), dim3(256), 0, s, src, lds_, (bf16*)dst, ldd, rows, C);
+  hipLaunchKernelGGL(k_f32_to_split, dim3(blocks_for(rows * (C / 8), 256)), dim3(256), 0, s, src, lds_, (sp16*)dst, ldd, rows, C);
   HIP_CHECK(hipGetLastError());
 }
 void launch_split_to_f32(const void* src, int64_t lds_, float* dst, int64_t ldd, int64_t rows, int C, hipStream_t s) {
   if (rows == 0) return;
   RTD_CHECK(C % SPLIT_GROUP == 0 && lds_ % SPLIT_GROUP == 0 && ldd % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, 1, "split -> f32: 32-channel groups, 16-byte rows");
-  hipLaunchKernelGGL(k_split_to_f32, dim3(blocks_for(rows * (C / 8), 256)), dim3(256), 0, s, (const bf16*)src, lds_, dst, ldd, rows, C);
+  hipLaunchKernelGGL(k_split_to_f32, dim3(blocks_for(rows * (C / 8), 256)), dim3(256), 0, s, (const sp16*)src, lds_, dst, ldd, rows, C);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -259,9 +259,9 @@ __global__ __launch_bounds__(256) void k_maxpool_bf16_2x2(const bf16* __restrict
     }
 }
 
-// BF16X2: 8 channels (one 16-byte hi chunk + one 16-byte lo chunk) of one output per thread; hi + lo is exact in fp32, so the max
+// F16X2: 8 channels (one 16-byte hi chunk + one 16-byte lo chunk) of one output per thread; hi + lo is exact in fp32, so the max
 // is the max of the represented values and re-splitting it reproduces the winning tap's (hi, lo) pair bit for bit
-__global__ __launch_bounds__(256) void k_maxpool_split(const bf16* __restrict__ x, bf16* __restrict__ y, int B, int H, int W, int C, int64_t ldx,
+__global__ __launch_bounds__(256) void k_maxpool_split(const sp16* __restrict__ x, sp16* __restrict__ y, int B, int H, int W, int C, int64_t ldx,
                                                        int OH, int OW, int64_t ldy) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int c8 = C / 8;
@@ -292,20 +292,18 @@ __global__ __launch_bounds__(256) void k_maxpool_split(const bf16* __restrict__ 
   split_store8(y, (((int64_t)b * OH + oy) * OW + ox) * ldy, cc, m);
 }
 
-static int g_maxpool_v1 = 0;   // A/B + test hook (rtd_debug_option "maxpool_v1"): 1 = the one-output-per-thread kernel for every dtype
-void maxpool_set_v1(int v) { g_maxpool_v1 = v; }
 void launch_maxpool3x3s2(const Tensor& x, const Tensor& y, hipStream_t s) {
   RTD_CHECK(x.dt == y.dt && x.c == y.c && x.c % 4 == 0 && x.n == y.n, 1, "maxpool: dtype/channels");
   RTD_CHECK(y.h == (x.h + 2 - 3) / 2 + 1 && y.w == (x.w + 2 - 3) / 2 + 1, 1, "maxpool: shape");
   RTD_CHECK(x.bstride == (int64_t)x.h * x.w * x.ld && y.bstride == (int64_t)y.h * y.w * y.ld, 1, "maxpool: dense images");
-  if (x.dt == BF16X2) {
+  if (x.dt == F16X2) {
     RTD_CHECK(x.c % SPLIT_GROUP == 0 && x.ld % SPLIT_GROUP == 0 && y.ld % SPLIT_GROUP == 0 && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0, 1, "maxpool: split layout");
     const int64_t total = (int64_t)y.n * y.h * y.w * (y.c / 8);
-    hipLaunchKernelGGL(k_maxpool_split, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const bf16*)x.p, (bf16*)y.p, x.n, x.h, x.w, x.c, x.ld, y.h, y.w, y.ld);
+    hipLaunchKernelGGL(k_maxpool_split, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const sp16*)x.p, (sp16*)y.p, x.n, x.h, x.w, x.c, x.ld, y.h, y.w, y.ld);
     HIP_CHECK(hipGetLastError());
     return;
   }
-  if (!g_maxpool_v1 && x.dt == BF16 && x.c % 8 == 0 && x.ld % 8 == 0 && y.ld % 8 == 0 && y.h % 2 == 0 && y.w % 2 == 0 && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0) {
+  if (x.dt == BF16 && x.c % 8 == 0 && x.ld % 8 == 0 && y.ld % 8 == 0 && y.h % 2 == 0 && y.w % 2 == 0 && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0) {
     const int64_t total2 = (int64_t)y.n * (y.h / 2) * (y.w / 2) * (y.c / 8);
     hipLaunchKernelGGL(k_maxpool_bf16_2x2, dim3(blocks_for(total2, 256)), dim3(256), 0, s, (const bf16*)x.p, (bf16*)y.p, x.n, x.h, x.w, x.c,
                        x.ld, y.h, y.w, y.ld);
@@ -343,7 +341,7 @@ __global__ void k_avgpool2(const T* __restrict__ x, T* __restrict__ y, int B, in
   for (int k = 0; k < V; ++k) o[k] = (T)((((float)a0[k] + (float)a1[k]) + ((float)a2[k] + (float)a3[k])) * 0.25f);
   *(VT*)(y + (((int64_t)b * OH + oy) * OW + ox) * ldy + cc) = o;
 }
-__global__ void k_avgpool2_split(const bf16* __restrict__ x, bf16* __restrict__ y, int B, int H, int W, int C, int64_t ldx, int64_t ldy) {
+__global__ void k_avgpool2_split(const sp16* __restrict__ x, sp16* __restrict__ y, int B, int H, int W, int C, int64_t ldx, int64_t ldy) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int cv = C / 8;
   const int OH = H / 2, OW = W / 2;
@@ -362,12 +360,12 @@ __global__ void k_avgpool2_split(const bf16* __restrict__ x, bf16* __restrict__ 
   split_store8(y, (((int64_t)b * OH + oy) * OW + ox) * ldy, cc, o);
 }
 void launch_avgpool2(const Tensor& x, const Tensor& y, hipStream_t s) {
-  if (x.dt == BF16X2) {
-    RTD_CHECK(y.dt == BF16X2 && x.c == y.c && x.c % SPLIT_GROUP == 0 && x.ld % SPLIT_GROUP == 0 && y.ld % SPLIT_GROUP == 0 && x.n == y.n, 1, "avgpool: split layout");
+  if (x.dt == F16X2) {
+    RTD_CHECK(y.dt == F16X2 && x.c == y.c && x.c % SPLIT_GROUP == 0 && x.ld % SPLIT_GROUP == 0 && y.ld % SPLIT_GROUP == 0 && x.n == y.n, 1, "avgpool: split layout");
     RTD_CHECK(x.h % 2 == 0 && x.w % 2 == 0 && y.h == x.h / 2 && y.w == x.w / 2, 1, "avgpool: even extents only");
     RTD_CHECK(x.bstride == (int64_t)x.h * x.w * x.ld && y.bstride == (int64_t)y.h * y.w * y.ld && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0, 1, "avgpool: dense images");
     const int64_t total = (int64_t)y.n * y.h * y.w * (y.c / 8);
-    hipLaunchKernelGGL(k_avgpool2_split, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const bf16*)x.p, (bf16*)y.p, x.n, x.h, x.w, x.c, x.ld, y.ld);
+    hipLaunchKernelGGL(k_avgpool2_split, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const sp16*)x.p, (sp16*)y.p, x.n, x.h, x.w, x.c, x.ld, y.ld);
     HIP_CHECK(hipGetLastError());
     return;
   }
@@ -1075,22 +1073,26 @@ void launch_resize_pil_u8(const uint8_t* src, int sh, int sw, uint8_t* tmp, uint
 // stem conv reads it back with K = 72 of which 27 taps are real.  Here a block stages the (2*8+1) x (2*32+1) pixel uint8 patch of
 // its 8 x 32 output tile (3.3 KB), every lane gathers the 27 real taps of its output pixel as bytes, converts them exactly like
 // the preprocess kernel ((T)(v / 255.0f)) and feeds two v_mfma_f32_32x32x16_bf16 steps (K = 32).  HBM: 3 bytes per input pixel.
-typedef __bf16 bf16x8_s __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_s __attribute__((ext_vector_type(4)));
+// element type of the kernel's operands and output: bf16 (bf16 engine) or the pair engines' fp16 (common.h sp16)
+template <bool SPLIT> struct StemT { typedef bf16 E; };
+template <> struct StemT<true> { typedef sp16 E; };
 typedef float f32x16_s __attribute__((ext_vector_type(16)));
 typedef float f32x4_s __attribute__((ext_vector_type(4)));
-// SPLIT (bf16x3 engine): the normalised pixel v / 255.0f is kept as a hi / lo bf16 pair (two patches), the filter row `wq` is a BF16X2 row
+// SPLIT (f16x3 engine): the normalised pixel v / 255.0f is kept as a hi / lo fp16 pair (two patches), the filter row `wq` is a pair row
 // (K = 72 real taps x channels in 32-element groups [32 hi | 32 lo]), every MFMA step runs hi*hi + hi*lo + lo*hi and the output rows are
-// BF16X2 pixels ([32 hi | 32 lo], y_bstride / ldy in channels).
+// F16X2 pixels ([32 hi | 32 lo], y_bstride / ldy in channels).
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __restrict__ table, int H, int W, const bf16* __restrict__ wq, int Kpad,
-                                                        const float* __restrict__ bias, bf16* __restrict__ y, long long y_bstride, long long ldy,
+__global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __restrict__ table, int H, int W, const typename StemT<SPLIT>::E* __restrict__ wq, int Kpad,
+                                                        const float* __restrict__ bias, typename StemT<SPLIT>::E* __restrict__ y, long long y_bstride, long long ldy,
                                                         int OH, int OW, int tiles_x, int tiles_y, int act) {
+  typedef typename StemT<SPLIT>::E E;
+  typedef E Ex8 __attribute__((ext_vector_type(8)));
+  typedef E Ex4 __attribute__((ext_vector_type(4)));
   constexpr int TH = 8, TW = 32, PR = 2 * TH + 1, PC = 2 * TW + 1, ROWE = 200;        // 65 px * 3 = 195 elements per patch row -> 200
   constexpr int NDW = (PC * 3 + 3 + 3) / 4;                                            // aligned dwords that cover one patch row
   constexpr int ROWO = (SPLIT ? 128 : 64) + 16;                                        // store slab row: 32 channels + skew
-  __shared__ __attribute__((aligned(16))) bf16 patch[PR * ROWE];                        // already normalised: (bf16)(v / 255.0f)
-  __shared__ __attribute__((aligned(16))) bf16 patch_lo[SPLIT ? PR * ROWE : 8];         // SPLIT: bf16(v / 255.0f - hi)
+  __shared__ __attribute__((aligned(16))) E patch[PR * ROWE];                        // already normalised: (E)(v / 255.0f)
+  __shared__ __attribute__((aligned(16))) E patch_lo[SPLIT ? PR * ROWE : 8];         // SPLIT: E(v / 255.0f - hi)
   __shared__ __attribute__((aligned(16))) char stage[4][32 * ROWO];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5;
   int t = blockIdx.x;
@@ -1125,22 +1127,22 @@ __global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __r
       const int ix = 2 * x0 - 1 + el / 3;
       const float v = (row_ok && (unsigned)ix < (unsigned)W) ? (float)((dw >> (8 * q)) & 0xffu) : 0.f;
       const float vn = v / 255.0f;
-      const bf16 hi = (bf16)vn;
+      const E hi = (E)vn;
       patch[r * ROWE + el] = hi;
-      if (SPLIT) patch_lo[r * ROWE + el] = (bf16)(vn - (float)hi);
+      if (SPLIT) patch_lo[r * ROWE + el] = (E)(vn - (float)hi);
     }
   }
   for (int e = tid; e < PR * (ROWE - PC * 3); e += 256) {                               // row tails: read (times a zero filter tap) by the last pixels
     const int r = e / (ROWE - PC * 3), i = e - r * (ROWE - PC * 3);
-    patch[r * ROWE + PC * 3 + i] = (bf16)0.f;
-    if (SPLIT) patch_lo[r * ROWE + PC * 3 + i] = (bf16)0.f;
+    patch[r * ROWE + PC * 3 + i] = (E)0.f;
+    if (SPLIT) patch_lo[r * ROWE + PC * 3 + i] = (E)0.f;
   }
   // K layout chosen for the GATHER, not for the filter: k = 10 kh + e, e = 3 kw + (BGR byte) for e < 9, e = 9 and k = 30, 31 carry
   // zero filter taps.  A filter row of the patch is then 10 consecutive elements starting at an even offset, so the 8 k values of
   // a lane (k = 16 s + 8 (lane >> 5) + j) are at most two runs of whole dwords: 4 ds_read_b32 per MFMA operand instead of 8
   // ds_read_u16 (measured: no change, 44.8 us either way - the launch is bound by the per-block patch staging, not the gather).
   // Pixel p starts at element 6 p: consecutive lanes are 3 banks apart.
-  bf16x8_s wf[2], wfl[2];
+  Ex8 wf[2], wfl[2];
   int doff[2][4];                     // dword j of the operand: element offset relative to the pixel's (2 r, 2 p) corner
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -1152,11 +1154,11 @@ __global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __r
       const int kr = (kh * 3 + kw) * 8 + (2 - cb);                                      // the filter's own K index (tap-major, 8 padded channels)
       const bool real = k < 30 && e < 9;
       if (SPLIT) {
-        const size_t pos = (size_t)(lane & 31) * Kpad + ((kr >> 5) << 6) + (kr & 31);   // BF16X2 row: group kr / 32, hi half
-        wf[s][j] = real ? wq[pos] : (bf16)0.f;
-        wfl[s][j] = real ? wq[pos + 32] : (bf16)0.f;
+        const size_t pos = (size_t)(lane & 31) * Kpad + ((kr >> 5) << 6) + (kr & 31);   // F16X2 row: group kr / 32, hi half
+        wf[s][j] = real ? wq[pos] : (E)0.f;
+        wfl[s][j] = real ? wq[pos + 32] : (E)0.f;
       } else {
-        wf[s][j] = real ? wq[(size_t)(lane & 31) * Kpad + kr] : (bf16)0.f;              // zero taps: the pixel operand may be anything finite
+        wf[s][j] = real ? wq[(size_t)(lane & 31) * Kpad + kr] : (E)0.f;              // zero taps: the pixel operand may be anything finite
       }
     }
 #pragma unroll
@@ -1171,7 +1173,7 @@ __global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __r
   for (int rr = 0; rr < 2; ++rr) {
     const int r = wv * 2 + rr;
     const int eoff = (2 * r) * ROWE + (2 * (lane & 31)) * 3;
-    const bf16* base = patch + eoff;
+    const E* base = patch + eoff;
     f32x16_s acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -1182,14 +1184,15 @@ __global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __r
 #pragma unroll
       for (int j = 0; j < 4; ++j) xd[j] = *(const unsigned*)(base + doff[s][j]);
       const u4_s xv = {xd[0], xd[1], xd[2], xd[3]};
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], __builtin_bit_cast(bf16x8_s, xv), acc, 0, 0, 0);
-      if (SPLIT) {
+      if constexpr (SPLIT) acc = mfma_pair32(wf[s], __builtin_bit_cast(Ex8, xv), acc);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], __builtin_bit_cast(Ex8, xv), acc, 0, 0, 0);
+      if constexpr (SPLIT) {
         unsigned xl[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) xl[j] = *(const unsigned*)(patch_lo + eoff + doff[s][j]);
         const u4_s xlv = {xl[0], xl[1], xl[2], xl[3]};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], __builtin_bit_cast(bf16x8_s, xlv), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfl[s], __builtin_bit_cast(bf16x8_s, xv), acc, 0, 0, 0);
+        acc = mfma_pair32(wf[s], __builtin_bit_cast(Ex8, xlv), acc);
+        acc = mfma_pair32(wfl[s], __builtin_bit_cast(Ex8, xv), acc);
       }
     }
     const int oy = y0 + r;
@@ -1197,27 +1200,27 @@ __global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __r
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4_s bv = *(const f32x4_s*)(bias + 8 * q + 4 * h);
-      bf16x4_s o, ol;
+      Ex4 o, ol;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float v = acc[4 * q + e] + bv[e];
         if (act == ACT_RELU) v = fmaxf(v, 0.f);
         else if (act == ACT_SILU) v = v / (1.f + __expf(-v));
-        o[e] = (bf16)v;
-        if (SPLIT) ol[e] = (bf16)(v - (float)o[e]);
+        if constexpr (SPLIT) { sp16 hh, ll; split2(v, hh, ll); o[e] = hh; ol[e] = ll; }
+        else o[e] = (E)v;
       }
-      *(bf16x4_s*)(sw_ + (lane & 31) * ROWO + (8 * q + 4 * h) * 2) = o;
-      if (SPLIT) *(bf16x4_s*)(sw_ + (lane & 31) * ROWO + 64 + (8 * q + 4 * h) * 2) = ol;
+      *(Ex4*)(sw_ + (lane & 31) * ROWO + (8 * q + 4 * h) * 2) = o;
+      if (SPLIT) *(Ex4*)(sw_ + (lane & 31) * ROWO + 64 + (8 * q + 4 * h) * 2) = ol;
     }
     __builtin_amdgcn_wave_barrier();
     if (oy < OH) {
       constexpr int CPP = SPLIT ? 8 : 4;                                               // 16-byte chunks per output pixel
-      bf16* yrow = y + (SPLIT ? 2 : 1) * ((long long)b * y_bstride + ((long long)oy * OW + x0) * ldy);
+      E* yrow = y + (SPLIT ? 2 : 1) * ((long long)b * y_bstride + ((long long)oy * OW + x0) * ldy);
 #pragma unroll
       for (int i2 = 0; i2 < CPP / 2; ++i2) {
         const int idx = i2 * 64 + lane;
         const int p = idx / CPP, ch = idx % CPP;
-        if (x0 + p < OW) *(bf16x8_s*)(yrow + (SPLIT ? 2 : 1) * (long long)p * ldy + ch * 8) = *(const bf16x8_s*)(sw_ + p * ROWO + ch * 16);
+        if (x0 + p < OW) *(Ex8*)(yrow + (SPLIT ? 2 : 1) * (long long)p * ldy + ch * 8) = *(const Ex8*)(sw_ + p * ROWO + ch * 16);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1226,11 +1229,11 @@ __global__ __launch_bounds__(256) void stem0_u8_kernel(const uint8_t* const* __r
 void launch_stem0_u8(const uint8_t* const* table_dev, int n, int H, int W, const void* w, int Kpad, const float* bias, const Tensor& y, int act,
                      hipStream_t s) {
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  RTD_CHECK((y.dt == BF16 || y.dt == BF16X2) && y.c == 32 && y.h == OH && y.w == OW && y.n >= n && y.ld % (y.dt == BF16X2 ? SPLIT_GROUP : 8) == 0 &&
-                (act == ACT_RELU || act == ACT_NONE || act == ACT_SILU), 1, "stem0_u8: output must be bf16 / BF16X2 [n, H/2, W/2, 32]");
+  RTD_CHECK((y.dt == BF16 || y.dt == F16X2) && y.c == 32 && y.h == OH && y.w == OW && y.n >= n && y.ld % (y.dt == F16X2 ? SPLIT_GROUP : 8) == 0 &&
+                (act == ACT_RELU || act == ACT_NONE || act == ACT_SILU), 1, "stem0_u8: output must be bf16 / F16X2 [n, H/2, W/2, 32]");
   const int tiles_x = (OW + 31) / 32, tiles_y = (OH + 7) / 8;
-  if (y.dt == BF16X2)
-    hipLaunchKernelGGL(stem0_u8_kernel<true>, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, table_dev, H, W, (const bf16*)w, Kpad, bias, (bf16*)y.p,
+  if (y.dt == F16X2)
+    hipLaunchKernelGGL(stem0_u8_kernel<true>, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, table_dev, H, W, (const sp16*)w, Kpad, bias, (sp16*)y.p,
                        (long long)y.bstride, (long long)y.ld, OH, OW, tiles_x, tiles_y, act);
   else
     hipLaunchKernelGGL(stem0_u8_kernel<false>, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, table_dev, H, W, (const bf16*)w, Kpad, bias, (bf16*)y.p,

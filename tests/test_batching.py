@@ -275,7 +275,7 @@ def test_four_camera_threads_through_the_real_detector():
 def test_pipelined_coordinator_on_two_real_detectors_matches_detect():
     from telescope_cam_detection_amd.rtdetr_detector import RTDETRDetector
     from tests.util import load_case
-    arch, wseed, input_size, frames, g = load_case("t_tinyc_160x224")     # default engine (bf16x3): widths in whole 32-channel groups
+    arch, wseed, input_size, frames, g = load_case("t_tinyc_160x224")     # default engine (f16x3): widths in whole 32-channel groups
     cfg = {"detection": {"detector_type": "rtdetr", "device": "cuda:0", "conf_threshold": 0.2, "input_size": list(input_size),
                          "wildlife_only": False, "rtdetr": {"config_path": "tinyc", "weights": f"synthetic:tinyc:{wseed}"},
                          "batching": {"enabled": True, "max_batch_size": 2, "max_batch_wait_ms": 2.0, "pipeline_depth": 2}}}

@@ -246,13 +246,12 @@ def test_conv(L, dt, case):
     bd = b.cuda()
     rd = nhwc(res, tdt) if res is not None else None
     from telescope_cam_detection_amd import _capi
-    _capi.debug_option("splitk", 2)        # exercise the in-launch split-K reduction on every small-grid shape (default: tiny grids only)
-    # conv_mode 0 = auto (LDS-DMA kernel where eligible), 2 = register-staged large tile, 1 = small tiles only,
-    # 3 / 4 = wave-specialised LDS-DMA kernel (4 / 2 stages), 5 = single-role LDS-DMA kernel, 6 = wave-specialised with
-    # whole-K-step fragment prefetch, 7 = wave-specialised 256-pixel tile, 8 = A-stationary kernel wherever it is eligible (1x1, K <= 256, no residual),
+    # conv_mode 0 = auto (LDS-DMA kernel where eligible), 1 = the register-staged fallback kernel only,
+    # 3 / 4 = wave-specialised LDS-DMA kernel (4 / 2 stages), 7 = wave-specialised 256-pixel tile,
+    # 8 = A-stationary kernel wherever it is eligible (1x1, K <= 256, no residual),
     # 9 = streaming 1x1 kernel wherever it is eligible (K = 64 / 128, Cout % 64 == 0), whatever the grid size
     # 10 = the 128 x 64 tile of the wave-specialised kernel (auto below 160 tiles) on every shape the LDS-DMA kernels take
-    for out_f32, mode in (((1, 0), (1, 1), (1, 2), (1, 3), (1, 6), (1, 7), (1, 10)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (1, 6), (0, 7), (1, 7), (0, 8), (0, 9), (0, 109), (0, 10), (1, 10))):
+    for out_f32, mode in (((1, 0), (1, 1), (1, 3), (1, 7), (1, 10)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 3), (0, 4), (0, 7), (1, 7), (0, 8), (0, 9), (0, 109), (0, 10), (1, 10))):
         _capi.debug_option("stream_slab", 0 if mode >= 100 else 1)      # 109 = mode 9 with accumulator-shaped global accesses
         mode %= 100
         _capi.debug_option("conv_mode", mode)
@@ -271,14 +270,13 @@ def test_conv(L, dt, case):
         torch.testing.assert_close(got, y, **tol)
     _capi.debug_option("conv_mode", 0)
     _capi.debug_option("stream_slab", 1)
-    _capi.debug_option("splitk", 0)
 
 
 SPLIT_CONV_CASES = [
-    # B, H, W, Cin, Cout, k, stride, pad, act, res_mode, out_f32   (Cin % 32 == 0; BF16X2 output: Cout % 32 == 0)
+    # B, H, W, Cin, Cout, k, stride, pad, act, res_mode, out_f32   (Cin % 32 == 0; F16X2 output: Cout % 32 == 0)
     (2, 20, 20, 64, 64, 1, 1, 0, "relu", 0, 0),         # 128 x 64 tile
     (1, 33, 29, 32, 96, 3, 1, 1, "silu", 0, 0),         # one channel group per tap, ragged M, Cout not a tile multiple
-    (2, 40, 40, 64, 128, 3, 2, 1, "relu", 1, 0),        # stride 2, pre-activation BF16X2 residual
+    (2, 40, 40, 64, 128, 3, 2, 1, "relu", 1, 0),        # stride 2, pre-activation F16X2 residual
     (1, 16, 16, 128, 256, 1, 1, 0, "none", 2, 0),       # post-activation residual
     (4, 60, 264, 32, 32, 3, 1, 1, "relu", 0, 0),        # stem.1: the direct (filter-in-registers) split kernel, ragged tiles both ways
     (4, 68, 232, 32, 64, 3, 1, 1, "silu", 0, 0),        # stem.2: two channel groups per block
@@ -288,9 +286,9 @@ SPLIT_CONV_CASES = [
     (2, 160, 160, 64, 256, 1, 1, 0, "relu", 1, 0),      # stage-0 c3
     (1, 8400, 1, 256, 1536, 1, 1, 0, "none", 0, 1),     # value projection: fp32 output
     (1, 400, 1, 2048, 256, 1, 1, 0, "none", 0, 1),      # enc.proj.2: long K, fp32 output, 4-stage kernel
-    (2, 20, 20, 512, 512, 3, 1, 1, "relu", 0, 0),       # stage-3 c2: K = 4608 real channels x taps (two-pass split-K, 2 slices, BF16X2 out)
+    (2, 20, 20, 512, 512, 3, 1, 1, "relu", 0, 0),       # stage-3 c2: K = 4608 real channels x taps (two-pass split-K, 2 slices, F16X2 out)
     (1, 70, 50, 256, 64, 1, 1, 0, "gelu", 0, 0),
-    (2, 40, 41, 256, 1024, 1, 1, 0, "relu", 1, 1),      # fp32 output with a BF16X2 residual
+    (2, 40, 41, 256, 1024, 1, 1, 0, "relu", 1, 1),      # fp32 output with a F16X2 residual
     (8, 40, 40, 256, 256, 3, 1, 1, "silu", 2, 0),       # 40^2 x 8 maps: flexible tile height (112 px -> 230 blocks), post residual
     (8, 80, 80, 64, 256, 3, 1, 1, "relu", 0, 0),        # 80^2 x 8 maps: 208-pixel tiles, 3 stages, one block per CU
     (8, 20, 20, 256, 512, 3, 1, 1, "relu", 1, 0),       # 20^2 x 8 maps: 64-pixel tiles
@@ -298,7 +296,7 @@ SPLIT_CONV_CASES = [
     (1, 81, 80, 64, 256, 1, 1, 0, "silu", 2, 0),        # streaming split kernel (>= 6400 pixels per image): ragged last 32-pixel tile, post residual
     (2, 80, 80, 128, 512, 1, 1, 0, "relu", 1, 0),       # stage-1 c3: K = 128, two 256-channel blocks in gridDim.y
     (1, 100, 70, 64, 512, 1, 1, 0, "none", 0, 0),       # no residual, linear
-    (1, 80, 80, 256, 1024, 1, 1, 0, "none", 0, 0),      # streaming kernel with K = 256 (one pixel-tile buffer), four channel blocks, BF16X2 out
+    (1, 80, 80, 256, 1024, 1, 1, 0, "none", 0, 0),      # streaming kernel with K = 256 (one pixel-tile buffer), four channel blocks, F16X2 out
     (1, 90, 75, 256, 1280, 1, 1, 0, "silu", 0, 1),      # ... fp32 rows out, ragged last tile
     (1, 20, 20, 512, 256, 3, 1, 1, "silu", 1, 1),       # 144 K-steps on 8 tiles per image: two-pass split-K in 4 slices, residual + fp32 rows in the reduce pass
     (2, 160, 160, 64, 64, 3, 1, 1, "relu", 0, 0),       # stage-0 c2: the direct 64-channel kernel (>= 128 8 x 16 tiles per image)
@@ -307,8 +305,8 @@ SPLIT_CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", SPLIT_CONV_CASES)
-def test_conv_split_bf16x3(L, case):
-    """BF16X2 operands (hi/lo bf16 pairs, 32-channel groups), three MFMAs per product: against fp64 on the values the kernel sees
+def test_conv_split_f16x3(L, case):
+    """F16X2 operands (hi/lo fp16 pairs, 32-channel groups), three MFMAs per product: against fp64 on the values the kernel sees
     (inputs rounded to hi + lo).  Error budget: the dropped lo*lo term (2^-18 per product) + fp32 accumulation + one hi/lo rounding
     of the output (2^-18) -> 2e-5 relative, 250x tighter than the bf16 kernels' tolerance."""
     from telescope_cam_detection_amd import _capi
@@ -338,30 +336,20 @@ def test_conv_split_bf16x3(L, case):
         yd = torch.full((B, OH, OW, Cout), float("nan"), dtype=torch.float32, device="cuda")
     else:
         yd = torch.full((B, OH, OW, 2 * Cout), -1, dtype=torch.int16, device="cuda")
-    # tile dispatch: auto | 2-stage 128-wide tiles everywhere | 4-stage, 64-wide tiles everywhere; kernel: the default, and the dedicated split
-    # kernel on either MFMA shape (rtd_debug_option "split_kernel" 1 = 32x32x16, 2 = 16x16x32)
-    # kern -1: the default dispatch; -2: flexible-height tiles (conv_igemm_wsf_kernel) on EVERY K length; -3: the persistent three-role kernel
-    # (conv_igemm_wsp_kernel) wherever it is eligible (N >= 128, >= 2 K-steps), whatever the grid size; -4: both at their own thresholds
-    for ws2, ws64, kern in ((257, 160, -1), (257, 160, -3), (257, 160, -2), (257, 160, -4), (1, 0, 2), (1 << 30, 1 << 30, 2), (257, 160, 0), (257, 160, 1), (1, 0, 1), (1 << 30, 1 << 30, 0)):
+    # dispatch variants: "auto" = the default; "flex" = flexible-height tiles (conv_igemm_wsf_kernel) on every grid and K length;
+    # "tiled" = only the fixed-tile kernel (no streaming / direct 3x3 / flexible kernels) with 2-stage 128-wide or 4-stage 64-wide tiles everywhere
+    for ws2, ws64, kern in ((257, 160, "auto"), (257, 160, "flex"), (1, 0, "tiled"), (1 << 30, 1 << 30, "tiled")):
         _capi.debug_option("reset", 0)
         _capi.debug_option("split_ws2_min_blocks", ws2)
         _capi.debug_option("split_ws64_max_blocks", ws64)
-        if kern >= 0:
-            _capi.debug_option("split_kernel", kern)
+        if kern == "tiled":
             _capi.debug_option("split_flex", 0)
-            _capi.debug_option("split_persist", 0)
-            _capi.debug_option("split_sx", 0)        # the tiled kernels on the streaming kernel's shapes too
-            _capi.debug_option("conv_reg", 1)        # ... and on the direct 64-channel 3x3 kernel's
-        if kern == -2:
-            _capi.debug_option("split_flex", 1)
+            _capi.debug_option("split_sx", 0)        # the tiled kernel on the streaming kernel's shapes too
+            _capi.debug_option("conv_reg", 0)        # ... and on the direct 3x3 kernels'
+        if kern == "flex":
+            _capi.debug_option("split_flex_small_max", 1 << 30)
             _capi.debug_option("split_flex_min_nk", 1)
-        if kern == -3:
-            _capi.debug_option("split_persist", 2)
-            _capi.debug_option("split_persist_min_tiles", 1)
-        if kern == -4:
-            _capi.debug_option("split_flex", 1)
-            _capi.debug_option("split_persist", 1)
-        ck(L, L.rtd_op_conv(_capi.DT_BF16X2, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None,
+        ck(L, L.rtd_op_conv(_capi.DT_F16X2, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None,
                             yd.data_ptr(), B, H, W, Cin, Cout, k, k, stride, pad, {"none": 0, "relu": 1, "silu": 2, "gelu": 3}[act],
                             res_mode, out_f32))
         got = yd.cpu().numpy() if out_f32 else _capi.from_split(yd.cpu().numpy().view(np.uint16))
@@ -412,7 +400,7 @@ def test_conv_split_streaming_with_fused_next(L, case):
     yd = torch.full((B, H, W, 2 * Cout), -1, dtype=torch.int16, device="cuda")
     y1d = torch.full((B, H, W, 2 * Cnext), -1, dtype=torch.int16, device="cuda")
     A = {"none": 0, "relu": 1, "silu": 2}
-    ck(L, L.rtd_op_conv_next(_capi.DT_BF16X2, xd.data_ptr(), x2d.data_ptr() if x2d is not None else None, wd.data_ptr(), bd.data_ptr(),
+    ck(L, L.rtd_op_conv_next(_capi.DT_F16X2, xd.data_ptr(), x2d.data_ptr() if x2d is not None else None, wd.data_ptr(), bd.data_ptr(),
                              rd.data_ptr() if rd is not None else None, yd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), y1d.data_ptr(),
                              B, H, W, Cin, C2, Cout, Cnext, A[act], res_mode, A[next_act]))
     got = torch.from_numpy(_capi.from_split(yd.cpu().numpy().view(np.uint16))).double()
@@ -427,21 +415,21 @@ def test_conv_split_streaming_with_fused_next(L, case):
     # the same conv without the follower gives the same y bits (kernel choice is per-image; the follower only reads the tile)
     yd2 = torch.full((B, H, W, 2 * Cout), -1, dtype=torch.int16, device="cuda")
     if x2d is None:
-        ck(L, L.rtd_op_conv(_capi.DT_BF16X2, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None, yd2.data_ptr(),
+        ck(L, L.rtd_op_conv(_capi.DT_F16X2, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None, yd2.data_ptr(),
                             B, H, W, Cin, Cout, 1, 1, 1, 0, A[act], res_mode, 0))
     else:
-        ck(L, L.rtd_op_conv_dual(_capi.DT_BF16X2, xd.data_ptr(), x2d.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, yd2.data_ptr(),
+        ck(L, L.rtd_op_conv_dual(_capi.DT_F16X2, xd.data_ptr(), x2d.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, yd2.data_ptr(),
                                  B, H, W, Cin, C2, Cout, 1, 1, 0, A[act], 0, 0, 0))
     assert torch.equal(yd, yd2)
     # and the separate follower launch (tiled split kernel) agrees with the fused one to rounding
     y1d2 = torch.full((B, H, W, 2 * Cnext), -1, dtype=torch.int16, device="cuda")
-    ck(L, L.rtd_op_conv(_capi.DT_BF16X2, yd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), None, y1d2.data_ptr(), B, H, W, Cout, Cnext, 1, 1, 1, 0, A[next_act], 0, 0))
+    ck(L, L.rtd_op_conv(_capi.DT_F16X2, yd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), None, y1d2.data_ptr(), B, H, W, Cout, Cnext, 1, 1, 1, 0, A[next_act], 0, 0))
     sep = torch.from_numpy(_capi.from_split(y1d2.cpu().numpy().view(np.uint16))).double()
     assert (sep - got1).abs().max().item() / y1.abs().max().item() < 2e-5
     # split_sx 0: the tiled kernels take the expand conv; a fused follower is then refused, not silently dropped
     _capi.debug_option("split_sx", 0)
     try:
-        rc = L.rtd_op_conv_next(_capi.DT_BF16X2, xd.data_ptr(), x2d.data_ptr() if x2d is not None else None, wd.data_ptr(), bd.data_ptr(),
+        rc = L.rtd_op_conv_next(_capi.DT_F16X2, xd.data_ptr(), x2d.data_ptr() if x2d is not None else None, wd.data_ptr(), bd.data_ptr(),
                                 rd.data_ptr() if rd is not None else None, yd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), y1d.data_ptr(),
                                 B, H, W, Cin, C2, Cout, Cnext, A[act], res_mode, A[next_act])
         assert rc != 0

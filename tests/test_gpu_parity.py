@@ -100,38 +100,36 @@ def test_fp32_engine_full_size_configs_against_hf_fixtures(name):
     eng.close()
 
 
-def x3_check(name, arch, eng, frames, ref_topk, ref_scores_all, refs, score_tol, cut_tol=5e-5, max_off=0, outer_box_tol=None):
-    """bf16x3 at the north-star tolerance (1e-3 on scores, 1e-2 px on boxes) with no slack on rows.  The model has two top-k cuts, and a
-    near-tie AT a cut may fall either way under any rounding pattern (the oracle's and HF's disagree there too), so the rule is:
+def x3_check(name, arch, w, input_size, eng, frames, ref_topk, ref_scores_all, refs, score_tol, cut_tol=5e-5):
+    """f16x3 at the north-star tolerance (1e-3 on scores, 1e-2 px on boxes) with no slack on rows, at every input size.  The model has two
+    top-k cuts, and a near-tie AT a cut may fall either way under any rounding pattern (the oracle's and HF's disagree there too), so:
       * encoder query selection: where the engine's selected token set differs from the reference's, every exchanged token must be within
-        2 x the measured score tolerance of the reference's rank-Q score;
+        2 x the measured score tolerance of the reference's rank-Q score - and the frame is then compared, ALL rows at the full
+        tolerance, with the oracle run on the engine's own selection (one exchanged query moves every row through the decoder's
+        self-attention, so the reference's rows are not the yardstick for that frame; the oracle under the same selection is);
       * post-processor top-Q over the Q x C (query, class) scores: a reference row without a partner must sit within `cut_tol` (3 x the
         worst measured score error) of the reference's LOWEST kept score, i.e. at the cut;
       * everything else must match - free-running on frames whose token sets agree, and on every frame with the selection forced to the
         reference's.
-    refs: list of (tag, labels, boxes, scores) per reference; ref_topk [B,Q]; ref_scores_all [B,S] = the reference's enc_cls_max.
-    max_off / outer_box_tol (1280-pixel frames only): at most max_off rows per frame may exceed 1e-2 px, none may exceed outer_box_tol."""
+    refs: list of (tag, labels, boxes, scores) per reference; ref_topk [B,Q]; ref_scores_all [B,S] = the reference's enc_cls_max."""
     Q = arch.num_queries
 
-    def rows(tag_phase, b, same_tokens, labels, boxes, scores):
-        for tag, rl, rb, rs in refs:
+    def rows(tag_phase, b, use_refs, labels, boxes, scores):
+        for tag, rl, rb, rs in use_refs:
             m, n, ws, wb, un = match_detections(rl[b], rb[b], rs[b], labels[b], boxes[b], scores[b], 1e-3, 1e-2, return_unmatched=True)
             cut = float(np.min(rs[b]))
             off_cut = [i for i in un if float(rs[b][i]) - cut > cut_tol]
-            print(f"{name}[{b}] bf16x3 {tag_phase} vs {tag}: matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px; "
+            print(f"{name}[{b}] f16x3 {tag_phase} vs {tag}: matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px; "
                   f"unmatched at the top-{Q} cut: {len(un) - len(off_cut)}, elsewhere: {len(off_cut)}")
-            if same_tokens:
-                assert len(off_cut) <= max_off and len(un) <= 6, (tag, b, m, n, [float(rs[b][i]) - cut for i in un])
-                if off_cut:
-                    m2, _, _, wb2, un2 = match_detections(rl[b], rb[b], rs[b], labels[b], boxes[b], scores[b], 1e-3, outer_box_tol, return_unmatched=True)
-                    print(f"{name}[{b}]   at {outer_box_tol} px: matched {m2}/{n}, worst dbox={wb2:.2e}px")
-                    assert not [i for i in un2 if float(rs[b][i]) - cut > cut_tol], (tag, b, m2, n, wb2)
+            assert not off_cut and len(un) <= 6, (tag, b, m, n, [float(rs[b][i]) - cut for i in un])
 
     labels, boxes, scores = eng.infer_raw(frames)
     mx = eng.debug_tensor("enc_cls_max")[:, :, 0, 0]
+    tk = eng.debug_tensor("topk")[:, :, 0, 0].astype(np.int64)                 # the tokens the decoder ran on
     flips = []
     for b in range(len(frames)):
-        mine = set(np.argsort(-mx[b], kind="stable")[:Q].tolist())
+        mine = set(tk[b].tolist())
+        assert len(mine) == Q
         ref = set(np.asarray(ref_topk[b]).tolist())
         diff = mine ^ ref
         kth = np.sort(ref_scores_all[b])[-Q]
@@ -141,27 +139,35 @@ def x3_check(name, arch, eng, frames, ref_topk, ref_scores_all, refs, score_tol,
             worst = max(abs(float(ref_scores_all[b][t]) - float(kth)) for t in diff)
             print(f"{name}[{b}] selection differs in {len(diff) // 2} token(s); farthest from the rank-{Q} score: {worst:.2e}")
             assert worst <= 2 * score_tol, (b, worst)
-        rows("free-running", b, not diff, labels, boxes, scores)
+            # the oracle on THIS selection (frame b alone: frames are independent units)
+            torch.set_num_threads(min(16, len(__import__('os').sched_getaffinity(0))))
+            xb, sz = orc.preprocess(frames[b], input_size)
+            with torch.no_grad():
+                l2, b2, s2 = orc.model_forward(arch, w, xb, [sz], force_topk=tk[b:b + 1])
+            own = [("oracle on the engine's selection", {b: l2[0].numpy()}, {b: b2[0].numpy()}, {b: s2[0].numpy()})]
+            rows("free-running", b, own, labels, boxes, scores)
+        else:
+            rows("free-running", b, refs, labels, boxes, scores)
         assert (np.diff(scores[b]) <= 0).all(), "scores must be descending"
     assert sum(flips) <= max(2, len(frames) // 2), flips           # measured: 0-1 per frame on the noise frames, none on the scenes
     eng.force_topk(np.asarray(ref_topk))
     labels, boxes, scores = eng.infer_raw(frames)
     eng.force_topk(None)
     for b in range(len(frames)):
-        rows("reference selection", b, True, labels, boxes, scores)
+        rows("reference selection", b, refs, labels, boxes, scores)
 
 
 X3_CASES = ["t_tinyc_160x224", "c1_r18_640_bs1", "c1_r18_640_scene", "c1_r18_640_resize", "c2_r50_640_scene_bs2"]
 
 
 @pytest.mark.parametrize("name", X3_CASES)
-def test_bf16x3_engine_matches_oracle_and_golden(name):
-    """The default engine (precision bf16x3: hi/lo bf16 pairs, three MFMAs per product) is held to the north-star tolerance with
+def test_f16x3_engine_matches_oracle_and_golden(name):
+    """The default engine (precision f16x3: hi/lo fp16 pairs, three MFMAs per product) is held to the north-star tolerance with
     its own free-running query selection: 1e-3 on scores, 1e-2 px on boxes, against the oracle AND the HF fixtures."""
     arch, wseed, input_size, frames, g = load_case(name)
     w = weights_for(arch, wseed)
     (ol, ob, osc), col = oracle_run(arch, w, frames, input_size)
-    eng = make_engine(arch, w, frames, input_size, "bf16x3")
+    eng = make_engine(arch, w, frames, input_size, "f16x3")
     labels, boxes, scores = eng.infer_raw(frames)
     x = nchw(eng.debug_tensor("input"))[:, :3]
     np.testing.assert_array_equal(x, col["input"].numpy())                 # the split engine keeps fp32 pixels: bit-exact preprocessing
@@ -177,27 +183,25 @@ def test_bf16x3_engine_matches_oracle_and_golden(name):
     print(f"{name} enc score max abs err {np.abs(mx - col['enc_cls_max'].numpy()).max():.2e}")
     np.testing.assert_allclose(mx, col["enc_cls_max"].numpy(), atol=5e-4)
     refs = [("oracle", [t.numpy() for t in ol], [t.numpy() for t in ob], [t.numpy() for t in osc]), ("hf", g["labels"], g["boxes"], g["scores"])]
-    x3_check(name, arch, eng, frames, col["topk"].numpy(), col["enc_cls_max"].numpy(), refs, 5e-4)
+    x3_check(name, arch, w, input_size, eng, frames, col["topk"].numpy(), col["enc_cls_max"].numpy(), refs, 5e-4)
     eng.close()
 
 
 @pytest.mark.parametrize("name", ["c2_r50_640_bs8", "c3_r101_1280_bs1", "c3_r101_1280_bs4"])
-def test_bf16x3_engine_full_size_configs_against_hf_fixtures(name):
+def test_f16x3_engine_full_size_configs_against_hf_fixtures(name):
     """BASELINE configs 2 (R50 640 bs8 = the benchmark frames) and 3 (R101 1280) on the default engine, hipGraph, against the
     committed HF outputs at the north-star tolerance."""
     arch, wseed, input_size, frames, g = load_case(name)
     w = weights_for(arch, wseed)
-    eng = make_engine(arch, w, frames, input_size, "bf16x3", use_graph=True)
+    eng = make_engine(arch, w, frames, input_size, "f16x3", use_graph=True)
     for _ in range(2):
         labels, boxes, scores = eng.infer_raw(frames)
     mx = eng.debug_tensor("enc_cls_max")[:, :, 0, 0]
     print(f"{name} enc score max abs err {np.abs(mx - g['enc_cls_max']).max():.2e}")
-    np.testing.assert_allclose(mx, g["enc_cls_max"], atol=2e-3 if "r101" in name else 5e-4)   # R101 1280: 101 layers, 33600 tokens (fp32 engine: 3e-4)
-    # 1280-pixel frames: 1e-2 px is 7.8e-6 of the frame - the resolution of a hi + lo bf16 pair itself (2^-17 = 7.6e-6).  Measured on R101 1280:
-    # worst matched row 5-8e-3 px, 0-4 rows of 300 between 1e-2 and 2e-2 px; bound: <= 6 rows per frame above 1e-2 px, none above 2e-2 px.
-    big = "1280" in name
-    x3_check(name, arch, eng, frames, g["topk"], g["enc_cls_max"], [("hf", g["labels"], g["boxes"], g["scores"])], 2e-3 if "r101" in name else 5e-4,
-             max_off=6 if big else 0, outer_box_tol=2e-2 if big else None)
+    np.testing.assert_allclose(mx, g["enc_cls_max"], atol=5e-4)
+    # 1280-pixel frames: 1e-2 px is 7.8e-6 of the frame.  fp16 pairs carry 2^-22 (round 2's bf16 pairs, 2^-17 = 7.6e-6, left 0-4 rows of 300
+    # between 1e-2 and 1.75e-2 px on R101 1280); no slack on rows at any size.
+    x3_check(name, arch, w, input_size, eng, frames, g["topk"], g["enc_cls_max"], [("hf", g["labels"], g["boxes"], g["scores"])], 5e-4)
     eng.close()
 
 
@@ -229,7 +233,7 @@ def test_full_size_properties_bf16_bs8():
     eng.close()
 
 
-def test_full_size_properties_bf16x3_bs8():
+def test_full_size_properties_f16x3_bs8():
     """The default engine at the benchmark configuration (R50 640 bs8, hipGraph): replay determinism, frame-order equivariance (bit-exact:
     frames are independent units and every kernel choice depends on per-image extents or on the grid as a whole, never on a frame's
     slot), sorted scores, label range, and batch invariance: a frame of the bs-8 call equals the bs-1 call of the same handle bit for bit
@@ -239,7 +243,7 @@ def test_full_size_properties_bf16x3_bs8():
     arch = ARCHS["r50"]
     w = weights_for(arch, 0)
     frames = [scene_frame(50 + i, 640, 640) if i % 2 else noise_frame(50 + i, 640, 640) for i in range(8)]
-    eng = make_engine(arch, w, frames, (640, 640), "bf16x3", use_graph=True)
+    eng = make_engine(arch, w, frames, (640, 640), "f16x3", use_graph=True)
     a = eng.infer_raw(frames)
     b = eng.infer_raw(frames)
     for x, y in zip(a, b):
@@ -258,7 +262,7 @@ def test_full_size_properties_bf16x3_bs8():
         sl, sb, ss = eng.infer_raw([frames[i]])
         m, n, ws, wb, un = match_detections(labels[i], boxes[i], scores[i], sl[0], sb[0], ss[0], 1e-3, 1e-2, return_unmatched=True)
         exact = np.array_equal(labels[i], sl[0]) and np.array_equal(boxes[i], sb[0]) and np.array_equal(scores[i], ss[0])
-        print(f"bs8[{i}] vs bs1 (bf16x3): matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px bit-exact={exact}")
+        print(f"bs8[{i}] vs bs1 (f16x3): matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px bit-exact={exact}")
         assert exact, (i, m, n, ws, wb)       # measured: bit-exact - the small-grid tile shapes of the bs-1 plan keep every output's K order
         worst = max(worst, wb)
     eng.close()
@@ -276,7 +280,7 @@ def test_side_stream_plan_equals_the_serial_plan():
     outs = []
     for v in (0, 1, 3):
         _capi.debug_option("side_stream", v)
-        e = make_engine(arch, w, frames, (640, 640), "bf16x3", use_graph=True)
+        e = make_engine(arch, w, frames, (640, 640), "f16x3", use_graph=True)
         for _ in range(3):
             o = e.infer_raw(frames)
         outs.append(o)
@@ -285,23 +289,6 @@ def test_side_stream_plan_equals_the_serial_plan():
     for o in outs[1:]:
         for x, y in zip(outs[0], o):
             np.testing.assert_array_equal(x, y)
-
-
-def test_patch_maxpool_equals_per_output_maxpool():
-    """the bf16 2x2-patch max-pool kernel against the one-output-per-thread kernel: max is exact, the stem must match bitwise"""
-    from telescope_cam_detection_amd import _capi
-    arch, wseed, input_size, frames, g = load_case("c1_r18_640_scene")
-    w = weights_for(arch, wseed)
-    outs = []
-    for v1 in (1, 0):
-        _capi.debug_option("maxpool_v1", v1)
-        e = make_engine(arch, w, frames, input_size, "bf16")
-        e.infer_raw(frames)
-        outs.append(e.debug_tensor("stem").copy())
-        e.close()
-    _capi.debug_option("maxpool_v1", 0)
-    assert outs[0].shape == outs[1].shape and np.isfinite(outs[0]).all()
-    np.testing.assert_array_equal(outs[0], outs[1])
 
 
 def test_fused_reduce_conv_matches_separate_launch():
@@ -330,8 +317,8 @@ def test_fused_reduce_conv_matches_separate_launch():
     assert rel < 3e-3 and err < 3e-2
 
 
-def test_bf16x3_fused_reduce_convs_match_separate_launches():
-    """bf16x3: the streaming expand convs of stage 0 carry the next block's reduce conv (also s0's last block -> stage 1's first c1):
+def test_f16x3_fused_reduce_convs_match_separate_launches():
+    """f16x3: the streaming expand convs of stage 0 carry the next block's reduce conv (also s0's last block -> stage 1's first c1):
     three launches fewer, stage outputs equal to the unfused plan to the engine's rounding (only that GEMM's accumulation order differs)."""
     from telescope_cam_detection_amd import _capi
     from telescope_cam_detection_amd.synth import noise_frame, scene_frame
@@ -342,7 +329,7 @@ def test_bf16x3_fused_reduce_convs_match_separate_launches():
     outs, launches = [], []
     for v in (0, 1):
         _capi.debug_option("c1_fuse", v)
-        e = make_engine(arch, w, frames, (640, 640), "bf16x3")
+        e = make_engine(arch, w, frames, (640, 640), "f16x3")
         e.infer_raw(frames)
         outs.append([e.debug_tensor(f"backbone{i}").astype(np.float64).copy() for i in range(3)])
         launches.append(len(e.profile(2, 1)))
@@ -351,7 +338,7 @@ def test_bf16x3_fused_reduce_convs_match_separate_launches():
     assert launches[1] == launches[0] - 3
     for a, b in zip(*outs):
         rel = np.linalg.norm(a - b) / np.linalg.norm(a)
-        print(f"bf16x3 fused reduce convs: rel l2 {rel:.2e}")
+        print(f"f16x3 fused reduce convs: rel l2 {rel:.2e}")
         assert rel < 2e-5
 
 
@@ -502,7 +489,7 @@ def test_bf16_engine_stagewise(name):
 
 def test_bf16_engine_on_the_benchmark_frames_against_hf_fixture():
     """precision="bf16" on BASELINE config 2's own frames (R50 640 bs8, seeds 2000-2007), free-running, against the committed HF
-    outputs: what the faster opt-in engine delivers, with the measured figures as bounds (the default bf16x3 engine is held to
+    outputs: what the faster opt-in engine delivers, with the measured figures as bounds (the default f16x3 engine is held to
     1e-3 / 1e-2 px on the same fixture above)."""
     arch, wseed, input_size, frames, g = load_case("c2_r50_640_bs8")
     w = weights_for(arch, wseed)
@@ -644,8 +631,8 @@ def test_fused_uint8_stem_matches_the_generic_preprocess_plus_conv():
         assert m >= n - 8, (b, m, n, ws, wb)                                     # measured: <= 5 of 300 miss (the resized frame)
 
 
-def test_bf16x3_fused_uint8_stem_matches_the_generic_stem():
-    """bf16x3: backbone.stem.0 straight from the uint8 frames (default, hi/lo pairs made on the fly) against the generic form (fp32
+def test_f16x3_fused_uint8_stem_matches_the_generic_stem():
+    """f16x3: backbone.stem.0 straight from the uint8 frames (default, hi/lo pairs made on the fly) against the generic form (fp32
     NHWC-8 image + exact fp32-MFMA conv): same detections at the north-star tolerance; the first stage output agrees to split rounding."""
     from telescope_cam_detection_amd import _capi
     from telescope_cam_detection_amd.arch import ARCHS
@@ -659,7 +646,7 @@ def test_bf16x3_fused_uint8_stem_matches_the_generic_stem():
     out, stem = {}, {}
     for fused in (0, 1):
         _capi.debug_option("stem_fused_split", fused)
-        eng = _capi.Engine(arch, blob, 0, _capi.PREC_BF16X3, 3, (640, 640), True)
+        eng = _capi.Engine(arch, blob, 0, _capi.PREC_F16X3, 3, (640, 640), True)
         for _ in range(2):
             out[fused] = eng.infer_raw(frames)
         stem[fused] = eng.debug_tensor("stem").astype(np.float64)
@@ -667,11 +654,11 @@ def test_bf16x3_fused_uint8_stem_matches_the_generic_stem():
         eng.close()
     np.testing.assert_array_equal(out[("input", 0)], out[("input", 1)])
     e = np.linalg.norm(stem[0] - stem[1]) / np.linalg.norm(stem[0])
-    print(f"bf16x3 fused stem vs generic: stem rel l2 {e:.2e}")
+    print(f"f16x3 fused stem vs generic: stem rel l2 {e:.2e}")
     assert e < 1e-5
     for b in range(len(frames)):
         m, n, ws, wb = match_detections(out[0][0][b], out[0][1][b], out[0][2][b], out[1][0][b], out[1][1][b], out[1][2][b], 1e-3, 1e-2)
-        print(f"bf16x3 fused stem vs generic [{b}]: matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
+        print(f"f16x3 fused stem vs generic [{b}]: matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
         assert m >= n - 2, (b, m, n, ws, wb)
 
 
@@ -709,7 +696,7 @@ def test_non_square_input_with_partial_tiles_bf16_and_fp32():
         assert m >= n - 18, ("bf16", b, m, n, ws, wb)                            # measured: 10-12 of 300 miss at 3e-2 / 4 px
 
 
-def test_bf16x3_non_square_frames_with_ragged_tiles_against_the_oracle():
+def test_f16x3_non_square_frames_with_ragged_tiles_against_the_oracle():
     """R50 at 480 x 608 (multiples of 32; 120 x 152, 60 x 76, 30 x 38 and 15 x 19 maps are not multiples of the 8 x 16 / 32- / 128-pixel tiles): the
     default engine's direct, streaming (fused follower, tiles straddling images), tiled, flexible and split-K kernels all meet ragged tiles inside
     the network.  Against the oracle at the north-star tolerance, free-running and with the oracle's query selection."""
@@ -720,19 +707,19 @@ def test_bf16x3_non_square_frames_with_ragged_tiles_against_the_oracle():
     size = (480, 608)
     frames = [scene_frame(300, size[0], size[1]), noise_frame(301, size[0], size[1]), scene_frame(302, 360, 500)]      # the third one is resampled
     (ol, ob, osc), col = oracle_run(arch, w, frames, size)
-    eng = make_engine(arch, w, frames, size, "bf16x3", use_graph=True)
+    eng = make_engine(arch, w, frames, size, "f16x3", use_graph=True)
     eng.infer_raw(frames)
     for i in range(3):
         e = rel_err(nchw(eng.debug_tensor(f"enc{i}")), col[f"enc{i}"].numpy())
         print(f"480x608 enc{i} rel l2 err {e:.2e}")
         assert e < 1e-4
     refs = [("oracle", [t.numpy() for t in ol], [t.numpy() for t in ob], [t.numpy() for t in osc])]
-    x3_check("r50_480x608", arch, eng, frames, col["topk"].numpy(), col["enc_cls_max"].numpy(), refs, 5e-4)
+    x3_check("r50_480x608", arch, w, size, eng, frames, col["topk"].numpy(), col["enc_cls_max"].numpy(), refs, 5e-4)
     eng.close()
 
 
 @pytest.mark.parametrize("aname,size,bs", [("r34", (640, 640), 2), ("r101", (640, 640), 1), ("r18", (320, 320), 5)])
-def test_bf16x3_other_backbones_and_sizes_against_the_oracle(aname, size, bs):
+def test_f16x3_other_backbones_and_sizes_against_the_oracle(aname, size, bs):
     """The variants the reference's config files name besides R50 (r18vd / r34vd basic blocks, r101vd) and a small input / odd batch: default
     engine vs the oracle at the north-star tolerance (no golden file: the oracle itself is pinned to HF on the committed cases)."""
     from telescope_cam_detection_amd.arch import ARCHS
@@ -741,9 +728,9 @@ def test_bf16x3_other_backbones_and_sizes_against_the_oracle(aname, size, bs):
     w = weights_for(arch, 5)
     frames = [scene_frame(400 + i, size[0], size[1]) if i % 2 == 0 else noise_frame(400 + i, size[0], size[1]) for i in range(bs)]
     (ol, ob, osc), col = oracle_run(arch, w, frames, size)
-    eng = make_engine(arch, w, frames, size, "bf16x3", use_graph=True)
+    eng = make_engine(arch, w, frames, size, "f16x3", use_graph=True)
     refs = [("oracle", [t.numpy() for t in ol], [t.numpy() for t in ob], [t.numpy() for t in osc])]
-    x3_check(f"{aname}_{size[0]}_bs{bs}", arch, eng, frames, col["topk"].numpy(), col["enc_cls_max"].numpy(), refs, 1e-3 if aname == "r101" else 5e-4)
+    x3_check(f"{aname}_{size[0]}_bs{bs}", arch, w, size, eng, frames, col["topk"].numpy(), col["enc_cls_max"].numpy(), refs, 5e-4)
     eng.close()
 
 

@@ -193,7 +193,7 @@ def test_detector_survives_the_callers_degrade_writes():
     (caught and logged by the caller).  detect / detect_batch keep working afterwards."""
     from telescope_cam_detection_amd.rtdetr_detector import RTDETRDetector, _DeviceModel
     det = RTDETRDetector(config_path="r18", model_path="synthetic:r18:0", device="cuda:3", input_size=(640, 640))
-    assert det.precision == "bf16x3"                       # the default engine is the one held to the reference tolerance
+    assert det.precision == "f16x3"                       # the default engine is the one held to the reference tolerance
     eng = _FakeEngine()
     det.model, det._dev_index, det._engine_input_size = _DeviceModel(eng, "cuda:3"), 3, (640, 640)
     # --- the caller's _apply_degradation, verbatim in effect ---
@@ -230,21 +230,24 @@ def test_oom_return_code_becomes_torch_cuda_out_of_memory_error():
     with pytest.raises(_capi.RtdError) as ei:
         _capi._raise(_capi.RTD_E_HIP, None)
     assert not isinstance(ei.value, torch.cuda.OutOfMemoryError) and ei.value.code == _capi.RTD_E_HIP
-    assert _capi.precision_code("bf16x3") == _capi.PREC_BF16X3 and _capi.precision_code("fp32") == _capi.PREC_FP32
+    assert _capi.precision_code("f16x3") == _capi.PREC_F16X3 and _capi.precision_code("fp32") == _capi.PREC_FP32
     with pytest.raises(ValueError):
         _capi.precision_code("int8")
 
 
 def test_split_layout_host_mirror_roundtrip():
-    """_capi.to_split / from_split mirror csrc/common.h's BF16X2 layout: 32-channel groups [32 hi | 32 lo], hi + lo within 2^-17 of x"""
+    """_capi.to_split / from_split mirror csrc/common.h's F16X2 layout: 32-channel groups [32 hi | 32 lo] of fp16; hi + lo is within
+    2^-22 of x in relative terms or 2^-25 in absolute terms (the lo half goes subnormal below |x| = 2^-3), and saturates at +-65504"""
     from telescope_cam_detection_amd import _capi
     rng = np.random.default_rng(0)
     x = (rng.standard_normal((3, 5, 96)) * np.exp(rng.uniform(-8, 8, (3, 5, 96)))).astype(np.float32)
     s = _capi.to_split(x)
     assert s.shape == (3, 5, 192) and s.dtype == np.uint16
     y = _capi.from_split(s)
-    assert np.all(np.abs(y - x) <= np.abs(x) * 2.0 ** -17)
-    hi = (s.reshape(3, 5, 3, 2, 32)[..., 0, :].astype(np.uint32) << 16).view(np.float32).reshape(3, 5, 96)
-    assert np.all(np.abs(hi - x) <= np.abs(x) * 2.0 ** -8)   # the hi half alone is the bf16 rounding of x
+    assert np.all(np.abs(y - x) <= np.maximum(np.abs(x) * 2.0 ** -22, 2.0 ** -25))
+    hi = s.reshape(3, 5, 3, 2, 32)[..., 0, :].copy().view(np.float16).astype(np.float32).reshape(3, 5, 96)
+    assert np.all(np.abs(hi - x) <= np.maximum(np.abs(x) * 2.0 ** -11, 2.0 ** -25))   # the hi half alone is the fp16 rounding of x
+    big = np.full((1, 32), 1.0e6, np.float32)
+    assert np.all(_capi.from_split(_capi.to_split(big)) == 65504.0) and np.all(_capi.from_split(_capi.to_split(-big)) == -65504.0)
     z = np.zeros((2, 64), np.float32)
     assert np.array_equal(_capi.from_split(_capi.to_split(z)), z)

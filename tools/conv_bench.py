@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--flush-mb", type=int, default=1024)
-    ap.add_argument("--dtype", type=int, default=4, help="0 bf16, 1 fp32, 4 BF16X2 (the bf16x3 engine's operands)")
+    ap.add_argument("--dtype", type=int, default=4, help="0 bf16, 1 fp32, 4 F16X2 (the f16x3 engine's operands)")
     ap.add_argument("--only", default="", help="substring filter on the layer name")
     args = ap.parse_args()
     from telescope_cam_detection_amd import _capi

@@ -9,9 +9,7 @@ from telescope_cam_detection_amd.synth import noise_frame
 from telescope_cam_detection_amd.weights import fold_weights, pack_blob, synth_weights
 arch = ARCHS["r50"]; B = 8
 _capi.debug_option("dec_stamps", 1)
-if os.environ.get("RTD_DEC_PF"):
-    _capi.debug_option("dec_pf", int(os.environ["RTD_DEC_PF"]))   # 2 / 3 = K steps in flight; +16 = L2-hot filter probe (wrong results)
-eng = _capi.Engine(arch, pack_blob(fold_weights(arch, synth_weights(arch, 0))), 0, _capi.precision_code(os.environ.get("RTD_PREC", "bf16x3")), B, (640, 640), use_graph=False)
+eng = _capi.Engine(arch, pack_blob(fold_weights(arch, synth_weights(arch, 0))), 0, _capi.precision_code(os.environ.get("RTD_PREC", "f16x3")), B, (640, 640), use_graph=False)
 frames = [noise_frame(i, 640, 640) for i in range(B)]
 for _ in range(3):
     eng.infer_raw(frames)

@@ -3,7 +3,7 @@
 plan's algorithmic bytes (profiles/*_layers_*.json): which layers re-read their operands from beyond L2.
 
     python tools/pmc_per_layer.py gpurun_out/r02/pmc_fetch/runc_counter_collection.csv gpurun_out/r02/pmc_write/runc_counter_collection.csv \
-        profiles/r02_layers_r50_bs8_bf16x3.json
+        profiles/r02_layers_r50_bs8_f16x3.json
 
 Launches are matched to layers in order: the layer list must come from the same plan as the counter passes (refresh_profiles.sh profiles the
 one-stream plan, `--opt side_stream=0`, whose decoder input projections sit after the PAN path: `tools/profile_layers.py --opt side_stream=0`).

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel HIP-event profile of one forward (rtd_profile), optionally A/B-ing debug options in ONE process.
 
-    python tools/profile_layers.py --arch r50 --batch 8 --ab conv_v1 --out gpurun_out/layers.json
+    python tools/profile_layers.py --arch r50 --batch 8 --ab split_flex --out gpurun_out/layers.json
 """
 import argparse
 import json
@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--arch", default="r50")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--precision", default="bf16x3")
+    ap.add_argument("--precision", default="f16x3")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--ab", default="", help="debug option to A/B")
     ap.add_argument("--vals", default="1,0", help="two values of the option: baseline,candidate")

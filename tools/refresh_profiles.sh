@@ -7,7 +7,7 @@ R=${1:-r02}
 export TMPDIR=/tmp
 O=gpurun_out/$R
 mkdir -p $O
-# 1. the bench line (default: bf16x3 engine, one batch in flight = `value`; + multi_stream, bf16_engine, cpu_baseline side lines)
+# 1. the bench line (default: f16x3 engine, one batch in flight = `value`; + multi_stream, bf16_engine, cpu_baseline side lines)
 timeout -k 10 600 python bench.py > $O/bench_r50.json 2> $O/bench_r50.err
 # 2. kernel trace + stats of ONE handle (what roofline.avg_launch_us must agree with), then the PMC passes.  side_stream=0: every kernel of the
 #    step on one stream, so that durations and counters belong to one kernel at a time (the product overlaps the query-selection chain with the

@@ -28,7 +28,7 @@ def csrc_sha() -> str:
     return h.hexdigest()[:16]
 
 
-CONFIG = os.environ.get("RTD_PROFILE_CONFIG", "r50_bs8_bf16x3")   # <arch>_bs<B>_<precision> of the profiled bench.py command
+CONFIG = os.environ.get("RTD_PROFILE_CONFIG", "r50_bs8_f16x3")   # <arch>_bs<B>_<precision> of the profiled bench.py command
 
 
 def family(name: str) -> str:

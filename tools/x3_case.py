@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: one golden case on the bf16x3 engine with rtd_debug_option settings from the command line; prints matched rows per tolerance.
+"""Diagnostic: one golden case on the f16x3 engine with rtd_debug_option settings from the command line; prints matched rows per tolerance.
     python tools/x3_case.py c3_r101_1280_bs1 conv_reg=1 split_sx=0"""
 import os, sys
 import numpy as np
@@ -12,7 +12,7 @@ for o in sys.argv[2:]:
     k, v = o.split("=")
     _capi.debug_option(k, int(v))
 arch, wseed, input_size, frames, g = load_case(name)
-eng = _capi.Engine(arch, pack_blob(fold_weights(arch, weights_for(arch, wseed))), 0, _capi.precision_code(os.environ.get("RTD_PREC", "bf16x3")), len(frames), input_size, use_graph=False)
+eng = _capi.Engine(arch, pack_blob(fold_weights(arch, weights_for(arch, wseed))), 0, _capi.precision_code(os.environ.get("RTD_PREC", "f16x3")), len(frames), input_size, use_graph=False)
 labels, boxes, scores = eng.infer_raw(frames)
 mx = eng.debug_tensor("enc_cls_max")[:, :, 0, 0]
 print(name, sys.argv[2:], "enc score max abs err %.2e" % np.abs(mx - g["enc_cls_max"]).max())
