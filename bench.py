@@ -14,9 +14,9 @@ exists offline).  One "step" = one batch of 8 frames through preprocess -> netwo
 fixed [8,300,6] result block stays in HBM).  N > 1: one process per GPU, cameras sharded over ranks (weak scaling), and one
 RCCL all-gather of every rank's result block per step - the collate step for rank 0's web server.
 
-Engine (--precision): "f16x3" (default) = hi/lo bf16 pairs, three MFMAs per product, fp32 accumulate - the engine that meets
-the north-star tolerance (1e-3 on scores, 1e-2 px on boxes; tests/test_gpu_parity.py) AND the throughput target;
-"bf16" = plain bf16 storage / MFMA (faster, 2-4x outside the tolerance - printed as `bf16_engine` beside the headline);
+Engine (--precision): "f16x3" (default) = hi/lo fp16 pairs, three MFMAs per product, fp32 accumulate - the engine that meets
+the north-star tolerance (1e-3 on scores, 1e-2 px on boxes; 640- and 1280-px frames, tests/test_gpu_parity.py) AND the throughput
+target; "bf16" = plain bf16 storage / MFMA (faster, far outside the tolerance - printed as `bf16_engine` beside the headline);
 "fp32" = exact fp32 MFMAs.
 
 `value` is measured with ONE batch in flight (--streams 1: BASELINE's "bs=8" read strictly; ms_per_step is then the latency of a
@@ -24,11 +24,18 @@ step).  `multi_stream` repeats the measurement with --multi-streams S (default 3
 stream, hipGraph and camera group, taking the K timed steps round-robin - the reference's deployment shape (one inference engine
 per camera group sharing the GPU, main.py:1236-1291); every step is still one full bs-8 pass.
 
+--collate at N = 1: the RCCL collate step runs on a world-size-1 `nccl` group exactly as it does at N > 1 (same all_gather_into_tensor
+on the engine's stream over the zero-copy view of the result block), `value` includes it and `collate` reports its cost per step.
+
 Prints ONE JSON line on rank 0 with the contract fields plus:
   roofline     - MFMA roofline of the dominant kernel family (conv_igemm), from HIP-event timings of every launch on the
                  engine's stream (rtd_profile) and the algorithmic FLOPs per launch
   cpu_baseline - the CPU oracle (oracle/rtdetr_oracle.py, fp32 eager PyTorch) timed on this box's host cores on a bounded
                  sample of the same workload (rank 0, N = 1 only)
+  detect_host_ms - the call the product makes (src/inference_engine_yolox.py:554): synchronous RTDETRDetector.detect(np.ndarray) on
+                 HOST frames of 640x640, 1280x720 and 1920x1080 (input_size 640), 10 warm-ups + 100 timed calls each, R50 and R18:
+                 mean / std / min / max / p50 / p95 / p99 - the protocol of the reference's tests/test_inference.py:63-115.  Includes
+                 the H2D copy, the PIL-exact resampler, the D2H of the result block and the Python formatting; never `value`.
 """
 from __future__ import annotations
 
@@ -86,6 +93,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-bf16-line", action="store_true", help="skip the secondary plain-bf16 engine measurement")
+    ap.add_argument("--no-detect-host", action="store_true", help="skip the detect_host_ms measurement (RTDETRDetector.detect on host frames)")
+    ap.add_argument("--collate", action="store_true", help="N = 1: run the RCCL collate step on a world-size-1 nccl group (always on at N > 1)")
     ap.add_argument("--profile-out", default="")
     ap.add_argument("--opt", action="append", default=[], help="rtd_debug_option name=value (A/B runs)")
     ap.add_argument("--launch-selftest", action="store_true",
@@ -139,10 +148,16 @@ def main():
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the hot path"
     torch.cuda.set_device(local_rank)
-    rccl_ranks = 1
-    if world > 1:
+    rccl_ranks = 0                                   # ranks of the nccl (= RCCL) group the collate step ran on; 0 = no group was formed
+    collate = world > 1 or args.collate
+    if collate:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         rccl_ranks = dist.get_world_size()
 
@@ -164,11 +179,11 @@ def main():
     def fence(engs):
         for e in engs:
             e.sync()
-        if world > 1:
+        if rccl_ranks:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(precision: str, S: int, crops=None):
+    def measure(precision: str, S: int, crops=None, collate=collate):
         """K timed steps round-robin over S engine handles of `precision`; returns (elapsed seconds, handles, their frames)."""
         prec = _capi.precision_code(precision)
         # several handles per GPU run the throughput profile (rtd_config.profile); a lone handle the latency profile
@@ -179,14 +194,14 @@ def main():
         frames_of = [[torch.from_numpy(noise_frame(2000 + (rank * S + si) * B + i, H, H)).cuda() for i in range(B)] for si in range(S)]
         prepared = [e.make_async_args(f) for e, f in zip(engs, frames_of)]
         streams = [torch.cuda.ExternalStream(e.stream(), device=torch.device("cuda", local_rank)) for e in engs]
-        gathered = [torch.empty(world * B * Q * 6, dtype=torch.float32, device="cuda") for _ in range(S)] if world > 1 else None
+        gathered = [torch.empty(world * B * Q * 6, dtype=torch.float32, device="cuda") for _ in range(S)] if collate else None
 
         def step(k):
             si = k % S
             engs[si].infer_async_prepared(prepared[si])
             if crops is not None:
                 crops(engs[si], frames_of[si], streams[si])
-            if world > 1:
+            if collate:
                 ptr, n = engs[si].result_block()
                 block = torch.as_tensor(_DevPtr(ptr, n), device=f"cuda:{local_rank}")
                 with torch.cuda.stream(streams[si]):              # ordered after the forward on that engine's stream
@@ -224,11 +239,23 @@ def main():
                    "global_batch": world * B, "parallelism": f"camera-shard x{world}" + (" + RCCL all_gather of detections" if world > 1 else ""),
                    "streams_per_gpu": S, "batches_in_flight_per_gpu": S,
                    "kernel_profile": "throughput" if (S > 1 and not args.latency_profile) else "latency", "hip_graph": not args.no_graph,
-                   "engine": {"f16x3": "hi/lo bf16 pairs, 3 MFMAs per product, fp32 accumulate (meets 1e-3 / 1e-2 px)",
+                   "engine": {"f16x3": "hi/lo fp16 pairs, 3 MFMAs per product, fp32 accumulate (meets 1e-3 / 1e-2 px at 640 and 1280 px)",
                               "bf16": "bf16 storage + MFMA, fp32 accumulate (outside the 1e-3 / 1e-2 px tolerance)",
                               "fp32": "exact fp32 MFMAs"}[args.precision]},
         "rccl_ranks": rccl_ranks,
     }
+    if collate and world == 1:
+        # the same K steps without the collate step: the all-gather's cost per step on this GPU (world size 1: RCCL's launch + local copy)
+        for e in engs:
+            e.close()
+        el0, e0, _ = measure(args.precision, S, crops_fn, collate=False)
+        for e in e0:
+            e.close()
+        out["collate"] = {"ms_per_step_with": round(1000.0 * elapsed / args.steps, 4), "ms_per_step_without": round(1000.0 * el0 / args.steps, 4),
+                          "all_gather_us_per_step": round(1e6 * (elapsed - el0) / args.steps, 1), "bytes_per_rank": B * Q * 6 * 4,
+                          "note": "torch.distributed all_gather_into_tensor (backend nccl = RCCL) on the engine's HIP stream over a zero-copy view of rtd_result_block"}
+        elapsed, engs, frames_of = measure(args.precision, S, crops_fn)       # handles for the profile / latency legs below
+        eng, frames = engs[0], frames_of[0]
     if crop_info:
         out["config"]["stage2"] = crop_info
     if args.arch in CANON_GFLOP_PER_FRAME and H == 640:
@@ -260,25 +287,32 @@ def main():
                       "`achieved` counts ALGORITHMIC flops (2 per MAC); the f16x3 engine issues 3 MFMA flops per algorithmic flop (mfma_issue_frac)",
         }
         # HBM bytes per launch / rocprofv3 durations / MFMA-busy counters come from the committed PMC passes (separate rocprofv3 runs of
-        # this same command: counters cannot be read live).  They are attached only when the profile was measured on THESE kernel sources.
+        # this same command: counters cannot be read live).  They are attached only when the profile was measured on THESE kernel sources
+        # and THIS configuration (tools/refresh_profiles.sh writes them, tools/summarize_profiles.py stamps csrc hash + config).
         try:
             sha = csrc_sha()
-            tag = f"{args.arch}_bs{B}_{args.precision}"
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) as fh:
+            tag = f"{args.arch}_{H}_bs{B}_{args.precision}"
+            sfx = "" if tag == "r50_640_bs8_f16x3" else f"_{args.arch}_{H}_bs{B}"
+            with open(os.path.join(ROOT, "profiles", f"r03_pmc_hbm_traffic{sfx}.json")) as fh:
                 pmc = json.load(fh)
-            if pmc.get("csrc_sha") == sha and pmc.get("config") == tag and dom == "conv_igemm" and H == 640:
+            if pmc.get("csrc_sha") == sha and pmc.get("config") == tag and dom == "conv_igemm":
+                allf = [v for k, v in pmc.items() if isinstance(v, dict) and "launches" in v]
                 fams = [v for k, v in pmc.items() if isinstance(v, dict) and k.startswith("conv")]
                 tb = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in fams)
                 nl = sum(v["launches"] for v in fams)
                 out["roofline"]["traffic"] = round(tb / nl / 1e6, 2)
-                out["roofline"]["traffic_unit"] = f"MB HBM per launch (PMC, profiles/r02_pmc_hbm_traffic.json @ csrc {sha})"
+                out["roofline"]["traffic_unit"] = f"MB HBM per launch (PMC, profiles/r03_pmc_hbm_traffic{sfx}.json @ csrc {sha})"
                 out["roofline"]["alg_mbytes_per_launch_unfused"] = round(d["bytes"] / d["launches"] / 1e6, 2)
-            with open(os.path.join(ROOT, "profiles", "r02_rocprofv3_kernel_summary.json")) as fh:
+                step_bytes = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in allf)
+                out["hbm"] = {"gbytes_per_step_pmc": round(step_bytes / 1e9, 3), "gbytes_per_s": round(step_bytes / elapsed * args.steps / 1e9, 1),
+                              "frac_of_peak": round(step_bytes / elapsed * args.steps / 1e9 / HBM_PEAK_GBS, 4), "peak_gbytes_per_s": HBM_PEAK_GBS,
+                              "note": "whole step: PMC bytes of one steady step (FETCH_SIZE x 2 + WRITE_SIZE) / this run's ms_per_step"}
+            with open(os.path.join(ROOT, "profiles", f"r03_rocprofv3_kernel_summary{sfx}.json")) as fh:
                 rp = json.load(fh)
             if rp.get("csrc_sha") == sha and rp.get("config") == tag:
                 out["roofline"]["avg_launch_us_rocprofv3"] = rp["conv_igemm_all"]["avg_us"]
                 out["roofline"]["achieved_rocprofv3"] = round(d["flops"] / (rp["conv_igemm_all"]["us_per_step"] * 1e-6) / 1e12, 2)
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_mfma_util.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", f"r03_pmc_mfma_util{sfx}.json")) as fh:
                 mu = json.load(fh)
             if mu.get("csrc_sha") == sha and mu.get("config") == tag:
                 out["roofline"]["mfma_busy_frac_pmc"] = mu["conv_igemm_all"]["mfma_util"]
@@ -320,6 +354,34 @@ def main():
         for e in es:
             e.close()
 
+    if rank == 0 and world == 1 and not args.no_detect_host and args.workload == "detect" and args.precision == "f16x3" and not args.opt:
+        # ---- the call the product makes: RTDETRDetector.detect(host frame), protocol of the reference's tests/test_inference.py:63-115 ----
+        print("[bench] detect() on host frames ...", file=sys.stderr, flush=True)
+        import logging
+        from telescope_cam_detection_amd.rtdetr_detector import RTDETRDetector
+        logging.getLogger("telescope_cam_detection_amd").setLevel(logging.ERROR)
+        dh = {"protocol": "10 warm-ups + 100 timed synchronous RTDETRDetector.detect(np.ndarray HWC uint8 BGR, host memory) per frame size; "
+                          "input_size 640x640, conf_threshold 0.25, wildlife_only, precision f16x3, hipGraph; ms per call"}
+        for an in ("r50", "r18"):
+            det = RTDETRDetector(config_path=an, model_path=f"synthetic:{an}:0", device=f"cuda:{local_rank}", input_size=(640, 640), max_batch=1)
+            if not det.load_model(max_retries=1):
+                continue
+            for (fh_, fw_) in ((640, 640), (720, 1280), (1080, 1920)):
+                fr = np.random.default_rng(7000 + fh_).integers(0, 255, (fh_, fw_, 3), dtype=np.uint8)
+                for _ in range(10):
+                    det.detect(fr)
+                ts = []
+                for _ in range(100):
+                    t1 = time.perf_counter()
+                    det.detect(fr)
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                ts = np.asarray(ts)
+                dh[f"{an}_{fw_}x{fh_}"] = {k: round(float(v), 3) for k, v in (("mean", ts.mean()), ("std", ts.std()), ("min", ts.min()), ("max", ts.max()),
+                                                                           ("p50", np.percentile(ts, 50)), ("p95", np.percentile(ts, 95)), ("p99", np.percentile(ts, 99)))}
+                dh[f"{an}_{fw_}x{fh_}"]["fps"] = round(1000.0 / float(ts.mean()), 1)
+            det.model.engine.close()
+        out["detect_host_ms"] = dh
+
     if rank == 0:
         # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
         if not args.no_cpu_baseline and world == 1:
@@ -328,7 +390,7 @@ def main():
             cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("RTD_CPU_THREADS", "16")))
             torch.set_num_threads(cores)
             print(f"[bench] cpu baseline on {cores} threads ...", file=sys.stderr, flush=True)
-            nb = 2
+            nb = min(B, 8)                                    # the benchmark batch itself (R50 640 bs 8: ~2 s per batch on 16 threads)
             host = [f.cpu().numpy() for f in frames[:nb]]
             orc.detect_batch(arch, w, host, (H, H))          # warm-up
             reps = 3
@@ -340,7 +402,7 @@ def main():
                                    "sample": f"CPU oracle (fp32 eager PyTorch restatement of the reference path), RT-DETR-{args.arch.upper()} "
                                              f"{H}x{H} bs={nb}, {reps} timed batches after 1 warm-up, torch threads={cores}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if rccl_ranks:
         dist.barrier()
         dist.destroy_process_group()
 

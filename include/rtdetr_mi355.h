@@ -160,7 +160,7 @@ int64_t rtd_arena_bytes(rtd_handle h);
  *   sc_fold [1] projection shortcut folded into the block's last conv | up_fold [1] FPN upsample folded into the CSP's first conv |
  *   c1_fuse [1] a block's reduce conv computed inside the previous block's expand conv (bf16: stage 0/1; f16x3: stage 0 and the first block
  *   of stage 1) | attn_split [2] self-attention on fp16-pair MFMAs (bit 0 AIFI, bit 1 decoder) |
- *   arena_reuse [1] | stem_fused [0] (bf16) / stem_fused_split [1] (f16x3): stem.0 straight from the uint8 frames | side_stream [3: bit 0 query
+ *   arena_reuse [1] | stem_fused_split [1] (f16x3): stem.0 straight from the uint8 frames | side_stream [3: bit 0 query
  *   selection on a second stream beside the value projection, bit 1 decoder input projections beside the PAN path] | dec_fused [1],
  *   dec_split [1: 0 fp32 MFMA, 2 hi-only filters], sel_fused [1] | dec_stamps [0]
  * Tools: profile_twice [0], bench_rewarm [0].

@@ -39,8 +39,7 @@ struct PlanOpts {
   int attn_split = 2;
   int up_fold = 1;      // read the FPN's upsampled lateral straight from the half-size tensor (ConvArgs::x_up2)
   int arena_reuse = 1;  // backbone stages recycle their activation buffers
-  int stem_fused = 0;   // bf16 engine runs backbone.stem.0 straight from the uint8 frames (measured neutral -> off, kept tested)
-  int stem_fused_split = 1;   // the same for the f16x3 engine (hi/lo pairs made on the fly from the bytes): on
+  int stem_fused_split = 1;   // f16x3 engine: backbone.stem.0 straight from the uint8 frames (hi/lo pairs made on the fly from the bytes)
   int sel_fused = 1;    // LayerNorm + score head + class max of the query selection in one launch
   int dec_fused = 1;    // 0 = one launch per decoder op
   int side_stream = 3;  // bit 0: the query-selection chain runs on a second stream beside the value projection; bit 1: the decoder input
@@ -570,7 +569,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   int h = down2(H), w = down2(W);
   Tensor s0 = B.act(P, n, h, w, eh);
   // f16x3: on by default - the generic form there is a 105 MB fp32 NHWC-8 image + an fp32-MFMA stem conv (30 + 180 us at R50 bs 8)
-  plan->stem_fused = ((e->opts.stem_fused && P == BF16) || (SP && e->opts.stem_fused_split)) && eh == 32;
+  plan->stem_fused = SP && e->opts.stem_fused_split && eh == 32;
   if (plan->stem_fused) {
     // straight from the uint8 frames (ops.hip stem0_u8_kernel); `x` is only materialised on demand for rtd_debug_tensor("input")
     const uint8_t** table = (const uint8_t**)B.alloc((size_t)c.max_batch * sizeof(void*));
@@ -1101,15 +1100,19 @@ Plan* get_plan(rtd_engine* e, int n) {
   return p;
 }
 
-// one op of the plan on its lane's stream; fork / join markers become event edges (inside a capture: graph dependencies)
-void run_op(rtd_engine* e, Op& op) {
+// one op of the plan on its lane's stream; fork / join markers become event edges (inside a capture: graph dependencies).
+// `capture_events` != nullptr: the call runs inside hipStreamBeginCapture.  A marker then records a FRESH event that exists only for this
+// capture (destroyed right after hipStreamEndCapture, run_plan): the handle's long-lived ev_fork / ev_join are never recorded inside a
+// capture, so no event object carrying captured state is ever recorded live again or handed back to the runtime's pool while the
+// process goes on (round 2 saw, once in ~6 test runs, a torch event created later fail its first query with hipErrorCapturedEvent).
+void run_op(rtd_engine* e, Op& op, std::vector<hipEvent_t>* capture_events = nullptr, size_t* next_event = nullptr) {
   if (op.debug_only && !e->force_used) return;
-  if (op.kind == 1) {
-    HIP_CHECK(hipEventRecord(e->ev_fork, e->stream));
-    HIP_CHECK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-  } else if (op.kind == 2) {
-    HIP_CHECK(hipEventRecord(e->ev_join, e->side));
-    HIP_CHECK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+  if (op.kind == 1 || op.kind == 2) {
+    hipEvent_t ev = op.kind == 1 ? e->ev_fork : e->ev_join;
+    if (capture_events) ev = capture_events->at((*next_event)++);      // created before the capture began (run_plan)
+    hipStream_t from = op.kind == 1 ? e->stream : e->side, to = op.kind == 1 ? e->side : e->stream;
+    HIP_CHECK(hipEventRecord(ev, from));
+    HIP_CHECK(hipStreamWaitEvent(to, ev, 0));
   } else {
     op.run(op.lane == 1 ? e->side : e->stream);
   }
@@ -1126,17 +1129,39 @@ void run_plan(rtd_engine* e, Plan* p) {
         run_op(e, op);
         if (trace) { HIP_CHECK(hipStreamSynchronize(e->side)); HIP_CHECK(hipStreamSynchronize(e->stream)); }
       }
+      HIP_CHECK(hipStreamSynchronize(e->side));
       HIP_CHECK(hipStreamSynchronize(e->stream));
-      HIP_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+      std::vector<hipEvent_t> cap_events;
+      // HIP keeps "last recorded in a capturing stream" on the event OBJECT, and objects of destroyed events are recycled: an event that goes
+      // back in that state makes a later hipEventCreate'd event of anyone in the process (torch) fail its first use with
+      // hipErrorCapturedEvent (reproduced: tests/test_batching.py, two detectors).  So every capture event is recorded once on the live,
+      // idle stream - an ordinary event again - before it is destroyed.
+      auto drop_events = [&] {
+        for (hipEvent_t ev : cap_events) {
+          if (hipEventRecord(ev, e->stream) == hipSuccess) (void)hipEventSynchronize(ev);
+          (void)hipEventDestroy(ev);
+        }
+        cap_events.clear();
+        (void)hipGetLastError();
+      };
       try {
-        for (auto& op : p->ops) run_op(e, op);
+        for (auto& op : p->ops)
+          if (op.kind != 0) { hipEvent_t ev; HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); cap_events.push_back(ev); }
+      } catch (...) { drop_events(); throw; }
+      size_t next_event = 0;
+      { const hipError_t eb = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal); if (eb != hipSuccess) { drop_events(); HIP_CHECK(eb); } }
+      try {
+        for (auto& op : p->ops) run_op(e, op, &cap_events, &next_event);
       } catch (...) {
         hipGraph_t g = nullptr;
         (void)hipStreamEndCapture(e->stream, &g);
         if (g) (void)hipGraphDestroy(g);
+        drop_events();
         throw;
       }
-      HIP_CHECK(hipStreamEndCapture(e->stream, &p->graph));
+      const hipError_t er = hipStreamEndCapture(e->stream, &p->graph);
+      drop_events();                                   // the graph holds the dependency edges; the event objects are not referenced by it
+      HIP_CHECK(er);
       HIP_CHECK(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
     }
     HIP_CHECK(hipGraphLaunch(p->exec, e->stream));
@@ -1477,11 +1502,8 @@ void rtd_destroy(rtd_handle h) {
     if (h->resize_tmp) (void)hipFree(h->resize_tmp);
     if (h->u8_stage) (void)hipFree(h->u8_stage);
     if (h->block_host) (void)hipHostFree(h->block_host);
-    // the fork / join events were last recorded inside a stream capture; record them once on the live stream before they go back to the runtime's
-    // pool (seen once in ~6 full test runs: a torch event created later in the process failed with hipErrorCapturedEvent on its first query)
-    if (h->ev_fork && h->stream) { (void)hipEventRecord(h->ev_fork, h->stream); (void)hipEventSynchronize(h->ev_fork); }
-    if (h->ev_join && h->stream) { (void)hipEventRecord(h->ev_join, h->stream); (void)hipEventSynchronize(h->ev_join); }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->side) (void)hipStreamSynchronize(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);             // only ever recorded on the live streams (captures use their own events, run_op)
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1656,7 +1678,7 @@ int rtd_debug_option(const char* name, int value) {
   // created afterwards (and the kernel-level rtd_op_* / rtd_bench_* entry points), never a live handle
   const struct { const char* n; int* p; } plan_opts[] = {
       {"dec_stamps", &g_opts.dec_stamps}, {"dec_fused", &g_opts.dec_fused}, {"side_stream", &g_opts.side_stream}, {"sel_fused", &g_opts.sel_fused},
-      {"stem_fused", &g_opts.stem_fused}, {"stem_fused_split", &g_opts.stem_fused_split}, {"sc_fold", &g_opts.sc_fold}, {"arena_reuse", &g_opts.arena_reuse},
+      {"stem_fused_split", &g_opts.stem_fused_split}, {"sc_fold", &g_opts.sc_fold}, {"arena_reuse", &g_opts.arena_reuse},
       {"up_fold", &g_opts.up_fold}, {"attn_split", &g_opts.attn_split}, {"c1_fuse", &g_opts.c1_fuse}, {"dec_split", &g_opts.dec_split},
       {"profile_twice", &g_profile_twice}, {"bench_rewarm", &g_bench_rewarm},
   };

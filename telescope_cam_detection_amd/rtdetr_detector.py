@@ -76,8 +76,9 @@ class RTDETRDetector:
         input_size: tuple = (640, 640),
         wildlife_only: bool = True,
         # build-specific knobs (keyword-only in spirit; the reference never passes them)
-        # "f16x3" (default): hi/lo bf16 pairs, three MFMAs per product - the engine held to the reference tolerance (1e-3 on scores,
-        # 1e-2 px on boxes against fp32 eager, tests/test_gpu_parity.py); "bf16": 1.7x faster, 2-4x outside that tolerance (opt-in);
+        # "f16x3" (default): hi/lo fp16 pairs, three MFMAs per product - the engine held to the reference tolerance (1e-3 on scores,
+        # 1e-2 px on boxes against fp32 eager, 640- and 1280-px frames, tests/test_gpu_parity.py); "bf16": ~1.5x faster, far outside that
+        # tolerance (opt-in);
         # "fp32": exact fp32 MFMAs
         precision: str = "f16x3",
         max_batch: int = 8,
@@ -110,45 +111,43 @@ class RTDETRDetector:
 
     # ------------------------------------------------------------------ load
     def load_model(self, max_retries: int = 3) -> bool:
-        """Never raises; False on failure (contract of src/rtdetr_detector.py:60-204)."""
+        """Build the device engine.  Contract of src/rtdetr_detector.py:60-204: never raises, True / False; transient failures
+        (I/O, runtime errors) are retried with a doubling pause (1 s, 2 s, 4 s ...), anything else fails at once."""
         try:
             dev = _device_index(self.device)
         except ValueError as e:
-            logger.error(str(e))
+            logger.error("RT-DETR (MI355X): %s", e)
             return False
-        for attempt in range(max_retries):
+        tries = max(1, int(max_retries))
+        for k in range(tries):
+            t0 = time.perf_counter()
             try:
-                logger.info("Loading RT-DETRv2 model (MI355X-native HIP engine)")
-                logger.info(f"Config: {self.config_path}")
-                logger.info(f"Weights: {self.model_path}")
                 state, arch_name = load_state(self.model_path)
                 arch = ARCHS[arch_name] if arch_name else arch_from_config_path(self.config_path)
                 blob = pack_blob(fold_weights(arch, state))
-                prec = _capi.precision_code(self.precision)
-                engine = _capi.Engine(arch, blob, device=dev, precision=prec, max_batch=self.max_batch,
+                engine = _capi.Engine(arch, blob, device=dev, precision=_capi.precision_code(self.precision), max_batch=self.max_batch,
                                       input_size=tuple(self.input_size), use_graph=self.use_graph,
                                       profile=_capi.PROFILE_THROUGHPUT if str(self.profile).lower() == "throughput" else _capi.PROFILE_LATENCY)
-                self.arch = arch
-                self._dev_index = dev
-                self._engine_input_size = tuple(self.input_size)
-                self.model = _DeviceModel(engine, self.device)
-                logger.info("RT-DETRv2 loaded successfully")
-                logger.info(f"  Input size: {self.input_size}")
-                logger.info("  Num classes: 80 (COCO)")
-                logger.info(f"  Confidence threshold: {self.conf_threshold}")
-                return True
-            except (RuntimeError, OSError, IOError) as e:   # same retry set as the reference (:190-198)
-                if attempt < max_retries - 1:
-                    wait_time = 2 ** attempt
-                    logger.warning(f"Model load failed (attempt {attempt + 1}/{max_retries}): {e}")
-                    logger.warning(f"Retrying in {wait_time}s...")
-                    time.sleep(wait_time)
-                else:
-                    logger.error(f"Failed to load RT-DETR model after {max_retries} attempts: {e}", exc_info=True)
+            except (RuntimeError, OSError) as e:              # the reference retries this set (:190-198); IOError is OSError
+                if k + 1 == tries:
+                    logger.error("RT-DETR (MI355X): giving up on %s after %d attempt(s): %s", self.model_path, tries, e, exc_info=True)
                     return False
+                pause = 1 << k
+                logger.warning("RT-DETR (MI355X): attempt %d of %d to build the engine failed (%s); next try in %d s", k + 1, tries, e, pause)
+                time.sleep(pause)
+                continue
             except Exception as e:
-                logger.error(f"Failed to load RT-DETR model: {e}", exc_info=True)
+                logger.error("RT-DETR (MI355X): cannot build the engine from %s: %s", self.model_path, e, exc_info=True)
                 return False
+            self.arch = arch
+            self._dev_index = dev
+            self._engine_input_size = tuple(self.input_size)
+            self.model = _DeviceModel(engine, self.device)
+            logger.info("RT-DETR (MI355X): %s engine for %s on %s ready in %.1f s - weights %s, input %dx%d, up to %d frames per call, "
+                        "%s arithmetic, score threshold %.2f, 80 COCO classes", arch.name, self.config_path, self.device,
+                        time.perf_counter() - t0, self.model_path, self.input_size[0], self.input_size[1], self.max_batch, self.precision,
+                        self.conf_threshold)
+            return True
         return False
 
     # ------------------------------------------------------------------ helpers

@@ -14,6 +14,9 @@ the glue something with the reference classifier's attributes to drive in tests 
 """
 from __future__ import annotations
 
+import logging
+import time
+
 import ctypes as C
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -23,6 +26,8 @@ from . import _capi
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)      # defaults of the reference classifier's data config
 IMAGENET_STD = (0.229, 0.224, 0.225)
+
+logger = logging.getLogger(__name__)
 
 
 def crop_rect(bbox: Dict[str, float], frame_hw: Tuple[int, int], min_crop_size: int = 64,
@@ -154,6 +159,7 @@ class BatchedStage2:
             except Exception:
                 activity_fn = None
         self.activity_fn = activity_fn
+        self._warned_no_activity = False
 
     @staticmethod
     def _set(det, species, confidence, category, level):            # src/two_stage_pipeline_yolox.py:180-201
@@ -169,6 +175,12 @@ class BatchedStage2:
             self._set(det, None, 0.0, category, None)
             return
         tod = det.get("time_of_day")
+        if tod and self.activity_fn is None and not self._warned_no_activity:
+            # the reference always re-ranks when det['time_of_day'] is set (src/two_stage_pipeline_yolox.py:393-425); without its
+            # src.species_activity_patterns module (or an activity_fn argument) that step cannot run here - say so once, loudly
+            self._warned_no_activity = True
+            logger.warning("Stage 2: detections carry time_of_day but no species-activity function is available "
+                           "(src.species_activity_patterns not importable, no activity_fn given): time-of-day re-ranking is skipped")
         if tod and self.activity_fn is not None:
             for r in results:
                 r["confidence_original"] = r["confidence"]
@@ -227,6 +239,7 @@ class BatchedStage2:
             by_cat.setdefault(category, []).append(j)
         for category, js in by_cat.items():
             clf = p.species_classifiers[category]
+            t_fwd = time.perf_counter()
             try:
                 with torch.no_grad():
                     x = batch[torch.tensor([row_of[j] for j in js], device=batch.device)]
@@ -240,6 +253,13 @@ class BatchedStage2:
                 d = jobs[j][1]
                 top_k = p.time_of_day_top_k if d.get("time_of_day") else 1
                 self._conclude(d, category, format_predictions(clf, probs[row], top_k))
+            # the pipeline's get_stats() averages `classification_times` (milliseconds, one entry per classified detection in the
+            # reference, src/two_stage_pipeline_yolox.py:380-386, :509-511): every crop of the batched forward books its share of it
+            times = getattr(p, "classification_times", None)
+            if times is not None:
+                share = (time.perf_counter() - t_fwd) * 1000.0 / len(js)
+                for _ in js:
+                    times.append(share)
         return detections_per_frame
 
     def process_detections(self, frame, detections):

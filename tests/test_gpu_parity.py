@@ -600,37 +600,6 @@ def test_mixed_frame_sizes_go_through_the_resampler_like_the_oracle(shapes):
     eng.close()
 
 
-def test_fused_uint8_stem_matches_the_generic_preprocess_plus_conv():
-    """rtd_debug_option("stem_fused", 1): backbone.stem.0 reads the uint8 frames itself (identity-sized frames in place, others
-    through the uint8 resampler).  Same arithmetic per element, other summation order: detections agree to bf16 noise, and the
-    on-demand "input" tensor is the stand-alone preprocess of the same frames."""
-    from telescope_cam_detection_amd import _capi
-    from telescope_cam_detection_amd.arch import ARCHS
-    from telescope_cam_detection_amd.synth import scene_frame
-    from telescope_cam_detection_amd.weights import fold_weights, pack_blob, synth_weights
-
-    arch = ARCHS["r18"]
-    w = synth_weights(arch, 3)
-    blob = pack_blob(fold_weights(arch, w))
-    frames = [scene_frame(70, 640, 640), scene_frame(71, 480, 600), scene_frame(72, 640, 640)]
-    out = {}
-    try:
-        for fused in (0, 1):
-            _capi.debug_option("stem_fused", fused)
-            eng = _capi.Engine(arch, blob, 0, _capi.PREC_BF16, 3, (640, 640), True)
-            for _ in range(2):
-                out[fused] = eng.infer_raw(frames)
-            out[("input", fused)] = eng.debug_tensor("input")[:, :, :, :3]
-            eng.close()
-    finally:
-        _capi.debug_option("stem_fused", 0)
-    np.testing.assert_array_equal(out[("input", 0)], out[("input", 1)])
-    for b in range(len(frames)):
-        m, n, ws, wb = match_detections(out[0][0][b], out[0][1][b], out[0][2][b], out[1][0][b], out[1][1][b], out[1][2][b], 2e-2, 2.0)
-        print(f"fused stem vs generic [{b}]: matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
-        assert m >= n - 8, (b, m, n, ws, wb)                                     # measured: <= 5 of 300 miss (the resized frame)
-
-
 def test_f16x3_fused_uint8_stem_matches_the_generic_stem():
     """f16x3: backbone.stem.0 straight from the uint8 frames (default, hi/lo pairs made on the fly) against the generic form (fp32
     NHWC-8 image + exact fp32-MFMA conv): same detections at the north-star tolerance; the first stage output agrees to split rounding."""
@@ -796,3 +765,27 @@ def test_device_frames_are_ordered_after_the_stream_that_produced_them():
         t = det.detect_batch_async([view])
         assert det.detect_batch_collect(t) == [want]
         del filler
+
+
+def test_no_captured_event_state_leaks_to_later_events_of_the_process():
+    """the fork / join markers of a side-stream plan record capture-only events (created for the capture, destroyed after
+    hipStreamEndCapture); the handle's long-lived events are only ever recorded on live streams.  After an engine with forked plans was
+    captured, replayed and closed, events created by anyone else in the process (here: torch) must record and query cleanly."""
+    from telescope_cam_detection_amd import _capi
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.synth import scene_frame
+    arch = ARCHS["tinyc"]
+    w = weights_for(arch, 3)
+    frames = [scene_frame(40, 160, 224), scene_frame(41, 160, 224)]
+    _capi.debug_option("side_stream", 3)
+    for _ in range(3):
+        eng = make_engine(arch, w, frames, (160, 224), "f16x3", use_graph=True)
+        for n in (2, 1, 2):                                    # two plans captured, then a replay
+            eng.infer_raw(frames[:n])
+        eng.close()
+        evs = [torch.cuda.Event(enable_timing=(i % 2 == 0)) for i in range(64)]
+        for ev in evs:
+            ev.record()
+        torch.cuda.synchronize()
+        assert all(ev.query() for ev in evs)
+        assert evs[0].elapsed_time(evs[2]) >= 0.0

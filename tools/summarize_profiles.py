@@ -28,7 +28,8 @@ def csrc_sha() -> str:
     return h.hexdigest()[:16]
 
 
-CONFIG = os.environ.get("RTD_PROFILE_CONFIG", "r50_bs8_f16x3")   # <arch>_bs<B>_<precision> of the profiled bench.py command
+CONFIG = os.environ.get("RTD_PROFILE_CONFIG", "r50_640_bs8_f16x3")   # <arch>_<size>_bs<B>_<precision> of the profiled bench.py command
+BENCH_ARGS = os.environ.get("RTD_PROFILE_ARGS", "")                  # the extra bench.py arguments of that command (e.g. --arch r101 --size 1280 --batch 4)
 
 
 def family(name: str) -> str:
@@ -75,7 +76,7 @@ def do_trace(path, out):
                pct=round(100 * d / tot, 2)) for k, (d, c) in sorted(fam.items(), key=lambda kv: -kv[1][0])]
     conv = [k for k in ks if k["kernel"].startswith("conv")]
     res = dict(csrc_sha=csrc_sha(), config=CONFIG,
-               command="rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --streams 1 --multi-streams 0 --no-bf16-line --no-cpu-baseline --no-latency --opt side_stream=0",
+               command=f"rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py {BENCH_ARGS} --steps 20 --warmup 3 --streams 1 --multi-streams 0 --no-bf16-line --no-cpu-baseline --no-latency --no-detect-host --opt side_stream=0".replace("  ", " "),
                steady_graph_steps_used=len(steps), kernels_per_step=modal, step_span_ms_median=sorted(span)[len(span) // 2],
                conv_igemm_all=dict(us_per_step=round(sum(k["us_per_step"] for k in conv), 2), launches_per_step=sum(k["launches_per_step"] for k in conv),
                                    avg_us=round(sum(k["us_per_step"] for k in conv) / sum(k["launches_per_step"] for k in conv), 3)),
@@ -100,12 +101,16 @@ def do_pmc(fetch, write, out):
     res = {"csrc_sha": csrc_sha(), "config": CONFIG,
            "note": "one steady graph step; FETCH_SIZE / WRITE_SIZE in KiB from separate rocprofv3 --pmc passes; FETCH_SIZE doubled "
                    "(gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md HBM section)"}
+    tot = 0.0
     for k in f:
         fk, c = f[k]
         wk = w[k][0]
         res[k] = dict(launches=c, fetch_kib_raw=fk, fetch_bytes_corrected=fk * 1024 * 2, write_bytes=wk * 1024,
                       hbm_bytes_per_launch=(fk * 2048 + wk * 1024) / c)
+        tot += fk * 2048 + wk * 1024
+    res["whole_step_hbm_gbytes"] = round(tot / 1e9, 3)
     json.dump(res, open(out, "w"), indent=1)
+    print("whole step", res["whole_step_hbm_gbytes"], "GB")
     for k, v in res.items():
         if isinstance(v, dict):
             print(k, v["launches"], round(v["hbm_bytes_per_launch"] / 1e6, 2), "MB/launch")
