@@ -105,6 +105,10 @@ struct ConvOpts {
   int split_sx = 3;               // streaming pair kernel: 0 off, 1 = K = 64 (+ 64) -> 256 (stage 0), 2 = also K = 128 (stage 1), 3 = also K = 256 -> N >= 1024
                                   // without a residual (value projection), 4 = also with a residual from 40^2 maps on (51.5 vs 39.5 us on the tiled kernel: off)
   int split_k2 = 1;               // two-pass split-K on long-K layers with few tiles per image
+  int split_wsq = 1;              // 160..256-pixel tiles at one block per CU (conv_igemm_wsq_kernel) on grids of >= split_wsq_min_blocks 128 x 128 tiles
+                                  // with >= split_wsq_min_nk K-steps (2 = on every grid: tests)
+  int split_wsq_min_blocks = 257;
+  int split_wsq_min_nk = 8;
 };
 ConvOpts& conv_opts_template();
 bool conv_set_option(const char* name, int value);   // edits the template; false = not a conv option

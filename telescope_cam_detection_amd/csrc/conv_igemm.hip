@@ -1162,6 +1162,215 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsf_ker
 
 
 // ------------------------------------------------------------------------------------------------
+// v4q: the F16X2 kernel for grids of MORE than one round of the chip: (MTA + MTB) x 16 pixels x 128 channels per block (160 .. 256 pixels),
+// 2 x 2 wave layout, 3 stages, one block per CU.  The 128 x 128 kernel's K-step keeps LDS exactly as busy as the matrix pipes (16 fragment
+// reads per 48 MFMAs and wave + 32 KiB of DMA writes: 768 cycles each) and its grids quantize badly (800 tiles on 512
+// slots).  Here an MFMA wave owns MT x 4 accumulator tiles (MT = MTA for the upper row half, MTB for the lower; 64 channels): 2 MT + 8
+// fragment reads per 12 MT MFMAs (7 x 4: 22 reads per 84 MFMAs, 3.8 MFMAs per read instead of 3), one filter tile staged per 256 instead
+// of 128 pixels, 12 instead of 16 DMA instructions per loader wave and 1536 MFMA cycles, and the host picks MTA + MTB so that the grid is
+// close to whole rounds of 256 blocks (launch_conv_split: 224 x 128 for 80^2 x 8 x 256 channels = 458 blocks, 160 x 128 for 512 channels
+// = 1280 blocks = 5 rounds).  The pixel fragments of tile j + 1 are read under the MFMAs of tile j.  Loader role, LDS image, swizzle,
+// barrier protocol, K walk and the order of the three products are conv_igemm_wsx_kernel's: an output's arithmetic does not depend on which
+// of the tile kernels ran it (bit-identical results, tested).
+template <int MTA, int MTB, bool STAMP = false>   // STAMP: the diagnostic build (tools/conv_bench.py with glds_drop = 32 and RTD_CONV_STAMPS=2), never dispatched by a plan
+__global__ __launch_bounds__(512, 2) void conv_igemm_wsq_kernel(const ConvG g) {
+  const ConvK& a = g.k;
+  constexpr int BN = 128, STAGES = 3;
+  constexpr int BM = (MTA + MTB) * 16;
+  constexpr int AROWS = (BM + 31) / 32 * 32;
+  constexpr int NAI = AROWS / 32, NBI = BN / 32;
+  constexpr int PPT = NAI + NBI;
+  constexpr int MTX = MTA > MTB ? MTA : MTB;
+  constexpr int CH8 = BN / 8, RSTEP = 512 / CH8, CITERS = (BM + RSTEP - 1) / RSTEP;
+  constexpr int BK = 64;
+  constexpr int STAGE = (AROWS + BN) * 128;
+  constexpr int SLD = BN + 4, SLB = 2 * BN + 8;
+  constexpr int EPI = (BM * SLD * 4 > BM * SLB * 2) ? BM * SLD * 4 : BM * SLB * 2;
+  constexpr int SMEM = (STAGES * STAGE > EPI) ? STAGES * STAGE : EPI;
+  constexpr int AHEAD = STAGES - 1;
+  static_assert(MTA >= MTB && MTB >= 1 && MTA <= 8, "row split");
+  static_assert(SMEM + 256 <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) char smem[SMEM + 256];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wv >= 4;
+  const int w4 = wv & 3;
+  const int wm = w4 & 1, wn = w4 >> 1;
+  int wg;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = wg % a.ntn, mt = wg / a.ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int nk = a.Kpad / BK;
+  long long* stamps = (STAMP && g.slab && blockIdx.x < 4096 && lane == 0) ? (long long*)g.slab + (size_t)blockIdx.x * 8 : nullptr;
+  const long long t_base = STAMP ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  if (STAMP && stamps && wv == 0) stamps[6] = (long long)__builtin_amdgcn_s_memrealtime();
+
+  f32x4 acc[4][MTX];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < MTX; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!loader) prefetch_share(a, blockIdx.x, gridDim.x, tid, 256, smem + SMEM);
+
+  if (loader) {
+    const int lrow = w4 * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((w4 * 4 + (lane >> 4)) & 7);
+    int a_off[NAI], a_iy0[NAI], a_ix0[NAI], b_off[NBI];
+    unsigned a2_off[8];   // fixed extent (see conv_igemm_wsf_kernel)
+    static_assert(NAI <= 8, "a2_off");
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) {
+      const int row = i * 32 + lrow;
+      const int m = m0 + row;
+      a2_off[i] = 0x80000000u;
+      if (m < a.M && row < BM) {
+        const int b = m / a.OHW;
+        const int r = m - b * a.OHW;
+        const int oy = r / a.OW;
+        const int ox = r - oy * a.OW;
+        a_iy0[i] = oy * a.stride - a.pad;
+        a_ix0[i] = ox * a.stride - a.pad;
+        a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)a_iy0[i] * a.W + a_ix0[i]) * a.ldx) * 2) + chunk * 16;
+        if (a.x_up2) a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)(oy >> 1) * (a.W >> 1) + (ox >> 1)) * a.ldx) * 2) + chunk * 16;
+        if (a.x2) a2_off[i] = (unsigned)(((long long)b * a.x2_bstride + (long long)r * a.ldx2) * 2) + chunk * 16;
+      } else {
+        a_iy0[i] = -(1 << 28);
+        a_ix0[i] = -(1 << 28);
+        a_off[i] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) b_off[i] = (n0 + i * 32 + lrow) * a.Kpad * 2 + chunk * 16;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x), 0, a.x2 ? g.x2_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
+    // K order: channel group outer, taps inner (conv_igemm_wsx_kernel)
+    const int nk_main = a.x2 ? a.k2_start / BK : nk;
+    int ksi = 0, kh = 0, kw = 0, c0 = 0;
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+      if (g.probe & 4) return;
+      char* sa = smem + buf * STAGE + w4 * 1024;
+      int kf;
+      if (ksi >= nk_main) {
+        const int d2 = (ksi - nk_main) * BK * 2;
+        kf = a.k2_start + (ksi - nk_main) * BK;
+#pragma unroll
+        for (int i = 0; i < NAI; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, (lds_ptr_t)(sa + i * 4096), 16, a2_off[i] + ((a2_off[i] >> 31) ? 0u : (unsigned)d2), 0, 0, 0);
+      } else {
+        const int delta = ((kh * a.W + kw) * (int)a.ldx + c0) * 2;
+        kf = (kh * a.KW + kw) * a.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < NAI; ++i) {
+          const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+          const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+          const unsigned vo = ok ? (unsigned)(a_off[i] + delta) : 0x80000000u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 4096), 16, vo, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NBI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sa + AROWS * 128 + i * 4096), 16, (unsigned)(b_off[i] + kf * 2), 0, 0, 0);
+      ++ksi;
+      if (++kw == a.KW) {
+        kw = 0;
+        if (++kh == a.KH) { kh = 0; c0 += BK; }
+      }
+    };
+    for (int t = 0; t < AHEAD && t < nk; ++t) issue(t);
+    for (int ks = 0; ks < nk; ++ks) {
+      if (nk - 1 - ks >= 1) wait_vmcnt<PPT>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (ks + AHEAD < nk) issue((ks + AHEAD) % STAGES);
+    }
+  } else {
+    const int r16 = lane & 15, c4 = lane >> 4;
+    const int sw = (r16 >> 1) & 7;
+    const int foh = r16 * 128 + ((c4 ^ sw) << 4), fol = r16 * 128 + (((c4 + 4) ^ sw) << 4);
+    // the wave's row half: MT tiles from row `rb` (wave-uniform branch; each body has a compile-time tile count)
+    auto body = [&](auto mtc, const int rb) __attribute__((always_inline)) {
+      constexpr int MT = decltype(mtc)::value;
+      for (int ks = 0; ks < nk; ++ks) {
+        __builtin_amdgcn_s_barrier();
+        if (STAMP && stamps && wv == 0 && ks == 0) stamps[0] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+        const char* sa = smem + (ks % STAGES) * STAGE + rb * 128;
+        const char* sb = smem + (ks % STAGES) * STAGE + (AROWS + wn * 64) * 128;
+        sp16x8 wh[4], wl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { wh[i] = *(const sp16x8*)(sb + i * 2048 + foh); wl[i] = *(const sp16x8*)(sb + i * 2048 + fol); }
+        sp16x8 xh[2], xl[2];
+        xh[0] = *(const sp16x8*)(sa + foh); xl[0] = *(const sp16x8*)(sa + fol);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          if (j + 1 < MT) { xh[(j + 1) & 1] = *(const sp16x8*)(sa + (j + 1) * 2048 + foh); xl[(j + 1) & 1] = *(const sp16x8*)(sa + (j + 1) * 2048 + fol); }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[i][j] = mfma_pair16(wh[i], xh[j & 1], acc[i][j]);
+            acc[i][j] = mfma_pair16(wh[i], xl[j & 1], acc[i][j]);
+            acc[i][j] = mfma_pair16(wl[i], xh[j & 1], acc[i][j]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    if (wm == 0) body(ActC<MTA>{}, 0);              // (ActC: a compile-time int)
+    else body(ActC<MTB>{}, MTA * 16);
+  }
+  if (STAMP && stamps && wv == 0) stamps[1] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+  __syncthreads();
+
+  auto for_each_group = [&](auto&& f) {
+    const int r16 = lane & 15, c4 = lane >> 4;
+    const int rb = wm ? MTA * 16 : 0, mtw = wm ? MTB : MTA;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < MTX; ++j)
+        if (j < mtw) f(wn * 64 + 16 * i + 4 * c4, rb + 16 * j + r16, acc[i][j]);
+  };
+  if (a.y_split && a.res_mode == RES_NONE) {
+    sp16* sb = (sp16*)smem;
+    if (!loader) {
+      dispatch_act(a.act, [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
+        for_each_group([&](int cl, int pl, const f32x4& v) {
+          const f32x4 bv = *(const f32x4*)(a.bias + n0 + cl);
+          sp16x4 oh, ol;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sp16 hi, lo; split2(act_c<ACT>(v[e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
+          sp16* d = sb + pl * SLB + ((cl >> 5) << 6) + (cl & 31);
+          *(sp16x4*)d = oh;
+          *(sp16x4*)(d + SPLIT_GROUP) = ol;
+        });
+      });
+    }
+    __syncthreads();
+    if (STAMP && stamps && wv == 0) stamps[2] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+    ws_copy_out_split_rows<BN, BM>(a, sb, SLB, tid, m0, n0);
+    if (STAMP && stamps && wv == 0) {
+      stamps[3] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamps[4] = (long long)__builtin_amdgcn_s_memtime() - t_base;
+      stamps[7] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+    return;
+  }
+  float* st = (float*)smem;
+  if (!loader) for_each_group([&](int cl, int pl, const f32x4& v) { *(f32x4*)(&st[pl * SLD + cl]) = v; });
+  __syncthreads();
+  dispatch_act(a.act, [&](auto actc) { ws_copy_out_sp<CITERS, decltype(actc)::value, BN, BM>(a, st, SLD, tid, m0, n0, 0); });
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // v4b: the wave-specialised kernel on a 256 pixel x 128 channel tile, 3 stages.  Each MFMA wave owns 128 x 64 outputs
 // (4 x 2 MFMA tiles): per 16-deep k slice it reads 4 + 2 fragments for 8 MFMAs (0.75 KiB of LDS per MFMA instead of 1 KiB),
 // and a K-step stages 48 KiB for twice the MACs (24 KiB per 128 x 128 x 64 unit instead of 32).  The 128 x 128 kernel's K-step
@@ -1552,7 +1761,8 @@ bool conv_set_option(const char* name, int value) {
       {"stream2", &o.stream2}, {"stream2_max_n", &o.stream2_max_n}, {"stream_slab", &o.stream_slab}, {"prefetch", &o.prefetch},
       {"glds_drop", &o.glds_drop}, {"split_ws2_min_blocks", &o.split_ws2_min_blocks}, {"split_ws64_max_blocks", &o.split_ws64_max_blocks},
       {"split_flex", &o.split_flex}, {"split_flex_min_nk", &o.split_flex_min_nk}, {"split_flex_small_max", &o.split_flex_small_max},
-      {"split_sx", &o.split_sx}, {"split_k2", &o.split_k2},
+      {"split_sx", &o.split_sx}, {"split_k2", &o.split_k2}, {"split_wsq", &o.split_wsq}, {"split_wsq_min_blocks", &o.split_wsq_min_blocks},
+      {"split_wsq_min_nk", &o.split_wsq_min_nk},
   };
   for (const auto& t : table)
     if (strcmp(name, t.n) == 0) { *t.p = value; return true; }
@@ -3141,6 +3351,43 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
 #undef RTD_WSF
     if (launched) { finish(); return; }
     k.ntn = 1;
+  }
+  // ---- grids of more than one round: (MTA + MTB) x 16 pixel tiles, one block per CU (conv_igemm_wsq_kernel).  The tile height minimises
+  // rounds x (K loop of the taller wave half + epilogue), in MFMA-pipe cycles
+  if (o.split_wsq && S == 1 && k.N > 64 && k.Kpad / 64 >= o.split_wsq_min_nk && (o.split_wsq == 2 || mt * ntn >= o.split_wsq_min_blocks)) {
+    static const int cand[7][2] = {{5, 5}, {6, 5}, {6, 6}, {7, 6}, {7, 7}, {8, 7}, {8, 8}};
+    const long long nk = k.Kpad / 64;
+    int best = -1;
+    double best_cost = 1e30;
+    for (int c = 0; c < 7; ++c) {
+      const int bm = 16 * (cand[c][0] + cand[c][1]);
+      const long long blocks = ((k.M + bm - 1) / bm) * ntn;
+      const double cost = (double)((blocks + 255) / 256) * ((double)nk * cand[c][0] * 192.0 + 1500.0 + 10.0 * bm);
+      if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    const bool stamped = (o.glds_drop & 32) && a.ws.slab && a.ws.slab_bytes >= (size_t)4096 * 64;
+    if (stamped && best != 6) best = 4;                        // the diagnostic build exists for 7 + 7 and 8 + 8 tiles only
+    const int bm = 16 * (cand[best][0] + cand[best][1]);
+    k.ntn = (int)ntn;
+    const dim3 grid((unsigned)(((k.M + bm - 1) / bm) * ntn)), blk(512);
+    if (stamped) {     // diagnostic build: block stamps
+      g.slab = a.ws.slab;
+      if (best == 4) hipLaunchKernelGGL((conv_igemm_wsq_kernel<7, 7, true>), grid, blk, 0, s, g);
+      else hipLaunchKernelGGL((conv_igemm_wsq_kernel<8, 8, true>), grid, blk, 0, s, g);
+      finish();
+      return;
+    }
+    switch (best) {
+      case 0: hipLaunchKernelGGL((conv_igemm_wsq_kernel<5, 5>), grid, blk, 0, s, g); break;
+      case 1: hipLaunchKernelGGL((conv_igemm_wsq_kernel<6, 5>), grid, blk, 0, s, g); break;
+      case 2: hipLaunchKernelGGL((conv_igemm_wsq_kernel<6, 6>), grid, blk, 0, s, g); break;
+      case 3: hipLaunchKernelGGL((conv_igemm_wsq_kernel<7, 6>), grid, blk, 0, s, g); break;
+      case 4: hipLaunchKernelGGL((conv_igemm_wsq_kernel<7, 7>), grid, blk, 0, s, g); break;
+      case 5: hipLaunchKernelGGL((conv_igemm_wsq_kernel<8, 7>), grid, blk, 0, s, g); break;
+      default: hipLaunchKernelGGL((conv_igemm_wsq_kernel<8, 8>), grid, blk, 0, s, g); break;
+    }
+    finish();
+    return;
   }
   // ---- fixed 128 x 128 / 128 x 64 tiles (conv_igemm_wsx_kernel): 4 stages at one block per CU below split_ws2_min_blocks blocks, 2 stages from there
   const bool n64 = k.N <= 64 || (mt * ntn < o.split_ws64_max_blocks && ntn64 > ntn);

@@ -1665,6 +1665,17 @@ __global__ void k_touch_read(const unsigned* p, size_t lines, unsigned* sink) {
   for (size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x; l < lines; l += (size_t)gridDim.x * blockDim.x) acc += p[l * 32];
   if (acc == 0x12345u) *sink = acc;
 }
+// bench only: finite fp16 values of mixed sign, exponents 2^-5 .. 2^2, random mantissas (matrix-core power depends on the operand bits:
+// zero-filled operands let the chip hold a clock that real activations do not)
+__global__ void k_fill_rand16(uint16_t* p, size_t n, unsigned seed) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    unsigned h = (unsigned)i * 2654435761u + seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = (uint16_t)((h & 0x8000u) | ((10u + ((h >> 16) & 7u)) << 10) | (h & 0x3ffu));
+  }
+}
 static int g_bench_rewarm = 0;   // "bench_rewarm": rtd_bench_conv rewrites 1 = activations, 2 = weights after its flush (back into the Infinity Cache)
 int rtd_debug_option(const char* name, int value) {
   if (!name) return RTD_E_INVALID;
@@ -1777,6 +1788,12 @@ int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, in
     HIP_CHECK(hipMalloc(&x, xb)); HIP_CHECK(hipMalloc(&y, yb)); HIP_CHECK(hipMalloc(&w, wb)); HIP_CHECK(hipMalloc((void**)&bias, Npad * 4));
     HIP_CHECK(hipMemset(x, 0, xb)); HIP_CHECK(hipMemset(w, 0, wb)); HIP_CHECK(hipMemset(bias, 0, Npad * 4));
     if (with_res) { HIP_CHECK(hipMalloc(&r, yb)); HIP_CHECK(hipMemset(r, 0, yb)); }
+    if ((g_bench_rewarm & 32) && dtype != F32) {                 // "bench_rewarm" bit 5: random 16-bit operands instead of zeros
+      hipLaunchKernelGGL(k_fill_rand16, dim3(1024), dim3(256), 0, nullptr, (uint16_t*)x, xb / 2, 1u);
+      hipLaunchKernelGGL(k_fill_rand16, dim3(1024), dim3(256), 0, nullptr, (uint16_t*)w, wb / 2, 2u);
+      if (r) hipLaunchKernelGGL(k_fill_rand16, dim3(1024), dim3(256), 0, nullptr, (uint16_t*)r, yb / 2, 3u);
+      HIP_CHECK(hipDeviceSynchronize());
+    }
     if (flush_mb > 0) HIP_CHECK(hipMalloc(&flush, (size_t)flush_mb << 20));
     ConvArgs a;
     a.x = mk(x, dtype, B, H, W, Cin);
@@ -1846,6 +1863,11 @@ int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, in
       }
       fprintf(stderr, "ws blocks stamped %d: mean clocks: first tile landed %.0f | K loop %.0f | staging %.0f | copy-out %.0f | store ack %.0f ; kernel wall %.2f us\n",
               cnt, s_land / cnt, s_k / cnt, s_stage / cnt, s_copy / cnt, s_ack / cnt, (tend - t0) * 0.01);
+      {   // the core clock the blocks ran at: shader clocks (s_memtime) per 100 MHz tick (s_memrealtime) over a block's life
+        double clk = 0; int c2 = 0;
+        for (int i = 0; i < nb; ++i) { const long long* q = &st[(size_t)i * 8]; if (q[6] && q[7] > q[6]) { clk += (double)q[4] / ((double)(q[7] - q[6]) * 10.0); ++c2; } }
+        if (c2) fprintf(stderr, "  in-kernel core clock %.3f GHz (mean over %d blocks)\n", clk / c2, c2);
+      }
       for (int i : {0, 1, 600, 1500, 3000}) {
         const long long* q = &st[(size_t)i * 8];
         if (q[6]) fprintf(stderr, "  block %4d: start %+8.2f us  landed %6lld  kdone %6lld  staged %6lld  stored %6lld  acked %6lld  life %.2f us\n", i,

@@ -338,14 +338,22 @@ def test_conv_split_f16x3(L, case):
         yd = torch.full((B, OH, OW, 2 * Cout), -1, dtype=torch.int16, device="cuda")
     # dispatch variants: "auto" = the default; "flex" = flexible-height tiles (conv_igemm_wsf_kernel) on every grid and K length;
     # "tiled" = only the fixed-tile kernel (no streaming / direct 3x3 / flexible kernels) with 2-stage 128-wide or 4-stage 64-wide tiles everywhere
-    for ws2, ws64, kern in ((257, 160, "auto"), (257, 160, "flex"), (1, 0, "tiled"), (1 << 30, 1 << 30, "tiled")):
+    # "quad" = the 160..256-pixel one-block-per-CU kernel (conv_igemm_wsq_kernel) wherever its shape rules allow (Cout > 64), else the tiled kernel
+    tiled_bits = None
+    for ws2, ws64, kern in ((257, 160, "auto"), (257, 160, "flex"), (1, 0, "tiled"), (1 << 30, 1 << 30, "tiled"), (1, 0, "quad")):
         _capi.debug_option("reset", 0)
         _capi.debug_option("split_ws2_min_blocks", ws2)
         _capi.debug_option("split_ws64_max_blocks", ws64)
-        if kern == "tiled":
+        if kern != "quad":
+            _capi.debug_option("split_wsq", 1 if kern == "auto" else 0)
+        if kern in ("tiled", "quad"):
             _capi.debug_option("split_flex", 0)
             _capi.debug_option("split_sx", 0)        # the tiled kernel on the streaming kernel's shapes too
             _capi.debug_option("conv_reg", 0)        # ... and on the direct 3x3 kernels'
+        if kern == "quad":
+            _capi.debug_option("split_wsq", 2)
+            _capi.debug_option("split_wsq_min_nk", 1)
+            _capi.debug_option("split_k2", 0)
         if kern == "flex":
             _capi.debug_option("split_flex_small_max", 1 << 30)
             _capi.debug_option("split_flex_min_nk", 1)
@@ -359,6 +367,15 @@ def test_conv_split_f16x3(L, case):
         rel = (torch.linalg.norm(got - y) / torch.linalg.norm(y)).item()
         print(f"split conv {case}: max err / max |y| {err:.2e}, rel l2 {rel:.2e}")
         assert err < 2e-5 and rel < 1e-5, (case, ws2, ws64, kern, err, rel)
+        # the tile kernels walk K in one order and issue the three products in one order: which of them ran a layer does not show in its bits
+        if kern == "tiled" and ws2 == 1:
+            _capi.debug_option("split_k2", 0)
+            ck(L, L.rtd_op_conv(_capi.DT_F16X2, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None,
+                                yd.data_ptr(), B, H, W, Cin, Cout, k, k, stride, pad, {"none": 0, "relu": 1, "silu": 2, "gelu": 3}[act],
+                                res_mode, out_f32))
+            tiled_bits = yd.cpu().numpy().copy()
+        if kern == "quad":
+            np.testing.assert_array_equal(yd.cpu().numpy().view(np.uint32 if out_f32 else np.uint16), tiled_bits.view(np.uint32 if out_f32 else np.uint16))
     _capi.debug_option("reset", 0)
 
 

@@ -55,10 +55,14 @@ def main():
     ap.add_argument("--flush-mb", type=int, default=1024)
     ap.add_argument("--dtype", type=int, default=4, help="0 bf16, 1 fp32, 4 F16X2 (the f16x3 engine's operands)")
     ap.add_argument("--only", default="", help="substring filter on the layer name")
+    ap.add_argument("--set", action="append", default=[], help="name=value: further debug options held fixed (e.g. bench_rewarm=32: random operands)")
     args = ap.parse_args()
     from telescope_cam_detection_amd import _capi
     L = _capi.lib()
     vals = [int(v) for v in args.vals.split(",")]
+    for kv in args.set:
+        n, v = kv.split("=")
+        _capi.debug_option(n, int(v))
     print(f"{'layer':34s} " + "  ".join(f"{args.opt or 'default'}={v}: warm / cold us" for v in vals))
     for name, hw, cin, cout, k, st, pad, res in SHAPES:
         if args.only and args.only not in name:
