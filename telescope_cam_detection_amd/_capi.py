@@ -102,7 +102,12 @@ def lib() -> C.CDLL:
     if _lib is not None:
         return _lib
     path = _build.LIB_PATH
-    if _build.needs_build():
+    override = os.environ.get("RTD_LIB_PATH")   # tools only (tools/ab_lib.sh): A/B an older build of the library on the same box
+    if override:
+        if not os.path.exists(override):
+            raise RuntimeError(f"RTD_LIB_PATH={override} does not exist")
+        path = override
+    elif _build.needs_build():
         try:
             path = _build.build(verbose=False)
         except Exception as e:  # no hipcc on this box: use the prebuilt library if it is there

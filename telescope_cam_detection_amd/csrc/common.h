@@ -108,7 +108,7 @@ struct ConvOpts {
   int split_wsq = 1;              // 160..256-pixel tiles at one block per CU (conv_igemm_wsq_kernel) on grids of >= split_wsq_min_blocks 128 x 128 tiles
                                   // with >= split_wsq_min_nk K-steps (2 = on every grid: tests)
   int split_wsq_min_blocks = 257;
-  int split_wsq_min_nk = 8;
+  int split_wsq_min_nk = 24;         // same-box A/B (tools/profile_layers.py --ab split_wsq): 3x3 layers 1.05-1.18x, 1x1 layers of 8-16 K-steps 0.80-0.96x
 };
 ConvOpts& conv_opts_template();
 bool conv_set_option(const char* name, int value);   // edits the template; false = not a conv option

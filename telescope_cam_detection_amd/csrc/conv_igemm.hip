@@ -1100,6 +1100,64 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsf_ker
     const int r16 = lane & 15, c4 = lane >> 4;
     const int sw = (r16 >> 1) & 7;
     const int foh = r16 * 128 + ((c4 ^ sw) << 4), fol = r16 * 128 + (((c4 + 4) ^ sw) << 4);
+    if constexpr (STAGES >= 3 && MT >= 2) {
+      // One block per CU (one MFMA wave per SIMD): conv_igemm_wsq_kernel's K-step schedule - the last tile's MFMAs are deferred past the next
+      // barrier and run from registers beside the new step's first fragment reads, never more than one ds_read_b128 per MFMA gap, filter
+      // fragments double-buffered by step parity.  (The 2-stage form runs two blocks per CU inside 128 registers: its waves cover each other.)
+      sp16x8 wh[2][CT], wl[2][CT], xh[2], xl[2], ph, pl;
+#pragma unroll
+      for (int i = 0; i < CT; ++i) { wh[1][i] = sp16x8{0, 0, 0, 0, 0, 0, 0, 0}; wl[1][i] = wh[1][i]; }
+      ph = sp16x8{0, 0, 0, 0, 0, 0, 0, 0}; pl = ph;
+#define RTD_SB() __builtin_amdgcn_sched_barrier(0)
+#define RTD_MF(A, B, C) C = mfma_pair16(A, B, C)
+      auto step = [&](auto parc, const int ks) __attribute__((always_inline)) {
+        constexpr int P = decltype(parc)::value, Q = P ^ 1;
+        __builtin_amdgcn_s_barrier();
+        const char* sa = smem + (ks % STAGES) * STAGE;
+        const char* sb = sa + (AROWS + w4 * (BN / 4)) * 128;
+        wh[P][0] = *(const sp16x8*)(sb + foh); xh[0] = *(const sp16x8*)(sa + foh); RTD_SB();
+        RTD_MF(wh[Q][0], ph, acc[0][MT - 1]);
+        if (CT == 2) { wh[P][1] = *(const sp16x8*)(sb + 2048 + foh); RTD_SB(); RTD_MF(wh[Q][1], ph, acc[1][MT - 1]); }
+        xl[0] = *(const sp16x8*)(sa + fol); RTD_SB();
+        RTD_MF(wh[Q][0], pl, acc[0][MT - 1]); wl[P][0] = *(const sp16x8*)(sb + fol); RTD_SB();
+        if (CT == 2) { RTD_MF(wh[Q][1], pl, acc[1][MT - 1]); wl[P][1] = *(const sp16x8*)(sb + 2048 + fol); RTD_SB(); }
+        RTD_MF(wl[Q][0], ph, acc[0][MT - 1]);
+        if (CT == 2) RTD_MF(wl[Q][1], ph, acc[1][MT - 1]);
+        RTD_SB();
+#pragma unroll
+        for (int j = 0; j < MT - 1; ++j) {
+          RTD_MF(wh[P][0], xh[j & 1], acc[0][j]); xh[(j + 1) & 1] = *(const sp16x8*)(sa + (j + 1) * 2048 + foh); RTD_SB();
+          if (CT == 2) RTD_MF(wh[P][1], xh[j & 1], acc[1][j]);
+          RTD_MF(wh[P][0], xl[j & 1], acc[0][j]); xl[(j + 1) & 1] = *(const sp16x8*)(sa + (j + 1) * 2048 + fol); RTD_SB();
+          if (CT == 2) RTD_MF(wh[P][1], xl[j & 1], acc[1][j]);
+          RTD_MF(wl[P][0], xh[j & 1], acc[0][j]);
+          if (CT == 2) RTD_MF(wl[P][1], xh[j & 1], acc[1][j]);
+          RTD_SB();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // every read of this stage has returned before the next barrier
+        ph = xh[(MT - 1) & 1]; pl = xl[(MT - 1) & 1];
+      };
+      int ks = 0;
+      for (; ks + 1 < nk; ks += 2) { step(ActC<0>{}, ks); step(ActC<1>{}, ks + 1); }
+      if (ks < nk) {
+        step(ActC<0>{}, ks);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) RTD_MF(wh[0][i], ph, acc[i][MT - 1]);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) RTD_MF(wh[0][i], pl, acc[i][MT - 1]);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) RTD_MF(wl[0][i], ph, acc[i][MT - 1]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < CT; ++i) RTD_MF(wh[1][i], ph, acc[i][MT - 1]);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) RTD_MF(wh[1][i], pl, acc[i][MT - 1]);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) RTD_MF(wl[1][i], ph, acc[i][MT - 1]);
+      }
+#undef RTD_SB
+#undef RTD_MF
+    } else {
     for (int ks = 0; ks < nk; ++ks) {
       __builtin_amdgcn_s_barrier();
       const char* sa = smem + (ks % STAGES) * STAGE;
@@ -1123,6 +1181,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsf_ker
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
     }
   }
   __syncthreads();
@@ -1294,32 +1353,70 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wsq_kernel(const ConvG g) {
     const int r16 = lane & 15, c4 = lane >> 4;
     const int sw = (r16 >> 1) & 7;
     const int foh = r16 * 128 + ((c4 ^ sw) << 4), fol = r16 * 128 + (((c4 + 4) ^ sw) << 4);
-    // the wave's row half: MT tiles from row `rb` (wave-uniform branch; each body has a compile-time tile count)
+    // the wave's row half: MT tiles from row `rb` (wave-uniform branch; each body has a compile-time tile count).
+    // Schedule of a K-step (tools/kstep_probe.hip: every ds_read_b128 costs the matrix pipe ~10 cycles wherever it sits, a barrier ~90, and
+    // the round trip of a step's first reads another ~100 when nothing covers it - 1675 cycles for 1344 of MFMA with all ten first reads
+    // up front, 1588 like this): the MFMAs of a step's LAST tile are deferred past the next barrier, where they run from registers one to
+    // one with the new step's first ten fragment reads; the two reads of pixel tile j + 1 follow the first and the fifth MFMA of tile j.
+    // Filter fragments are double-buffered by step parity (two steps per loop trip).  Per accumulator the order of the products is
+    // conv_igemm_wsx_kernel's (hh, hl, lh per K-step); the first step's deferred slot multiplies zeros (+0 onto +0).
     auto body = [&](auto mtc, const int rb) __attribute__((always_inline)) {
       constexpr int MT = decltype(mtc)::value;
-      for (int ks = 0; ks < nk; ++ks) {
+      sp16x8 wh[2][4], wl[2][4];
+      sp16x8 xh[2], xl[2], ph, pl;                               // ph / pl: pixel fragments of the deferred tile
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { wh[1][i] = sp16x8{0, 0, 0, 0, 0, 0, 0, 0}; wl[1][i] = wh[1][i]; }
+      ph = sp16x8{0, 0, 0, 0, 0, 0, 0, 0}; pl = ph;
+#define RTD_SB() __builtin_amdgcn_sched_barrier(0)
+#define RTD_MF(A, B, C) C = mfma_pair16(A, B, C)
+      auto step = [&](auto parc, const int ks) __attribute__((always_inline)) {
+        constexpr int P = decltype(parc)::value, Q = P ^ 1;
         __builtin_amdgcn_s_barrier();
         if (STAMP && stamps && wv == 0 && ks == 0) stamps[0] = (long long)__builtin_amdgcn_s_memtime() - t_base;
         const char* sa = smem + (ks % STAGES) * STAGE + rb * 128;
         const char* sb = smem + (ks % STAGES) * STAGE + (AROWS + wn * 64) * 128;
-        sp16x8 wh[4], wl[4];
+        wh[P][0] = *(const sp16x8*)(sb + foh); xh[0] = *(const sp16x8*)(sa + foh); RTD_SB();
+        RTD_MF(wh[Q][0], ph, acc[0][MT - 1]); wh[P][1] = *(const sp16x8*)(sb + 2048 + foh); RTD_SB();
+        RTD_MF(wh[Q][1], ph, acc[1][MT - 1]); wh[P][2] = *(const sp16x8*)(sb + 4096 + foh); RTD_SB();
+        RTD_MF(wh[Q][2], ph, acc[2][MT - 1]); wh[P][3] = *(const sp16x8*)(sb + 6144 + foh); RTD_SB();
+        RTD_MF(wh[Q][3], ph, acc[3][MT - 1]); xl[0] = *(const sp16x8*)(sa + fol); RTD_SB();
+        RTD_MF(wh[Q][0], pl, acc[0][MT - 1]); wl[P][0] = *(const sp16x8*)(sb + fol); RTD_SB();
+        RTD_MF(wh[Q][1], pl, acc[1][MT - 1]); wl[P][1] = *(const sp16x8*)(sb + 2048 + fol); RTD_SB();
+        RTD_MF(wh[Q][2], pl, acc[2][MT - 1]); wl[P][2] = *(const sp16x8*)(sb + 4096 + fol); RTD_SB();
+        RTD_MF(wh[Q][3], pl, acc[3][MT - 1]); wl[P][3] = *(const sp16x8*)(sb + 6144 + fol); RTD_SB();
+        RTD_MF(wl[Q][0], ph, acc[0][MT - 1]); RTD_MF(wl[Q][1], ph, acc[1][MT - 1]); RTD_MF(wl[Q][2], ph, acc[2][MT - 1]); RTD_MF(wl[Q][3], ph, acc[3][MT - 1]); RTD_SB();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { wh[i] = *(const sp16x8*)(sb + i * 2048 + foh); wl[i] = *(const sp16x8*)(sb + i * 2048 + fol); }
-        sp16x8 xh[2], xl[2];
-        xh[0] = *(const sp16x8*)(sa + foh); xl[0] = *(const sp16x8*)(sa + fol);
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-          if (j + 1 < MT) { xh[(j + 1) & 1] = *(const sp16x8*)(sa + (j + 1) * 2048 + foh); xl[(j + 1) & 1] = *(const sp16x8*)(sa + (j + 1) * 2048 + fol); }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            acc[i][j] = mfma_pair16(wh[i], xh[j & 1], acc[i][j]);
-            acc[i][j] = mfma_pair16(wh[i], xl[j & 1], acc[i][j]);
-            acc[i][j] = mfma_pair16(wl[i], xh[j & 1], acc[i][j]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < MT - 1; ++j) {
+          RTD_MF(wh[P][0], xh[j & 1], acc[0][j]); xh[(j + 1) & 1] = *(const sp16x8*)(sa + (j + 1) * 2048 + foh); RTD_SB();
+          RTD_MF(wh[P][1], xh[j & 1], acc[1][j]); RTD_MF(wh[P][2], xh[j & 1], acc[2][j]); RTD_MF(wh[P][3], xh[j & 1], acc[3][j]); RTD_SB();
+          RTD_MF(wh[P][0], xl[j & 1], acc[0][j]); xl[(j + 1) & 1] = *(const sp16x8*)(sa + (j + 1) * 2048 + fol); RTD_SB();
+          RTD_MF(wh[P][1], xl[j & 1], acc[1][j]); RTD_MF(wh[P][2], xl[j & 1], acc[2][j]); RTD_MF(wh[P][3], xl[j & 1], acc[3][j]); RTD_SB();
+          RTD_MF(wl[P][0], xh[j & 1], acc[0][j]); RTD_MF(wl[P][1], xh[j & 1], acc[1][j]); RTD_MF(wl[P][2], xh[j & 1], acc[2][j]); RTD_MF(wl[P][3], xh[j & 1], acc[3][j]); RTD_SB();
         }
+        // every LDS read of this stage has returned before the wave reaches the next barrier (after it the loaders refill the stage)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ph = xh[(MT - 1) & 1]; pl = xl[(MT - 1) & 1];
+      };
+      int ks = 0;
+      for (; ks + 1 < nk; ks += 2) { step(ActC<0>{}, ks); step(ActC<1>{}, ks + 1); }
+      if (ks < nk) {
+        step(ActC<0>{}, ks);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) RTD_MF(wh[0][i], ph, acc[i][MT - 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) RTD_MF(wh[0][i], pl, acc[i][MT - 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) RTD_MF(wl[0][i], ph, acc[i][MT - 1]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) RTD_MF(wh[1][i], ph, acc[i][MT - 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) RTD_MF(wh[1][i], pl, acc[i][MT - 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) RTD_MF(wl[1][i], ph, acc[i][MT - 1]);
       }
+#undef RTD_SB
+#undef RTD_MF
     };
     if (wm == 0) body(ActC<MTA>{}, 0);              // (ActC: a compile-time int)
     else body(ActC<MTB>{}, MTA * 16);

@@ -76,6 +76,19 @@ int main() {
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
       }
+      if (waves == 4) {
+        // dependent chains: NACC accumulators in rotation (1 = every MFMA waits for the previous one's result)
+        auto chain = [&](auto kern, int nacc) {
+          hipLaunchKernelGGL(kern, dim3(cus), dim3(threads), 0, 0, seed, iters, out, sink);
+          CHECK(hipDeviceSynchronize());
+          std::vector<long long> h2((size_t)cus * waves * 2);
+          CHECK(hipMemcpy(h2.data(), out, h2.size() * 8, hipMemcpyDeviceToHost));
+          double c = 0;
+          for (int w = 0; w < cus * waves; ++w) c += h2[2 * w];
+          printf("  %2d accumulator(s) in rotation: %.1f shader clocks per MFMA\n", nacc, c / (cus * waves) / ((double)iters * nacc));
+        };
+        chain(k_mfma<1>, 1); chain(k_mfma<2>, 2); chain(k_mfma<3>, 3); chain(k_mfma<4>, 4); chain(k_mfma<8>, 8);
+      }
       float ms = 0.f;
       CHECK(hipEventElapsedTime(&ms, e0, e1));
       CHECK(hipMemcpy(ho.data(), out, ho.size() * 8, hipMemcpyDeviceToHost));
