@@ -339,6 +339,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
 //    channel dimension; XCD-aware bijective block order (neighbouring pixel tiles share halo rows in one XCD's L2).
 // ------------------------------------------------------------------------------------------------
 
+// (image, row, column) of an output pixel, walked 32 pixels at a time: the loaders of the tile kernels need it for every 32nd row of their
+// tile, and a division by a run-time extent is ~35 instructions with quarter-rate multiplies - seven rows' worth was 5000 cycles before a
+// block's first DMA (stamps of conv_igemm_wsq_kernel: first barrier passed at 4944 cycles with the DMA switched off).
+struct PixWalk { int b, oy, ox; };
+__device__ __forceinline__ void pix_init(const ConvK& a, int m, PixWalk& p) {
+  p.b = m / a.OHW;
+  const int r = m - p.b * a.OHW;
+  p.oy = r / a.OW;
+  p.ox = r - p.oy * a.OW;
+}
+__device__ __forceinline__ void pix_step32(const ConvK& a, int dq, int dr, PixWalk& p) {   // dq = 32 / OW, dr = 32 % OW
+  p.ox += dr; p.oy += dq;
+  if (p.ox >= a.OW) { p.ox -= a.OW; ++p.oy; }
+  while (p.oy >= a.OH) { p.oy -= a.OH; ++p.b; }
+}
+
 struct ConvG {
   ConvK k;
   unsigned x_bytes, w_bytes;   // extents of the two buffers from their base pointers (buffer descriptors)
@@ -830,15 +846,16 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_ker
     const int lrow = w4 * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((w4 * 4 + (lane >> 4)) & 7);
     int a_off[4], a_iy0[4], a_ix0[4], b_off[4], a2_off[4];
+    PixWalk pw;
+    pix_init(a, m0 + lrow, pw);
+    const int dq32 = 32 / a.OW, dr32 = 32 - dq32 * a.OW;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + i * 32 + lrow;
       a2_off[i] = (int)0x80000000;
+      const int b = pw.b, oy = pw.oy, ox = pw.ox, r = oy * a.OW + ox;
+      pix_step32(a, dq32, dr32, pw);
       if (m < a.M) {
-        const int b = m / a.OHW;
-        const int r = m - b * a.OHW;
-        const int oy = r / a.OW;
-        const int ox = r - oy * a.OW;
         a_iy0[i] = oy * a.stride - a.pad;
         a_ix0[i] = ox * a.stride - a.pad;
         a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)a_iy0[i] * a.W + a_ix0[i]) * a.ldx) * 2) + chunk * 16;
@@ -1024,16 +1041,17 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsf_ker
     int a_off[NAI], a_iy0[NAI], a_ix0[NAI], b_off[NBI];
     unsigned a2_off[8];   // fixed extent (NAI <= 7): with a dependent extent hipcc (ROCm 7.2) silently drops the HOST stub of every instantiation
     static_assert(NAI <= 8, "a2_off");
+    PixWalk pw;
+    pix_init(a, m0 + lrow, pw);
+    const int dq32 = 32 / a.OW, dr32 = 32 - dq32 * a.OW;
 #pragma unroll
     for (int i = 0; i < NAI; ++i) {
       const int row = i * 32 + lrow;
       const int m = m0 + row;
       a2_off[i] = 0x80000000u;
+      const int b = pw.b, oy = pw.oy, ox = pw.ox, r = oy * a.OW + ox;
+      pix_step32(a, dq32, dr32, pw);
       if (m < a.M && row < BM) {
-        const int b = m / a.OHW;
-        const int r = m - b * a.OHW;
-        const int oy = r / a.OW;
-        const int ox = r - oy * a.OW;
         a_iy0[i] = oy * a.stride - a.pad;
         a_ix0[i] = ox * a.stride - a.pad;
         a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)a_iy0[i] * a.W + a_ix0[i]) * a.ldx) * 2) + chunk * 16;
@@ -1283,16 +1301,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wsq_kernel(const ConvG g) {
     int a_off[NAI], a_iy0[NAI], a_ix0[NAI], b_off[NBI];
     unsigned a2_off[8];   // fixed extent (see conv_igemm_wsf_kernel)
     static_assert(NAI <= 8, "a2_off");
+    PixWalk pw;
+    pix_init(a, m0 + lrow, pw);
+    const int dq32 = 32 / a.OW, dr32 = 32 - dq32 * a.OW;
 #pragma unroll
     for (int i = 0; i < NAI; ++i) {
       const int row = i * 32 + lrow;
       const int m = m0 + row;
       a2_off[i] = 0x80000000u;
+      const int b = pw.b, oy = pw.oy, ox = pw.ox, r = oy * a.OW + ox;
+      pix_step32(a, dq32, dr32, pw);
       if (m < a.M && row < BM) {
-        const int b = m / a.OHW;
-        const int r = m - b * a.OHW;
-        const int oy = r / a.OW;
-        const int ox = r - oy * a.OW;
         a_iy0[i] = oy * a.stride - a.pad;
         a_ix0[i] = ox * a.stride - a.pad;
         a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)a_iy0[i] * a.W + a_ix0[i]) * a.ldx) * 2) + chunk * 16;

@@ -493,6 +493,96 @@ __global__ __launch_bounds__(256) void k_attention(const T* __restrict__ qk, int
   }
 }
 
+// The same attention on the matrix cores, exact fp32 (v_mfma_f32_16x16x4_f32 = an fp32 fma chain): the long-sequence form (AIFI of the
+// wide encoders: 1600 tokens x 384 channels at 1280 px ran 0.67 ms per step on the VALU kernel above, 23 TFLOP/s).  A block = 4 waves = 64
+// queries of one (image, head); keys / values are staged 64 at a time in LDS (coalesced 16-byte loads) and every wave runs decoder.hip's
+// transposed scheme on its 16 queries: S^T = K Q^T per 16-key tile (keys on the accumulator rows, the lane's query on the column), the
+// softmax reductions over keys are 4 registers + one row-swap reduction, and the accumulator tile of P^T is already the B operand of
+// O^T += V^T P^T.
+template <int HD>
+__global__ __launch_bounds__(256) void k_attention_mfma_f32(const float* __restrict__ qk, int64_t ldqk, const float* __restrict__ v, int64_t ldv,
+                                                             float* __restrict__ o, int64_t ldo, int L, int D) {
+  constexpr int KT = 64, LDK = HD + 4, NC = HD / 16;
+  static_assert(HD % 16 == 0, "head dim");
+  __shared__ __attribute__((aligned(16))) float Ks[KT * LDK];
+  __shared__ __attribute__((aligned(16))) float Vs[KT * LDK];
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int qi = blockIdx.x * 64 + wave * 16 + r16;
+  const float scale = rsqrtf((float)HD);
+  f32x4 qa[NC];
+  {
+    const float* qrow = qk + ((int64_t)b * L + min(qi, L - 1)) * ldqk + head * HD + 4 * q;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      qa[c] = *(const f32x4*)(qrow + 16 * c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) qa[c][u] *= scale;
+    }
+  }
+  float m = -INFINITY, l = 0.f;
+  f32x4 O[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) O[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* kbase = qk + (int64_t)b * L * ldqk + D + head * HD;
+  const float* vbase = v + (int64_t)b * L * ldv + head * HD;
+  for (int k0 = 0; k0 < L; k0 += KT) {
+    __syncthreads();
+    for (int e = tid; e < KT * (HD / 4); e += 256) {
+      const int j = e / (HD / 4), d4 = (e - j * (HD / 4)) * 4;
+      const int kj = k0 + j;
+      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+      if (kj < L) { kv = *(const f32x4*)(kbase + (int64_t)kj * ldqk + d4); vv = *(const f32x4*)(vbase + (int64_t)kj * ldv + d4); }
+      *(f32x4*)&Ks[j * LDK + d4] = kv;
+      *(f32x4*)&Vs[j * LDK + d4] = vv;
+    }
+    __syncthreads();
+    const int nsub = (min(KT, L - k0) + 15) >> 4;
+    for (int sub = 0; sub < nsub; ++sub) {
+      f32x4 S = {0.f, 0.f, 0.f, 0.f};                           // S^T[key 4 q + r][query r16]
+      const float* kr = &Ks[(sub * 16 + r16) * LDK + 4 * q];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const f32x4 kf = *(const f32x4*)(kr + 16 * c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) S = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u], qa[c][u], S, 0, 0, 0);
+      }
+      float sv[4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sv[r] = (k0 + sub * 16 + 4 * q + r < L) ? S[r] : -INFINITY;
+        mx = fmaxf(mx, sv[r]);
+      }
+      mx = rows4_max(mx);
+      const float mn = fmaxf(m, mx);
+      const float alpha = __expf(m - mn);
+      f32x4 pr;
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pr[r] = __expf(sv[r] - mn); rs += pr[r]; }
+      rs = rows4_sum(rs);
+      l = l * alpha + rs;
+      m = mn;
+      const float* vr = &Vs[(sub * 16 + 4 * q) * LDK + r16];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) O[c][r] *= alpha;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) O[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[u * LDK + 16 * c], pr[u], O[c], 0, 0, 0);
+      }
+    }
+  }
+  if (qi < L) {
+    const float inv = 1.f / l;
+    float* orow = o + ((int64_t)b * L + qi) * ldo + head * HD + 4 * q;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) *(f32x4*)(orow + 16 * c) = f32x4{O[c][0] * inv, O[c][1] * inv, O[c][2] * inv, O[c][3] * inv};
+  }
+}
+
 void launch_attention(const Tensor& qk, const Tensor& v, const Tensor& o, int heads, hipStream_t s) {
   const int B = qk.n, L = qk.h * qk.w, D = v.c;
   RTD_CHECK(qk.c == 2 * D && o.c == D && v.n == B && o.n == B && v.h * v.w == L && o.h * o.w == L, 1, "attention: shape");
@@ -500,6 +590,14 @@ void launch_attention(const Tensor& qk, const Tensor& v, const Tensor& o, int he
   RTD_CHECK(D % heads == 0, 1, "attention: heads");
   const int hd = D / heads;
   const dim3 grid((L + 63) / 64, heads, B), blk(256);
+  if (qk.dt == F32 && L >= 64 && (hd == 32 || hd == 48 || hd == 64) && qk.ld % 4 == 0 && v.ld % 4 == 0 && o.ld % 4 == 0 &&
+      (((uintptr_t)qk.p | (uintptr_t)v.p | (uintptr_t)o.p) & 15) == 0) {
+    if (hd == 32) hipLaunchKernelGGL(k_attention_mfma_f32<32>, grid, blk, 0, s, (const float*)qk.p, qk.ld, (const float*)v.p, v.ld, (float*)o.p, o.ld, L, D);
+    else if (hd == 48) hipLaunchKernelGGL(k_attention_mfma_f32<48>, grid, blk, 0, s, (const float*)qk.p, qk.ld, (const float*)v.p, v.ld, (float*)o.p, o.ld, L, D);
+    else hipLaunchKernelGGL(k_attention_mfma_f32<64>, grid, blk, 0, s, (const float*)qk.p, qk.ld, (const float*)v.p, v.ld, (float*)o.p, o.ld, L, D);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
 #define ATT_GO(HD) DISPATCH_T(qk.dt, hipLaunchKernelGGL((k_attention<T, HD>), grid, blk, 0, s, (const T*)qk.p, qk.ld, (const T*)v.p, v.ld, (T*)o.p, o.ld, L, D))
   if (hd == 32) ATT_GO(32);
   else if (hd == 48) ATT_GO(48);

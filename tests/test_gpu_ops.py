@@ -475,7 +475,7 @@ def test_layernorm(L, dt, dim):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("shape", [(2, 400, 8, 32), (1, 300, 8, 32), (1, 130, 4, 48), (2, 70, 2, 64)])
+@pytest.mark.parametrize("shape", [(2, 400, 8, 32), (1, 300, 8, 32), (1, 130, 4, 48), (2, 70, 2, 64), (1, 1600, 8, 48), (3, 50, 2, 32)])
 def test_attention(L, dt, shape):
     code, tdt = DT[dt]
     B, Lq, heads, hd = shape

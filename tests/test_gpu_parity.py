@@ -268,6 +268,27 @@ def test_full_size_properties_f16x3_bs8():
     eng.close()
 
 
+@pytest.mark.parametrize("aname,size,bs", [("r50", 640, 14), ("r18", 320, 16), ("r50", 256, 9)])
+def test_f16x3_batch_invariance_at_large_batches_and_small_inputs(aname, size, bs):
+    """A frame's result does not depend on the batch it travels in - bit for bit - also above the batch where round 2's fixed split-K slab
+    ran out (13 at R50 640) and on small inputs, where tile shapes and the direct-kernel choice once followed the batch: the slice count
+    and every kernel family are chosen from per-image extents, the tile kernels keep an output's K order."""
+    from telescope_cam_detection_amd.synth import noise_frame, scene_frame
+    from telescope_cam_detection_amd.arch import ARCHS
+    arch = ARCHS[aname]
+    w = weights_for(arch, 0)
+    frames = [scene_frame(70 + i, size, size) if i % 2 else noise_frame(70 + i, size, size) for i in range(bs)]
+    eng = make_engine(arch, w, frames, (size, size), "f16x3", use_graph=True)
+    labels, boxes, scores = eng.infer_raw(frames)
+    for i in (0, bs // 2, bs - 1):
+        sl, sb, ss = eng.infer_raw([frames[i]])
+        assert np.array_equal(labels[i], sl[0]) and np.array_equal(boxes[i], sb[0]) and np.array_equal(scores[i], ss[0]), (aname, size, bs, i)
+    half = eng.infer_raw(frames[: bs // 2])
+    for x, y in zip((labels, boxes, scores), half):
+        np.testing.assert_array_equal(x[: bs // 2], y)
+    eng.close()
+
+
 def test_side_stream_plan_equals_the_serial_plan():
     """side_stream (query selection beside the value projection, decoder input projections beside the PAN path: fork / join edges in the
     hipGraph) runs the same kernels on the same data as the one-stream plan: bit-identical outputs, eager and replayed."""
