@@ -42,8 +42,10 @@ struct PlanOpts {
   int stem_fused_split = 1;   // f16x3 engine: backbone.stem.0 straight from the uint8 frames (hi/lo pairs made on the fly from the bytes)
   int sel_fused = 1;    // LayerNorm + score head + class max of the query selection in one launch
   int dec_fused = 1;    // 0 = one launch per decoder op
-  int side_stream = 3;  // bit 0: the query-selection chain runs on a second stream beside the value projection; bit 1: the decoder input
-                        // projections of the two larger levels run there beside the PAN path (0: one stream)
+  int side_stream = 7;  // bit 0: the query-selection chain runs on a second stream beside the value projection; bit 1: the decoder input
+                        // projections of the two larger levels run there beside the PAN path; bit 2: the encoder input projections of the two
+                        // larger levels (they only need the stage-1 / stage-2 maps) run there beside stages 2 / 3 and AIFI, whose 40^2 / 20^2
+                        // grids and row kernels leave CUs idle (0: one stream)
 };
 PlanOpts g_opts;
 
@@ -592,6 +594,14 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   B.push("backbone.pool", "maxpool", 9.0 * cur.pixels() * cur.c, Builder::tbytes(s2) + Builder::tbytes(cur),
          [s2, cur](hipStream_t s) { launch_maxpool3x3s2(s2, cur, s); });
 
+  // the FPN's concat buffers exist before the backbone runs: their projection halves are filled as soon as a stage's map is complete
+  const int d = c.enc_dim, hh = c.csp_hidden;
+  const int* lh = e->lvl_h; const int* lw = e->lvl_w;
+  Tensor cat1 = B.act(P, n, lh[0], lw[0], 2 * d);   // [up(lat1) | proj0]
+  Tensor cat0 = B.act(P, n, lh[1], lw[1], 2 * d);   // [up(lat0) | proj1]
+  const bool early_enc_proj = (e->opts.side_stream & 4) != 0;
+  bool enc_proj_forked = false;
+
   // ---- residual stages (HF:rt_detr_resnet.py:135-310) ------------------------------------------
   Tensor feats[3];
   int cin = c.embedding_size;
@@ -703,17 +713,22 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       cur = out; h = oh; w = ow; cin = cout;
     }
     if (si >= 1) feats[si - 1] = cur;
+    if (early_enc_proj && (si == 1 || si == 2)) {
+      // HF:v2.py:1348-1360 encoder input projection of this level, beside the next stage (side stream)
+      B.marker(1); B.lane = 1;
+      B.conv(si == 1 ? "enc.proj.0" : "enc.proj.1", cur, (si == 1 ? cat1 : cat0).slice_c(d, d), 1, 1, 0, ACT_NONE);
+      B.lane = 0;
+      enc_proj_forked = true;
+    }
   }
 
   // ---- hybrid encoder (HF:v2.py:1348-1360 input proj, :1041-1095 AIFI, :1183-1209 FPN/PAN) ------
-  const int d = c.enc_dim, hh = c.csp_hidden;
-  const int* lh = e->lvl_h; const int* lw = e->lvl_w;
-  Tensor cat1 = B.act(P, n, lh[0], lw[0], 2 * d);   // [up(lat1) | proj0]
-  Tensor cat0 = B.act(P, n, lh[1], lw[1], 2 * d);   // [up(lat0) | proj1]
   Tensor pcat0 = B.act(P, n, lh[1], lw[1], 2 * d);  // [down0 | lat1]
   Tensor pcat1 = B.act(P, n, lh[2], lw[2], 2 * d);  // [down1 | lat0]
-  B.conv("enc.proj.0", feats[0], cat1.slice_c(d, d), 1, 1, 0, ACT_NONE);
-  B.conv("enc.proj.1", feats[1], cat0.slice_c(d, d), 1, 1, 0, ACT_NONE);
+  if (!early_enc_proj) {
+    B.conv("enc.proj.0", feats[0], cat1.slice_c(d, d), 1, 1, 0, ACT_NONE);
+    B.conv("enc.proj.1", feats[1], cat0.slice_c(d, d), 1, 1, 0, ACT_NONE);
+  }
   const int L = lh[2] * lw[2];
   Tensor t0 = B.act(F32, n, L, 1, d, "aifi_in");
   {
@@ -834,6 +849,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   // FPN top-down
   Tensor lat0 = pcat1.slice_c(d, d);
   B.conv("enc.lat.0", t2, lat0, 1, 1, 0, ACT_SILU);
+  if (enc_proj_forked) B.marker(2);                  // the projection halves of cat0 / cat1 are complete
   Tensor F0 = csp("enc.fpn.0", cat0, "", &lat0);
   Tensor lat1 = pcat0.slice_c(d, d);
   B.conv("enc.lat.1", F0, lat1, 1, 1, 0, ACT_SILU);

@@ -292,12 +292,63 @@ __global__ __launch_bounds__(256) void k_maxpool_split(const sp16* __restrict__ 
   split_store8(y, (((int64_t)b * OH + oy) * OW + ox) * ldy, cc, m);
 }
 
+// ... on a 2 x 2 output patch per thread (even output extents): the 5 x 5 input window is read once - 25 x 32 bytes for 4 outputs instead
+// of 36 x 32 - and the taps the patch's outputs share stay in registers (k_maxpool_bf16_2x2's scheme)
+__global__ __launch_bounds__(256) void k_maxpool_split_2x2(const sp16* __restrict__ x, sp16* __restrict__ y, int B, int H, int W, int C, int64_t ldx,
+                                                           int OH, int OW, int64_t ldy) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c8 = C / 8, PW = OW / 2, PH = OH / 2;
+  const int64_t total = (int64_t)B * PH * PW * c8;
+  if (i >= total) return;
+  const int cc = (int)(i % c8) * 8;
+  int64_t p = i / c8;
+  const int px = (int)(p % PW); p /= PW;
+  const int py = (int)(p % PH);
+  const int b = (int)(p / PH);
+  const int iy0 = 4 * py - 1, ix0 = 4 * px - 1;
+  float m[4][8];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[o][k] = -INFINITY;
+#pragma unroll
+  for (int dy = 0; dy < 5; ++dy) {
+    const int iy = iy0 + dy;
+    if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) {
+      const int ix = ix0 + dx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      float v[8];
+      split_load8(x, (((int64_t)b * H + iy) * W + ix) * ldx, cc, v);
+#pragma unroll
+      for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox)
+          if (dy >= 2 * oy && dy <= 2 * oy + 2 && dx >= 2 * ox && dx <= 2 * ox + 2) {     // compile-time after unrolling
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m[oy * 2 + ox][k] = fmaxf(m[oy * 2 + ox][k], v[k]);
+          }
+    }
+  }
+#pragma unroll
+  for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+    for (int ox = 0; ox < 2; ++ox) split_store8(y, (((int64_t)b * OH + 2 * py + oy) * OW + 2 * px + ox) * ldy, cc, m[oy * 2 + ox]);
+}
+
 void launch_maxpool3x3s2(const Tensor& x, const Tensor& y, hipStream_t s) {
   RTD_CHECK(x.dt == y.dt && x.c == y.c && x.c % 4 == 0 && x.n == y.n, 1, "maxpool: dtype/channels");
   RTD_CHECK(y.h == (x.h + 2 - 3) / 2 + 1 && y.w == (x.w + 2 - 3) / 2 + 1, 1, "maxpool: shape");
   RTD_CHECK(x.bstride == (int64_t)x.h * x.w * x.ld && y.bstride == (int64_t)y.h * y.w * y.ld, 1, "maxpool: dense images");
   if (x.dt == F16X2) {
     RTD_CHECK(x.c % SPLIT_GROUP == 0 && x.ld % SPLIT_GROUP == 0 && y.ld % SPLIT_GROUP == 0 && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0, 1, "maxpool: split layout");
+    if (y.h % 2 == 0 && y.w % 2 == 0) {
+      const int64_t total2 = (int64_t)y.n * (y.h / 2) * (y.w / 2) * (y.c / 8);
+      hipLaunchKernelGGL(k_maxpool_split_2x2, dim3(blocks_for(total2, 256)), dim3(256), 0, s, (const sp16*)x.p, (sp16*)y.p, x.n, x.h, x.w, x.c, x.ld, y.h, y.w, y.ld);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     const int64_t total = (int64_t)y.n * y.h * y.w * (y.c / 8);
     hipLaunchKernelGGL(k_maxpool_split, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const sp16*)x.p, (sp16*)y.p, x.n, x.h, x.w, x.c, x.ld, y.h, y.w, y.ld);
     HIP_CHECK(hipGetLastError());

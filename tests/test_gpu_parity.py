@@ -299,14 +299,14 @@ def test_side_stream_plan_equals_the_serial_plan():
     w = weights_for(arch, 0)
     frames = [scene_frame(70, 640, 640), noise_frame(71, 640, 640), scene_frame(72, 640, 640)]
     outs = []
-    for v in (0, 1, 3):
+    for v in (0, 1, 3, 7):                        # bit 2: the encoder input projections beside stages 2 / 3 and AIFI
         _capi.debug_option("side_stream", v)
         e = make_engine(arch, w, frames, (640, 640), "f16x3", use_graph=True)
         for _ in range(3):
             o = e.infer_raw(frames)
         outs.append(o)
         e.close()
-    _capi.debug_option("side_stream", 3)
+    _capi.debug_option("reset", 0)
     for o in outs[1:]:
         for x, y in zip(outs[0], o):
             np.testing.assert_array_equal(x, y)
@@ -798,7 +798,7 @@ def test_no_captured_event_state_leaks_to_later_events_of_the_process():
     arch = ARCHS["tinyc"]
     w = weights_for(arch, 3)
     frames = [scene_frame(40, 160, 224), scene_frame(41, 160, 224)]
-    _capi.debug_option("side_stream", 3)
+    _capi.debug_option("side_stream", 7)
     for _ in range(3):
         eng = make_engine(arch, w, frames, (160, 224), "f16x3", use_graph=True)
         for n in (2, 1, 2):                                    # two plans captured, then a replay
