@@ -40,6 +40,7 @@ Prints ONE JSON line on rank 0 with the contract fields plus:
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import hashlib
 import json
 import os
@@ -94,6 +95,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-bf16-line", action="store_true", help="skip the secondary plain-bf16 engine measurement")
     ap.add_argument("--no-detect-host", action="store_true", help="skip the detect_host_ms measurement (RTDETRDetector.detect on host frames)")
+    ap.add_argument("--no-mfma-probe", action="store_true", help="skip the sustained-MFMA-rate probe (roofline.sustained_mfma)")
     ap.add_argument("--collate", action="store_true", help="N = 1: run the RCCL collate step on a world-size-1 nccl group (always on at N > 1)")
     ap.add_argument("--profile-out", default="")
     ap.add_argument("--opt", action="append", default=[], help="rtd_debug_option name=value (A/B runs)")
@@ -318,6 +320,26 @@ def main():
                 out["roofline"]["mfma_busy_frac_pmc"] = mu["conv_igemm_all"]["mfma_util"]
         except (OSError, KeyError, ValueError):
             pass
+        # ---- context for `frac` (never a replacement of it): what the matrix pipes of THIS device sustain on random operands.  `peak` is the
+        # 2.5 PFLOP/s of 2.4 GHz; under dense MFMA load on real data the chip holds 1.6-1.9 GHz (rtd_bench_mfma_rate: operands in registers,
+        # no memory traffic), and the f16x3 arithmetic issues 3 MFMA flops per algorithmic flop.
+        if not args.no_mfma_probe and args.precision != "fp32":
+            try:
+                buf = (C.c_float * 3)()
+                rates = {}
+                for rnd in (0, 1):
+                    rc = _capi.lib().rtd_bench_mfma_rate(rnd, 40, buf)
+                    if rc != 0:
+                        raise RuntimeError("rtd_bench_mfma_rate")
+                    rates["random" if rnd else "zero"] = {"tflops": round(buf[0], 1), "core_clock_ghz": round(buf[1], 3)}
+                sus = rates["random"]["tflops"]
+                out["roofline"]["sustained_mfma"] = {
+                    "operands_zero": rates["zero"], "operands_random": rates["random"],
+                    "frac_of_sustained": round(achieved / sus, 4), "mfma_issue_frac_of_sustained": round(mpp * achieved / sus, 4),
+                    "note": "v_mfma_f32_16x16x32_f16 back to back on every CU, operands in registers (measured now, this device): the rate the "
+                            "matrix pipes hold on random operand bits is the ceiling a kernel on real activations can reach; `frac` stays against the 2.5 PFLOP/s peak"}
+            except Exception as e:                                    # a probe failure never costs the bench line
+                print(f"[bench] mfma rate probe failed: {e}", file=sys.stderr)
         out["kernel_families_ms"] = {k: round(v["ms"], 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         if args.profile_out:
             with open(args.profile_out, "w") as fh:

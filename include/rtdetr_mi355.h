@@ -155,15 +155,17 @@ int64_t rtd_arena_bytes(rtd_handle h);
  * Conv dispatch, pair operands (RTD_PREC_F16X3): split_ws2_min_blocks [257] | split_ws64_max_blocks [160] |
  *   split_flex [1: flexible tile heights on grids of <= split_flex_small_max [200] tiles], split_flex_min_nk [4] |
  *   split_k2 [1: two-pass split-K on >= 128 K-steps with <= 16 tiles per image] |
+ *   split_wsq [1: 160..256-pixel tiles at one block per CU on grids of >= split_wsq_min_blocks [257] tiles with >= split_wsq_min_nk [24] K-steps] |
  *   split_sx [3: streaming 1x1 kernel 0 off, 1 stage-0 shapes, 2 + K = 128, 3 + K = 256 -> N >= 1024 (value projection), 4 + with residual (slower)]
  * Plan building:
  *   sc_fold [1] projection shortcut folded into the block's last conv | up_fold [1] FPN upsample folded into the CSP's first conv |
  *   c1_fuse [1] a block's reduce conv computed inside the previous block's expand conv (bf16: stage 0/1; f16x3: stage 0 and the first block
  *   of stage 1) | attn_split [2] self-attention on fp16-pair MFMAs (bit 0 AIFI, bit 1 decoder) |
- *   arena_reuse [1] | stem_fused_split [1] (f16x3): stem.0 straight from the uint8 frames | side_stream [3: bit 0 query
- *   selection on a second stream beside the value projection, bit 1 decoder input projections beside the PAN path] | dec_fused [1],
+ *   arena_reuse [1] | stem_fused_split [1] (f16x3): stem.0 straight from the uint8 frames | side_stream [7: bit 0 query
+ *   selection on a second stream beside the value projection, bit 1 decoder input projections beside the PAN path, bit 2 encoder input
+ *   projections beside stages 2 / 3 and AIFI] | dec_fused [1],
  *   dec_split [1: 0 fp32 MFMA, 2 hi-only filters], sel_fused [1] | dec_stamps [0]
- * Tools: profile_twice [0], bench_rewarm [0].
+ * Tools: profile_twice [0], bench_rewarm [0: bit 5 = rtd_bench_conv fills its operands with random fp16 values instead of zeros].
  * "reset" (any value): every template back to the values in brackets. */
 int rtd_debug_option(const char* name, int value);
 
@@ -208,6 +210,12 @@ int rtd_op_resize(const uint8_t* src, int sh, int sw, void* dst, int dh, int dw,
 int rtd_bench_conv_pair(const int* shape_a, const int* shape_b, int reps, float* us_out);
 int rtd_bench_conv(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int stride, int pad, int with_res,
                    int reps, int flush_mb, float* us_out);
+
+/* What the matrix pipes of THIS device sustain (tools/mfma_rate_probe.hip inside the library; bench.py reports it beside `roofline`):
+ * v_mfma_f32_16x16x32_f16 back to back on every CU, operands in registers, `random_operands` 0 = all-zero bits / 1 = random finite fp16
+ * (the chip lowers its clock under matrix load on real data).  out[0] = TFLOP/s by HIP events, out[1] = in-kernel core clock in GHz
+ * (s_memtime per s_memrealtime), out[2] = kernel milliseconds.  ~`ms_target` milliseconds of work per timed launch (3 launches). */
+int rtd_bench_mfma_rate(int random_operands, int ms_target, float* out);
 
 #ifdef __cplusplus
 }

@@ -92,7 +92,7 @@ EXPORTS = [
     "rtd_version", "rtd_create", "rtd_load_weights", "rtd_infer", "rtd_infer_raw", "rtd_infer_async",
     "rtd_result_block", "rtd_sync", "rtd_stream", "rtd_destroy", "rtd_last_error", "rtd_debug_tensor",
     "rtd_debug_force_topk", "rtd_profile", "rtd_arena_bytes", "rtd_debug_option", "rtd_op_conv", "rtd_op_conv_dual", "rtd_op_conv_next", "rtd_op_layernorm",
-    "rtd_op_attention", "rtd_op_msdeform", "rtd_op_topk", "rtd_op_resize", "rtd_crop_resize_batch", "rtd_bench_conv", "rtd_bench_conv_pair",
+    "rtd_op_attention", "rtd_op_msdeform", "rtd_op_topk", "rtd_op_resize", "rtd_crop_resize_batch", "rtd_bench_conv", "rtd_bench_conv_pair", "rtd_bench_mfma_rate",
 ]
 
 
@@ -152,6 +152,8 @@ def lib() -> C.CDLL:
     L.rtd_op_resize.argtypes = [vp, i32, i32, vp, i32, i32, i32]
     L.rtd_bench_conv.argtypes = [i32] * 12 + [C.POINTER(f32)]
     L.rtd_bench_conv_pair.argtypes = [C.POINTER(i32), C.POINTER(i32), i32, C.POINTER(f32)]
+    if hasattr(L, "rtd_bench_mfma_rate"):      # (absent from older builds loaded through RTD_LIB_PATH)
+        L.rtd_bench_mfma_rate.argtypes = [i32, i32, C.POINTER(f32)]
     L.rtd_crop_resize_batch.argtypes = [i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), i32, C.POINTER(f32), C.POINTER(f32), vp, vp]
     _lib = L
     return L

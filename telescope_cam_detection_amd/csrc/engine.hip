@@ -1692,6 +1692,30 @@ __global__ void k_fill_rand16(uint16_t* p, size_t n, unsigned seed) {
     p[i] = (uint16_t)((h & 0x8000u) | ((10u + ((h >> 16) & 7u)) << 10) | (h & 0x3ffu));
   }
 }
+// rtd_bench_mfma_rate: 16 independent accumulators per wave, 4 waves per CU (one per SIMD), operands in registers
+__global__ __launch_bounds__(256) void k_mfma_rate(const unsigned* __restrict__ seed, int iters, long long* __restrict__ out, float* __restrict__ sink) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  sp16x8 a[4], b[4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 8; ++j) {
+      const unsigned h = seed[(lane * 8 + j + i * 512) & 4095];
+      a[i][j] = __builtin_bit_cast(sp16, (unsigned short)h);
+      b[i][j] = __builtin_bit_cast(sp16, (unsigned short)(h >> 16));
+    }
+  f32x4 acc[16];
+  for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = mfma_pair16(a[i & 3], b[(i >> 2) & 3], acc[i]);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  const long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][3];
+  if (s == 123.456f) sink[0] = s;
+  if (lane == 0) { const int w = blockIdx.x * 4 + (tid >> 6); out[2 * w] = c1 - c0; out[2 * w + 1] = r1 - r0; }
+}
 static int g_bench_rewarm = 0;   // "bench_rewarm": rtd_bench_conv rewrites 1 = activations, 2 = weights after its flush (back into the Infinity Cache)
 int rtd_debug_option(const char* name, int value) {
   if (!name) return RTD_E_INVALID;
@@ -1953,6 +1977,48 @@ int rtd_bench_conv_pair(const int* shape_a, const int* shape_b, int reps, float*
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(f0); (void)hipEventDestroy(f1);
     (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2);
     for (BenchConv* c : {&A, &B}) { (void)hipFree(c->x); (void)hipFree(c->y); (void)hipFree(c->w); (void)hipFree(c->bias); }
+  });
+}
+
+int rtd_bench_mfma_rate(int random_operands, int ms_target, float* out) {
+  return op_guard([&] {
+    RTD_CHECK(out && ms_target >= 1 && ms_target <= 2000, RTD_E_INVALID, "arguments");
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    std::vector<unsigned> hs(4096, 0u);
+    if (random_operands)
+      for (int i = 0; i < 4096; ++i) {
+        unsigned h = (unsigned)i * 2654435761u + 12345u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const unsigned lo = (h & 0x8000u) | ((10u + ((h >> 20) & 7u)) << 10) | (h & 0x3ffu);
+        unsigned h2 = h * 2654435761u; h2 ^= h2 >> 16;
+        const unsigned hi = (h2 & 0x8000u) | ((10u + ((h2 >> 20) & 7u)) << 10) | (h2 & 0x3ffu);
+        hs[i] = lo | (hi << 16);
+      }
+    unsigned* seed = nullptr; long long* stamps = nullptr; float* sink = nullptr;
+    HIP_CHECK(hipMalloc((void**)&seed, 4096 * 4)); HIP_CHECK(hipMalloc((void**)&stamps, (size_t)cus * 4 * 2 * 8)); HIP_CHECK(hipMalloc((void**)&sink, 16));
+    HIP_CHECK(hipMemcpy(seed, hs.data(), 4096 * 4, hipMemcpyHostToDevice));
+    // 16 MFMAs of 16 cycles per iteration at <= 2.4 GHz: 9400 iterations per millisecond
+    const int iters = ms_target * 9400;
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    float ms = 0.f;
+    for (int rep = 0; rep < 3; ++rep) {
+      HIP_CHECK(hipEventRecord(e0, nullptr));
+      hipLaunchKernelGGL(k_mfma_rate, dim3(cus), dim3(256), 0, nullptr, seed, iters, stamps, sink);
+      HIP_CHECK(hipEventRecord(e1, nullptr));
+      HIP_CHECK(hipEventSynchronize(e1));
+      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    std::vector<long long> h((size_t)cus * 4 * 2);
+    HIP_CHECK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+    double cyc = 0, rt = 0;
+    for (int w = 0; w < cus * 4; ++w) { cyc += (double)h[2 * w]; rt += (double)h[2 * w + 1]; }
+    out[0] = (float)((double)iters * 16.0 * cus * 4.0 * 16384.0 / (ms * 1e-3) / 1e12);
+    out[1] = (float)(cyc / (rt * 10.0));
+    out[2] = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(seed); (void)hipFree(stamps); (void)hipFree(sink);
   });
 }
 

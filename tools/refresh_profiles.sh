@@ -17,7 +17,7 @@ run() {   # run <seconds> <log> <command...>: stop the whole script when a step 
   echo "[refresh] $log rc=$rc"
   if [ $rc -ge 124 ]; then echo "[refresh] step timed out / died: stopping"; tail -n 20 "${log%.*}.err"; exit $rc; fi
 }
-PROF="--streams 1 --multi-streams 0 --no-bf16-line --no-cpu-baseline --no-latency --no-detect-host --opt side_stream=0"
+PROF="--streams 1 --multi-streams 0 --no-bf16-line --no-cpu-baseline --no-latency --no-detect-host --no-mfma-probe --opt side_stream=0"
 if [ "$WHAT" = r50 ]; then
   # 1. the bench line (f16x3 engine, one batch in flight = `value`; + multi_stream, bf16_engine, detect_host_ms, cpu_baseline side lines)
   run 900 $O/bench_r50.json python bench.py

@@ -76,7 +76,7 @@ def do_trace(path, out):
                pct=round(100 * d / tot, 2)) for k, (d, c) in sorted(fam.items(), key=lambda kv: -kv[1][0])]
     conv = [k for k in ks if k["kernel"].startswith("conv")]
     res = dict(csrc_sha=csrc_sha(), config=CONFIG,
-               command=f"rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py {BENCH_ARGS} --steps 20 --warmup 3 --streams 1 --multi-streams 0 --no-bf16-line --no-cpu-baseline --no-latency --no-detect-host --opt side_stream=0".replace("  ", " "),
+               command=f"rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py {BENCH_ARGS} --steps 20 --warmup 3 --streams 1 --multi-streams 0 --no-bf16-line --no-cpu-baseline --no-latency --no-detect-host --no-mfma-probe --opt side_stream=0".replace("  ", " "),
                steady_graph_steps_used=len(steps), kernels_per_step=modal, step_span_ms_median=sorted(span)[len(span) // 2],
                conv_igemm_all=dict(us_per_step=round(sum(k["us_per_step"] for k in conv), 2), launches_per_step=sum(k["launches_per_step"] for k in conv),
                                    avg_us=round(sum(k["us_per_step"] for k in conv) / sum(k["launches_per_step"] for k in conv), 3)),
