@@ -51,6 +51,9 @@ CASES = {
     "c3_r101_1280_bs1": ("r101", 0, (1280, 1280), [(3000, 1280, 1280)], "scene"),
     # BASELINE config 3 at its full batch: 4 of the reference benchmark's noise frames (seeds 3000 + i)
     "c3_r101_1280_bs4": ("r101", 0, (1280, 1280), [(3000 + i, 1280, 1280) for i in range(4)], "noise"),
+    # the reference's largest advertised input (config/config.yaml:122: 1920x1920, "~150-250 ms/frame"): a 1080p camera frame stretched to
+    # 1920 x 1920 by the resampler, the reference's default model (R18); 1e-2 px is 5.2e-6 of this frame, 75 600 memory tokens
+    "c4_r18_1920_bs1": ("r18", 0, (1920, 1920), [(5000, 1080, 1920)], "scene"),
     # small graph-shaped cases for fast unit tests (the network itself only accepts input sizes
     # that are multiples of 32: the FPN concat of a 2x-upsampled map fails otherwise, in HF and
     # upstream alike); non-square maps and resized frames included

@@ -7,7 +7,7 @@ from oracle import rtdetr_oracle as orc
 from tests.util import load_case, match_detections, sample, weights_for
 
 FAST = ["t_tiny_160", "t_tiny_160x224", "t_tinyb_192x128", "t_tinyc_160x224", "c1_r18_640_bs1", "c1_r18_640_scene", "c1_r18_640_resize"]
-SLOW = ["c2_r50_640_scene_bs2"]
+SLOW = ["c2_r50_640_scene_bs2", "c4_r18_1920_bs1"]
 
 
 @pytest.mark.parametrize("name", FAST + SLOW)

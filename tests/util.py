@@ -13,7 +13,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # fixture name -> arch (the .npz carries seeds / sizes / frame list itself)
 CASE_ARCH = {
     "c1_r18_640_bs1": "r18", "c1_r18_640_scene": "r18", "c1_r18_640_resize": "r18",
-    "c2_r50_640_bs8": "r50", "c2_r50_640_scene_bs2": "r50", "c3_r101_1280_bs1": "r101", "c3_r101_1280_bs4": "r101",
+    "c2_r50_640_bs8": "r50", "c2_r50_640_scene_bs2": "r50", "c3_r101_1280_bs1": "r101", "c3_r101_1280_bs4": "r101", "c4_r18_1920_bs1": "r18",
     "t_tiny_160": "tiny", "t_tiny_160x224": "tiny", "t_tinyb_192x128": "tinyb", "t_tinyc_160x224": "tinyc",
 }
 
