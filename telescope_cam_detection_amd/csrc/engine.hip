@@ -942,7 +942,9 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   B.lane = 0;
   // value_proj of every decoder layer in ONE GEMM (they all read `mem`, HF:v2.py:177)
   Tensor vall = B.linear("dec.vp_all", mem, NL * dm, SP ? F32 : P, ACT_NONE, nullptr, "value_all");   // the samplers read bf16 or fp32 values
-  if (side) B.marker(2);
+  // the join sits after the decoder prologue in the fused plan (the prologue needs the selected rows, not the value maps: it stays on the
+  // side stream and the chain's 150 + 45 us run beside the projection's 175 instead of 45 after it)
+  bool side_joined = !side;
   const int npts = c.dec_heads * c.n_levels * c.n_points;
   float* ref_unact8 = (float*)B.alloc((size_t)n * Q * 8 * 4);
   float* ref8 = (float*)B.alloc((size_t)n * Q * 8 * 4);
@@ -954,6 +956,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   }
   Tensor hs = target;
   Tensor logits;
+  if (!fused && !side_joined) { B.marker(2); side_joined = true; }
   if (fused) {
     // ---- fused decoder: 1 prologue + per layer (self-attention kernel + one fused kernel), decoder.hip -----
     Tensor qpos = B.act(F32, n, Q, 1, dm);
@@ -998,8 +1001,11 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       a.bb0 = lin("dec.enc_bbox.0", dm, dm); a.bb1 = lin("dec.enc_bbox.1", dm, dm); a.bb2 = lin("dec.enc_bbox.2", 4, dm);
       a.qk = lin("dec.l0.sa.qk", 2 * dm, dm); a.v = lin("dec.l0.sa.v", dm, dm);
       a.kfrag_out = kfrag[0]; a.vfrag_out = vfrag[0];
+      if (!side_joined) B.lane = 1;
       B.push("dec.prologue", "dec_layer", 2.0 * n * Q * (2.0 * dm * dm + 4.0 * dm) + row_flops_next, (double)n * Q * dm * 4 * 6,
              [a](hipStream_t s) { launch_dec_layer(a, s); });
+      B.lane = 0;
+      if (!side_joined) { B.marker(2); side_joined = true; }
     }
     for (int i = 0; i < NL; ++i) {
       const std::string p = nm("dec.l%d", i);
