@@ -159,6 +159,10 @@ int conv_kpad(int K);                 // padded filter row length the kernels ex
 int conv_kpad_split(int K);           // F16X2 filter row length in bf16 elements (K real taps x channels)
 bool conv_split_supported(const ConvArgs& a);   // F16X2 input: does the split kernel take this launch?
 int conv_npad(int N);
+// stem.2 + the 3x3 / stride-2 max-pool in one pass (f16x3 engine): `a` = the conv whose output would be pooled into `pooled`
+bool conv_pool_supported(const ConvArgs& a, const Tensor& pooled);
+size_t conv_pool_side_bytes(const ConvArgs& a);
+void launch_conv_pool(const ConvArgs& a, const Tensor& pooled, void* side, hipStream_t s);
 size_t conv_split_slab_bytes(const ConvArgs& a);   // workspace the launch would use for its two-pass split-K (0 = it does not split)
 
 void launch_layernorm(const Tensor& x, const Tensor* res, const float* g, const float* b, const Tensor& y,

@@ -2151,8 +2151,25 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv3x3_reg_kernel(const Conv
 // of its 32 output channels in registers (36 fragments = 144 VGPRs) and runs hi*hi + hi*lo + lo*hi per tap (6 MFMAs per tap and row).
 // 8 waves per block, one block per CU (two 43 KiB patch buffers): COG channel groups x (8 / COG) waves, each wave 8 / (8 / COG) rows.
 // The epilogue writes the row's F16X2 pixels ([32 hi | 32 lo] per 32-channel group) through the wave's slab, 16-byte stores.
-template <int COG>   // output channel groups of 32 (1 or 2)
-__global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a, unsigned x_bytes, unsigned y_bytes, int tiles_x, int tiles_y, int ntiles) {
+// POOL (stem.2 -> 3x3 / stride-2 / pad-1 max-pool, HF:rt_detr_resnet.py:100-113): the conv rows are never written.  The waves of a
+// channel group own the tile's rows in pairs (rows 2 w, 2 w + 1 = the pooled row w's lower two); a wave takes the row above from its
+// neighbour through LDS, pools vertically in registers and horizontally through its slab, and writes the 4 x 16 pooled pixels.  A window
+// that crosses the tile's top row or left column lacks the conv pixels of the tile above / to the left: every tile also leaves its last row
+// (`side_row`) and its vertically pooled last column (`side_col`) in a side buffer and k_pool_fixup completes the first pooled row and
+// column of every tile afterwards.  The conv outputs are >= 0 (ReLU) and max is exact: the result equals conv -> pool bit for bit.
+struct PoolOut {
+  sp16* y;                 // pooled output [B][OH][OW][C] as F16X2
+  long long ldy, bstride;  // channels
+  int OH, OW;
+  unsigned y_bytes;
+  sp16* side_row;          // [tile][32 px][2 groups][32 hi | 32 lo]
+  sp16* side_col;          // [tile][4 rows][2 groups][32 hi | 32 lo]
+  unsigned row_bytes, col_bytes;
+};
+template <int COG, bool POOL = false>   // output channel groups of 32 (1 or 2)
+__global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a, unsigned x_bytes, unsigned y_bytes, int tiles_x, int tiles_y, int ntiles,
+                                                                   const PoolOut po) {
+  static_assert(!POOL || COG == 2, "the pooled form is stem.2's (32 -> 64 channels)");
   constexpr int NW = 8, NT_ = 512, WPG = NW / COG, RPW = 8 / WPG;    // waves per channel group, rows per wave
   constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2, NPIX = PW * PH;
   constexpr int ROWB = 128, CPP = 8, PPI = 8;
@@ -2188,7 +2205,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a
   }
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(POOL ? (void*)po.y : (void*)a.y, 0, POOL ? po.y_bytes : y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc((void*)(POOL ? po.side_row : (sp16*)a.y), 0, POOL ? po.row_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)(POOL ? po.side_col : (sp16*)a.y), 0, POOL ? po.col_bytes : 0u, 0x00020000);
   auto swz = [](int pi) { return (pi >> 1) & 7; };
   auto issue_patch = [&](int tile, int buf) {
     const int tx = tile % tiles_x;
@@ -2224,6 +2243,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a
     const int x0 = tx * TW, y0 = ty * TH;
     const char* pbuf = patch + buf * PBUF;
 
+    float vm[16];                                   // POOL: max over the wave's two rows, per (pixel = lane & 31, channel 8 q + 4 h + e)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) vm[e] = 0.f;
 #pragma unroll 1
     for (int rr_ = 0; rr_ < RPW; ++rr_) {
       const int r = wq * RPW + rr_;
@@ -2255,6 +2277,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a
       // ---- epilogue of this 32-pixel row: lane = pixel (lane & 31), channels 8 q + 4 h + (0..3) of the wave's group ----
       const int oy = y0 + r;
       char* sw_ = stage[wv];
+      const bool pix_ok = !POOL || (oy < a.H && x0 + (lane & 31) < a.W);       // POOL: pixels outside the map count as 0 (every window holds a real one)
       dispatch_act(a.act, [&](auto actc) {
         constexpr int ACT = decltype(actc)::value;
 #pragma unroll
@@ -2262,13 +2285,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a
           const f32x4 bv = *(const f32x4*)(a.bias + nbase + 8 * q + 4 * h);
           sp16x4 oh, ol;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { sp16 hi, lo; split2(act_c<ACT>(acc[4 * q + e] + bv[e]), hi, lo); oh[e] = hi; ol[e] = lo; }
+          for (int e = 0; e < 4; ++e) {
+            sp16 hi, lo;
+            split2(pix_ok ? act_c<ACT>(acc[4 * q + e] + bv[e]) : 0.f, hi, lo);
+            oh[e] = hi; ol[e] = lo;
+            if (POOL) vm[4 * q + e] = fmaxf(vm[4 * q + e], (float)hi + (float)lo);      // the represented value
+          }
           *(sp16x4*)(sw_ + (lane & 31) * ROWO + (8 * q + 4 * h) * 2) = oh;
           *(sp16x4*)(sw_ + (lane & 31) * ROWO + 64 + (8 * q + 4 * h) * 2) = ol;
         }
       });
       __builtin_amdgcn_wave_barrier();
-      {
+      if constexpr (POOL) {
+        // only the tile's LAST row leaves the block as it is: the side buffer of the tile below (4 stores per wave, out of range for the others)
+        if (rr_ == RPW - 1) {
+          const long long rrow = (long long)tile * 8192 + grp * 128;
+#pragma unroll
+          for (int i2 = 0; i2 < 4; ++i2) {
+            const int idx = i2 * 64 + lane;
+            const int p = idx >> 3, ch = idx & 7;
+            const unsigned vo = (wq == WPG - 1) ? (unsigned)(rrow + p * 256 + ch * 16) : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_*)(sw_ + p * ROWO + ch * 16), rsr, vo, 0, 0);
+          }
+        }
+      } else {
         const long long yrow = 4 * ((long long)b * a.y_bstride + ((long long)oy * a.W + x0) * a.ldy + nbase);   // bytes; ldy: channels
 #pragma unroll
         for (int i2 = 0; i2 < 4; ++i2) {
@@ -2281,7 +2321,109 @@ __global__ __launch_bounds__(512, 2) void conv3x3_reg_split_kernel(const ConvK a
       }
       __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (POOL) {
+      char* sw_ = stage[wv];
+      __syncthreads();                               // every wave's second row sits in its slab as hi / lo
+      if (wq > 0) {                                  // the row above this wave's pair: the neighbour's second row (wave 0: the tile above, k_pool_fixup)
+        const char* nb = stage[wv - 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const sp16x4 nh = *(const sp16x4*)(nb + (lane & 31) * ROWO + (8 * q + 4 * h) * 2);
+          const sp16x4 nl = *(const sp16x4*)(nb + (lane & 31) * ROWO + 64 + (8 * q + 4 * h) * 2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vm[4 * q + e] = fmaxf(vm[4 * q + e], (float)nh[e] + (float)nl[e]);
+        }
+      }
+      __syncthreads();                               // the slabs may be overwritten
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(f32x4*)(sw_ + (lane & 31) * ROWO + (8 * q + 4 * h) * 4) = f32x4{vm[4 * q], vm[4 * q + 1], vm[4 * q + 2], vm[4 * q + 3]};
+      __builtin_amdgcn_wave_barrier();
+      // horizontal: pooled pixel k = lane >> 2 of this wave's pooled row, channels 8 (lane & 3) .. + 7 of the group, from pixels 2 k - 1 .. 2 k + 1
+      const int k = lane >> 2, cq = lane & 3;
+      float pm[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pm[e] = 0.f;
+#pragma unroll
+      for (int d = -1; d <= 1; ++d) {
+        const int px = 2 * k + d;
+        if (px >= 0) {                               // (px <= 31 always; pixel -1 belongs to the tile on the left: k_pool_fixup)
+          const f32x4 t0 = *(const f32x4*)(sw_ + px * ROWO + cq * 32), t1 = *(const f32x4*)(sw_ + px * ROWO + cq * 32 + 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { pm[e] = fmaxf(pm[e], t0[e]); pm[4 + e] = fmaxf(pm[4 + e], t1[e]); }
+        }
+      }
+      sp16x8 ph, pl;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sp16 hi, lo; split2(pm[e], hi, lo); ph[e] = hi; pl[e] = lo; }
+      const int py = (y0 >> 1) + wq, pxo = (x0 >> 1) + k;
+      {
+        const bool ok = py < po.OH && pxo < po.OW;
+        const long long pb = 4 * ((long long)b * po.bstride + ((long long)py * po.OW + pxo) * po.ldy + nbase) + cq * 16;   // bytes
+        const unsigned vo = ok ? (unsigned)pb : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, ph), ry, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, pl), ry, vo == 0x80000000u ? vo : vo + 64u, 0, 0);
+      }
+      {
+        // the tile's last column, vertically pooled over this wave's rows: what the tile on the right lacks for its first pooled column
+        float cm[8];
+        const f32x4 t0 = *(const f32x4*)(sw_ + 31 * ROWO + cq * 32), t1 = *(const f32x4*)(sw_ + 31 * ROWO + cq * 32 + 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cm[e] = t0[e]; cm[4 + e] = t1[e]; }
+        sp16x8 chh, cll;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sp16 hi, lo; split2(cm[e], hi, lo); chh[e] = hi; cll[e] = lo; }
+        const unsigned vo = (k == 15) ? (unsigned)((long long)tile * 1024 + wq * 256 + grp * 128 + cq * 16) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, chh), rsc, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, cll), rsc, vo == 0x80000000u ? vo : vo + 64u, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
   }
+}
+
+// completes the first pooled row and the first pooled column of every tile of the fused stem.2 -> max-pool launch (see PoolOut): one
+// thread per (tile, 16 + 3 boundary pixels, 8 channels)
+__global__ __launch_bounds__(256) void k_pool_fixup(const PoolOut po, int tiles_x, int tiles_y, int ntiles, int C) {
+  const int c8n = C / 8;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)ntiles * 19 * c8n) return;
+  const int cc = (int)(i % c8n) * 8;
+  const long long t = i / c8n;
+  const int item = (int)(t % 19), tile = (int)(t / 19);
+  const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, b = t2 / tiles_y;
+  const int j = item < 16 ? 0 : item - 15, k = item < 16 ? item : 0;
+  const int py = 4 * ty + j, px = 16 * tx + k;
+  if (py >= po.OH || px >= po.OW) return;
+  const bool up = j == 0 && ty > 0, left = k == 0 && tx > 0;
+  if (!up && !left) return;
+  const long long pix = (long long)b * po.bstride + ((long long)py * po.OW + px) * po.ldy;
+  float v[8], w[8];
+  split_load8(po.y, pix, cc, v);
+  const int grp = cc >> 5, cg = cc & 31;
+  auto row_at = [&](int tl, int p) {      // side_row[tl][p][grp][hi | lo]
+    const sp16* q = po.side_row + (size_t)tl * 4096 + p * 128 + grp * 64 + cg;
+    const sp16x8 hh = *(const sp16x8*)q, ll = *(const sp16x8*)(q + 32);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], (float)hh[e] + (float)ll[e]);
+  };
+  if (up) {
+    const int above = tile - tiles_x;
+#pragma unroll
+    for (int d = -1; d <= 1; ++d) {
+      const int p = 2 * k + d;
+      if (p >= 0) row_at(above, p);
+    }
+    if (left) row_at(above - 1, 31);
+  }
+  if (left) {
+    const sp16* q = po.side_col + (size_t)(tile - 1) * 512 + j * 128 + grp * 64 + cg;
+    const sp16x8 hh = *(const sp16x8*)q, ll = *(const sp16x8*)(q + 32);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], (float)hh[e] + (float)ll[e]);
+  }
+  (void)w;
+  split_store8(po.y, pix, cc, v);
 }
 
 
@@ -3390,8 +3532,8 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
     const long long ntiles = (long long)x.n * tiles_x * tiles_y;
     if (tiles_x * tiles_y >= 32 && ntiles < (1ll << 30) && y_bytes < (1ll << 31)) {
       const unsigned gx = (unsigned)std::min<long long>(ntiles, 256);        // persistent, one block per CU
-      if (y.c == 32) hipLaunchKernelGGL((conv3x3_reg_split_kernel<1>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles);
-      else hipLaunchKernelGGL((conv3x3_reg_split_kernel<2>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles);
+      if (y.c == 32) hipLaunchKernelGGL((conv3x3_reg_split_kernel<1>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, PoolOut{});
+      else hipLaunchKernelGGL((conv3x3_reg_split_kernel<2>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, PoolOut{});
       HIP_CHECK(hipGetLastError());
       return;
     }
@@ -3514,6 +3656,55 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
   if (n64) { if (four) hipLaunchKernelGGL((conv_igemm_wsx_kernel<4, 64>), grid, blk, 0, s, g); else hipLaunchKernelGGL((conv_igemm_wsx_kernel<2, 64>), grid, blk, 0, s, g); }
   else { if (four) hipLaunchKernelGGL((conv_igemm_wsx_kernel<4, 128>), grid, blk, 0, s, g); else hipLaunchKernelGGL((conv_igemm_wsx_kernel<2, 128>), grid, blk, 0, s, g); }
   finish();
+}
+
+// ---- stem.2 -> max-pool in one pass (conv3x3_reg_split_kernel<2, true> + k_pool_fixup) ----------------------------------------------
+// a = the 3x3 / stride 1 / pad 1 conv 32 -> 64 channels with ReLU whose output a.y would be pooled 3x3 / stride 2 / pad 1 into `pooled`;
+// a.y.p is not touched (the plan does not allocate it).  `side` = conv_pool_side_bytes(a) bytes of scratch.
+bool conv_pool_supported(const ConvArgs& a, const Tensor& pooled) {
+  const Tensor& x = a.x;
+  const Tensor& y = a.y;
+  if (x.dt != F16X2 || y.dt != F16X2 || pooled.dt != F16X2) return false;
+  if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.x2.p && !a.next_y.p && a.res_mode == RES_NONE && a.act == ACT_RELU)) return false;
+  if (x.c != 32 || y.c != 64 || pooled.c != 64 || x.ld % SPLIT_GROUP || pooled.ld % SPLIT_GROUP) return false;
+  if (y.h != x.h || y.w != x.w || (y.h & 1) || (y.w & 1) || pooled.h != y.h / 2 || pooled.w != y.w / 2 || pooled.n != x.n) return false;
+  if (((uintptr_t)x.p & 15) || ((uintptr_t)pooled.p & 15) || ((uintptr_t)a.w & 15)) return false;
+  const int tiles_x = (x.w + 31) / 32, tiles_y = (x.h + 7) / 8;
+  return tiles_x * tiles_y >= 32 && opts_of(a).conv_reg != 0;
+}
+size_t conv_pool_side_bytes(const ConvArgs& a) {
+  const long long ntiles = (long long)a.x.n * ((a.x.w + 31) / 32) * ((a.x.h + 7) / 8);
+  return (size_t)ntiles * (8192 + 1024) + 256;
+}
+void launch_conv_pool(const ConvArgs& a, const Tensor& pooled, void* side, hipStream_t s) {
+  RTD_CHECK(conv_pool_supported(a, pooled) && side, 1, "conv + max-pool: shape not supported");
+  const Tensor& x = a.x;
+  ConvK k;
+  k.x = x.p; k.w = a.w; k.bias = a.bias; k.y = nullptr; k.res = nullptr;
+  k.H = x.h; k.W = x.w; k.M = x.n * x.h * x.w;
+  k.Cin = 2 * x.c; k.ldx = 2 * x.ld; k.x_bstride = 2 * x.bstride;
+  k.OH = x.h; k.OW = x.w; k.OHW = x.h * x.w;
+  k.N = 64; k.Kreal = 2 * 9 * x.c; k.Kpad = a.Kpad;
+  k.KH = 3; k.KW = 3; k.stride = 1; k.pad = 1;
+  k.ldy = 0; k.y_bstride = 0; k.ldr = 0; k.r_bstride = 0; k.res_f32 = 0;
+  k.act = a.act; k.res_mode = RES_NONE; k.y_f32 = 0; k.split = 1; k.y_split = 1; k.res_split = 0;
+  k.x2 = nullptr; k.ldx2 = 0; k.x2_bstride = 0; k.k2_start = 0; k.ntn = 1; k.reg_epi = 1; k.prefer256 = 0; k.pf = nullptr; k.pf_bytes = 0; k.x_up2 = 0;
+  k.next_w = nullptr; k.next_bias = nullptr; k.next_y = nullptr; k.next_ldy = 0; k.next_y_bstride = 0; k.next_kpad = 0; k.next_act = 0;
+  const long long x_bytes = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * 4;
+  const long long p_bytes = ((long long)(pooled.n - 1) * pooled.bstride + ((long long)pooled.h * pooled.w - 1) * pooled.ld + pooled.c) * 4;
+  const int tiles_x = (x.w + 31) / 32, tiles_y = (x.h + 7) / 8;
+  const long long ntiles = (long long)x.n * tiles_x * tiles_y;
+  RTD_CHECK(x_bytes < (1ll << 31) && p_bytes < (1ll << 31) && ntiles * 8192 < (1ll << 31), 1, "conv + max-pool: operand larger than a buffer descriptor");
+  PoolOut po;
+  po.y = (sp16*)pooled.p; po.ldy = pooled.ld; po.bstride = pooled.bstride; po.OH = pooled.h; po.OW = pooled.w; po.y_bytes = (unsigned)p_bytes;
+  po.side_row = (sp16*)side; po.row_bytes = (unsigned)(ntiles * 8192);
+  po.side_col = (sp16*)((char*)side + ntiles * 8192); po.col_bytes = (unsigned)(ntiles * 1024);
+  const unsigned gx = (unsigned)std::min<long long>(ntiles, 256);
+  hipLaunchKernelGGL((conv3x3_reg_split_kernel<2, true>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, 0u, tiles_x, tiles_y, (int)ntiles, po);
+  HIP_CHECK(hipGetLastError());
+  const long long items = ntiles * 19 * (64 / 8);
+  hipLaunchKernelGGL(k_pool_fixup, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, po, tiles_x, tiles_y, (int)ntiles, 64);
+  HIP_CHECK(hipGetLastError());
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t s) {

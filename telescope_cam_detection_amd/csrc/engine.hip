@@ -40,6 +40,7 @@ struct PlanOpts {
   int up_fold = 1;      // read the FPN's upsampled lateral straight from the half-size tensor (ConvArgs::x_up2)
   int arena_reuse = 1;  // backbone stages recycle their activation buffers
   int stem_fused_split = 1;   // f16x3 engine: backbone.stem.0 straight from the uint8 frames (hi/lo pairs made on the fly from the bytes)
+  int stem_pool_fuse = 1;     // f16x3 engine: backbone.stem.2 and the 3x3 / stride-2 max-pool in one pass (the conv rows are never written)
   int sel_fused = 1;    // LayerNorm + score head + class max of the query selection in one launch
   int dec_fused = 1;    // 0 = one launch per decoder op
   int side_stream = 7;  // bit 0: the query-selection chain runs on a second stream beside the value projection; bit 1: the decoder input
@@ -587,12 +588,47 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   }
   Tensor s1 = B.act(P, n, h, w, eh);
   B.conv("backbone.stem.1", s0, s1, 3, 1, 1, ACT_RELU);
-  Tensor s2 = B.act(P, n, h, w, c.embedding_size);
-  B.conv("backbone.stem.2", s1, s2, 3, 1, 1, ACT_RELU);
-  h = down2(h); w = down2(w);
-  Tensor cur = B.act(P, n, h, w, c.embedding_size, "stem");
-  B.push("backbone.pool", "maxpool", 9.0 * cur.pixels() * cur.c, Builder::tbytes(s2) + Builder::tbytes(cur),
-         [s2, cur](hipStream_t s) { launch_maxpool3x3s2(s2, cur, s); });
+  Tensor cur;
+  {
+    // stem.2 + max-pool (HF:rt_detr_resnet.py:100-113).  f16x3: one pass when the direct kernel takes the conv (stem_pool_fuse) - the
+    // 320^2 x 64-channel conv output (210 MB at R50 bs 8) is neither written nor read back
+    Tensor s2v;                                    // stem.2's output as a shape (allocated only when the pool runs on its own)
+    s2v.dt = P; s2v.n = n; s2v.h = h; s2v.w = w; s2v.c = c.embedding_size; s2v.ld = c.embedding_size; s2v.bstride = (int64_t)h * w * c.embedding_size;
+    const int ph = down2(h), pw = down2(w);
+    Tensor pv = s2v; pv.h = ph; pv.w = pw; pv.bstride = (int64_t)ph * pw * pv.ld;
+    ConvArgs probe;
+    probe.opts = &e->conv_opts;
+    probe.x = s1; probe.x.p = (void*)16; probe.y = s2v; probe.y.p = (void*)16;
+    probe.KH = probe.KW = 3; probe.stride = 1; probe.pad = 1; probe.act = ACT_RELU; probe.w = (const void*)16;
+    Tensor pvp = pv; pvp.p = (void*)16;
+    Tensor probe1 = probe.x; probe1.n = 1;          // asked for ONE image: every plan of a handle makes the same choice
+    ConvArgs probe_one = probe; probe_one.x = probe1; probe_one.y.n = 1;
+    Tensor pv1 = pvp; pv1.n = 1;
+    const bool fuse = SP && e->opts.stem_pool_fuse && conv_pool_supported(probe_one, pv1);
+    if (fuse) {
+      h = ph; w = pw;
+      cur = B.act(P, n, h, w, c.embedding_size, "stem");
+      ConvArgs a;
+      a.x = s1; a.y = s2v; a.y.p = nullptr;
+      a.KH = a.KW = 3; a.stride = 1; a.pad = 1; a.act = ACT_RELU; a.opts = &e->conv_opts;
+      DevWeight w2;
+      if (!B.dry) w2 = get_weight(e, "backbone.stem.2", P, c.embedding_size, 9 * s1.c);
+      else { w2.Kpad = conv_kpad_split(9 * s1.c); w2.Npad = conv_npad(c.embedding_size); }
+      a.w = w2.w; a.bias = w2.bias; a.Kpad = w2.Kpad; a.Npad = w2.Npad;
+      void* side = B.alloc(conv_pool_side_bytes(a));
+      const Tensor curv = cur;
+      B.push("backbone.stem.2+pool", "conv_igemm", 2.0 * s2v.pixels() * s2v.c * 9.0 * s1.c, Builder::tbytes(s1) + Builder::tbytes(cur),
+             [a, curv, side](hipStream_t st) { launch_conv_pool(a, curv, side, st); });
+    } else {
+      Tensor s2 = B.act(P, n, h, w, c.embedding_size);
+      B.conv("backbone.stem.2", s1, s2, 3, 1, 1, ACT_RELU);
+      h = ph; w = pw;
+      cur = B.act(P, n, h, w, c.embedding_size, "stem");
+      const Tensor curv = cur;
+      B.push("backbone.pool", "maxpool", 9.0 * cur.pixels() * cur.c, Builder::tbytes(s2) + Builder::tbytes(cur),
+             [s2, curv](hipStream_t s) { launch_maxpool3x3s2(s2, curv, s); });
+    }
+  }
 
   // the FPN's concat buffers exist before the backbone runs: their projection halves are filled as soon as a stage's map is complete
   const int d = c.enc_dim, hh = c.csp_hidden;
@@ -1738,7 +1774,7 @@ int rtd_debug_option(const char* name, int value) {
   // created afterwards (and the kernel-level rtd_op_* / rtd_bench_* entry points), never a live handle
   const struct { const char* n; int* p; } plan_opts[] = {
       {"dec_stamps", &g_opts.dec_stamps}, {"dec_fused", &g_opts.dec_fused}, {"side_stream", &g_opts.side_stream}, {"sel_fused", &g_opts.sel_fused},
-      {"stem_fused_split", &g_opts.stem_fused_split}, {"sc_fold", &g_opts.sc_fold}, {"arena_reuse", &g_opts.arena_reuse},
+      {"stem_fused_split", &g_opts.stem_fused_split}, {"stem_pool_fuse", &g_opts.stem_pool_fuse}, {"sc_fold", &g_opts.sc_fold}, {"arena_reuse", &g_opts.arena_reuse},
       {"up_fold", &g_opts.up_fold}, {"attn_split", &g_opts.attn_split}, {"c1_fuse", &g_opts.c1_fuse}, {"dec_split", &g_opts.dec_split},
       {"profile_twice", &g_profile_twice}, {"bench_rewarm", &g_bench_rewarm},
   };

@@ -653,6 +653,38 @@ def test_f16x3_fused_uint8_stem_matches_the_generic_stem():
         assert m >= n - 2, (b, m, n, ws, wb)
 
 
+@pytest.mark.parametrize("aname,size,bs", [("tinyc", (160, 224), 3), ("r18", (352, 608), 2), ("r50", (640, 640), 2), ("r18", (1280, 1280), 1)])
+def test_f16x3_fused_stem2_maxpool_equals_conv_then_pool(aname, size, bs):
+    """stem.2 and the 3x3 / stride-2 max-pool in one pass (rows exchanged between the waves of a tile through LDS, the first pooled row and
+    column of every tile completed from side buffers by k_pool_fixup) against conv -> pool as two launches: the pooled map and the final
+    outputs bit for bit - max is exact and ReLU outputs are >= 0.  Ragged tiles in both directions (352 x 608 -> a 176 x 304 conv map:
+    22 tile rows, 9.5 tile columns), a single tile row per wave pair, the benchmark size and 1280 px."""
+    from telescope_cam_detection_amd import _capi
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.synth import noise_frame, scene_frame
+    from telescope_cam_detection_amd.weights import fold_weights, pack_blob, synth_weights
+
+    arch = ARCHS[aname]
+    blob = pack_blob(fold_weights(arch, synth_weights(arch, 5)))
+    frames = [noise_frame(80 + i, size[0], size[1]) if i % 2 else scene_frame(80 + i, size[0], size[1]) for i in range(bs)]
+    out, stem = {}, {}
+    for fused in (0, 1):
+        _capi.debug_option("stem_pool_fuse", fused)
+        eng = _capi.Engine(arch, blob, 0, _capi.PREC_F16X3, bs, size, True)
+        for _ in range(2):
+            out[fused] = eng.infer_raw(frames)
+        stem[fused] = eng.debug_tensor("stem")
+        one = eng.infer_raw(frames[:1])                       # the bs-1 plan of the same handle
+        for x, y in zip(out[fused], one):
+            np.testing.assert_array_equal(x[:1], y)
+        eng.close()
+    _capi.debug_option("reset", 0)
+    assert stem[0].shape == stem[1].shape and np.isfinite(stem[1]).all()
+    np.testing.assert_array_equal(stem[0], stem[1])
+    for x, y in zip(out[0], out[1]):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_non_square_input_with_partial_tiles_bf16_and_fp32():
     """416 x 736 (multiples of 32, but 208 x 368 and 104 x 184 are not multiples of the 8 x 32 / 128-pixel tiles): every conv
     kernel family meets ragged tiles.  fp32 engine vs oracle at the north-star tolerance, bf16 engine vs fp32 engine to bf16 noise."""
