@@ -139,6 +139,9 @@ struct ConvArgs {
   const float* next_bias = nullptr;
   Tensor next_y;                    // [B,OH,OW,64]
   int next_kpad = 0, next_act = ACT_NONE;
+  // optional (streaming pair kernel, a stage's last expand conv): the 2 x 2 / stride-2 average of y, [B, OH / 2, OW / 2, N] F16X2, written by
+  // the same launch (the next stage's vd-shortcut input); see conv_avg_supported()
+  Tensor avg_y;
   int prefer256 = 0;   // throughput profile (rtd_config.profile): take the 256-pixel tile from 100 blocks on (bf16 / fp32 operands)
   const ConvOpts* opts = nullptr;   // the handle's snapshot of the dispatch switches; nullptr = the process-wide template
   Tensor y;            // output [B,OH,OW,N] (view)
@@ -160,6 +163,7 @@ int conv_kpad_split(int K);           // F16X2 filter row length in bf16 element
 bool conv_split_supported(const ConvArgs& a);   // F16X2 input: does the split kernel take this launch?
 int conv_npad(int N);
 // stem.2 + the 3x3 / stride-2 max-pool in one pass (f16x3 engine): `a` = the conv whose output would be pooled into `pooled`
+bool conv_avg_supported(const ConvArgs& a);      // can this launch (shapes for ONE image) carry ConvArgs::avg_y?
 bool conv_pool_supported(const ConvArgs& a, const Tensor& pooled);
 size_t conv_pool_side_bytes(const ConvArgs& a);
 void launch_conv_pool(const ConvArgs& a, const Tensor& pooled, void* side, hipStream_t s);

@@ -3075,6 +3075,14 @@ bool conv_dual_supported(const ConvArgs& a) {
 // N = 512 (K = 128) -> 128 channels.  Asked per plan (batch size): the fused and the separate form use the same filter tensors and
 // give bit-identical outputs, so plans of different batch sizes may differ.
 static bool sx_shape_ok(const ConvArgs& a);
+bool conv_avg_supported(const ConvArgs& a) {
+  const Tensor& x = a.x;
+  const Tensor& y = a.y;
+  if (x.dt != F16X2 || y.dt != F16X2 || !sx_shape_ok(a)) return false;
+  if (a.x2.p || a.res_mode == RES_NONE || (y.h & 1) || (y.w & 15) || y.ld % SPLIT_GROUP) return false;
+  if (x.c == 64) return y.c == 256 && a.next_y.p && a.next_y.c == 128 && conv_next_supported(a);
+  return x.c == 128 && !a.next_y.p;
+}
 bool conv_next_supported(const ConvArgs& a) {
   const ConvOpts& o = opts_of(a);
   const Tensor& x = a.x;
@@ -3120,9 +3128,19 @@ int conv_kpad_split(int K) { return 2 * ((K + SPLIT_GROUP - 1) / SPLIT_GROUP * S
 // Arithmetic per output: K chunks in order into a zero accumulator (lo-terms first inside a chunk), + bias, + residual (hi + lo),
 // activation, one hi/lo rounding.  Kernel choice depends on the per-IMAGE extents only, so every batch size runs the same arithmetic.
 // ------------------------------------------------------------------------------------------------
-template <int NGX, int NG2, bool RES, int NEXTN, bool F32OUT = false>   // NGX / NG2: 32-channel K groups read from x / from ConvK::x2; F32OUT: fp32 rows out
+// AVG (a stage's last expand conv): the pixel tile is a 2-row x 16-column PATCH instead of 32 consecutive pixels, and while a wave's slab
+// holds its 32 channels of the tile it also writes the 2 x 2 / stride-2 average of the patch (8 pixels) to AvgOut: the next stage's
+// vd-shortcut input (HF:rt_detr_resnet.py:199-205, AvgPool2d(2, 2)) - that launch and its read of the whole stage output disappear.  The
+// average is ((a00 + a01) + (a10 + a11)) * 0.25 on the represented values hi + lo, re-split: k_avgpool2_split's arithmetic bit for bit.
+struct AvgOut {
+  sp16* y;                 // [B][OH / 2][OW / 2][C] as F16X2
+  long long ldy, bstride;  // channels
+  unsigned y_bytes;
+};
+template <int NGX, int NG2, bool RES, int NEXTN, bool F32OUT = false, bool AVG = false>   // NGX / NG2: 32-channel K groups read from x / from ConvK::x2; F32OUT: fp32 rows out
 __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsigned x_bytes, unsigned r_bytes, unsigned y_bytes, unsigned x2_bytes, int ntiles,
-                                                            unsigned yn_bytes, int ny) {
+                                                            unsigned yn_bytes, int ny, const AvgOut ao) {
+  static_assert(!AVG || !F32OUT, "the averaged copy is a F16X2 tensor");
   constexpr int NKX = 2 * NGX, NK2 = 2 * NG2, NKK = NKX + NK2;   // 16-deep MFMA chunks
   constexpr int NG_ = NGX + NG2;
   constexpr int SROW = 144;
@@ -3173,6 +3191,20 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res : a.x), 0, RES ? r_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ryn = __builtin_amdgcn_make_buffer_rsrc((void*)(NEXTN ? a.next_y : a.y), 0, NEXTN ? yn_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rya = __builtin_amdgcn_make_buffer_rsrc((void*)(AVG ? (void*)ao.y : a.y), 0, AVG ? ao.y_bytes : 0u, 0x00020000);
+  // tile t -> (image, first pixel); pixel px of the tile -> pixel index inside the image.  AVG: 2 x 16 patches, (OH / 2) x (OW / 16) per image
+  const int tpr = AVG ? a.OW >> 4 : 1, tpi = AVG ? (a.OH >> 1) * tpr : 1;
+  auto tile_origin = [&](int t, int& b0, int& p0) {
+    if (AVG) { b0 = t / tpi; const int r = t - b0 * tpi, ty = r / tpr; p0 = 2 * ty * a.OW + 16 * (r - ty * tpr); }
+    else { const int m0 = t * 32; b0 = m0 / a.OHW; p0 = m0 - b0 * a.OHW; }
+  };
+  auto tile_pixel = [&](int t, int b0, int p0, int px, int& b, int& p) -> bool {      // false: the pixel does not exist
+    b = b0;
+    if (AVG) { p = p0 + (px >> 4) * a.OW + (px & 15); return true; }
+    p = p0 + px;
+    if (p >= a.OHW) { p -= a.OHW; ++b; }
+    return t * 32 + px < a.M;
+  };
   const float* bl = sbias + wv * 32 + 16 * h;
   char* sl = slabs[wv];
   char* sl_acc = sl + pl * SROW + 32 * h;                         // this lane's 16 channels in accumulator shape: hi here, lo at + 64
@@ -3188,30 +3220,27 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
   static_assert(LX <= 4 && L2 <= 1, "staging registers");       // (fixed extents below: hipcc drops the host stub of a kernel template whose lambdas see dependent-extent arrays)
   auto issue = [&](int t, u32x4_ (&gx)[4], u32x4_ (&g2)[1], u32x4_ (&rv)[4], unsigned (&yrow)[4]) {
     // one division per tile: the tile's first pixel (uniform); a tile crosses at most one image boundary (OHW >= 32)
-    const int m0 = t * 32;
-    const int b0 = m0 / a.OHW, p0 = m0 - b0 * a.OHW;
+    int b0, p0;
+    tile_origin(t, b0, p0);
 #pragma unroll
     for (int i = 0; i < LX; ++i) {
       const int e = tid + 512 * i, px = e / CPRX, ck = e - px * CPRX;
-      int b = b0, p = p0 + px;
-      if (p >= a.OHW) { p -= a.OHW; ++b; }
-      const bool ok = m0 + px < a.M && px < 32;
+      int b, p;
+      const bool ok = tile_pixel(t, b0, p0, px & 31, b, p) && px < 32;
       gx[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(((long long)b * a.x_bstride + (long long)p * a.ldx) * 2 + ck * 16) : 0x80000000u, 0, 0);
     }
     if (NG2) {
       const int px = tid / CPR2, ck = tid - px * CPR2;
-      int b = b0, p = p0 + px;
-      if (p >= a.OHW) { p -= a.OHW; ++b; }
-      const bool ok = m0 + px < a.M && px < 32;
+      int b, p;
+      const bool ok = tile_pixel(t, b0, p0, px & 31, b, p) && px < 32;
       g2[0] = __builtin_amdgcn_raw_buffer_load_b128(rx2, ok ? (unsigned)(((long long)b * a.x2_bstride + (long long)p * a.ldx2) * 2 + ck * 16) : 0x80000000u, 0, 0);
     }
     // row-shaped offsets of this lane's 4 output chunks (rows 8 apart); residual chunks requested now
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int px = (lane >> 3) + 8 * j;
-      int b = b0, p = p0 + px;
-      if (p >= a.OHW) { p -= a.OHW; ++b; }
-      const bool ok2 = m0 + px < a.M;
+      int b, p;
+      const bool ok2 = tile_pixel(t, b0, p0, px, b, p);
       yrow[j] = ok2 ? (unsigned)(((long long)b * a.y_bstride + (long long)p * a.ldy + cb) * 4 + (lane & 7) * 16) : 0x80000000u;   // channels: 4 bytes each in a F16X2 row
       if (RES) rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rr, ok2 ? (unsigned)(((long long)b * a.r_bstride + (long long)p * a.ldr + cb) * 4 + (lane & 7) * 16) : 0x80000000u, 0, 0);
     }
@@ -3288,6 +3317,31 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_*)(sl_row + j * 8 * SROW), ry, yrow[j], 0, 0);
+      if constexpr (AVG) {
+        // lane -> averaged pixel lane / 8 of the patch's 8, channels 4 (lane % 8) .. + 3 of the wave's group; its four sources are the patch's
+        // pixels (row 0 | 1, column 2 pp | 2 pp + 1) = tile pixels 2 pp, 2 pp + 1, 16 + 2 pp, 17 + 2 pp
+        const int pp = lane >> 3, cq = lane & 7;
+        const char* s0 = sl + (2 * pp) * SROW + cq * 8;
+        float o[4];
+        {
+          const sp16x4 h00 = *(const sp16x4*)s0, l00 = *(const sp16x4*)(s0 + 64), h01 = *(const sp16x4*)(s0 + SROW), l01 = *(const sp16x4*)(s0 + SROW + 64);
+          const sp16x4 h10 = *(const sp16x4*)(s0 + 16 * SROW), l10 = *(const sp16x4*)(s0 + 16 * SROW + 64);
+          const sp16x4 h11 = *(const sp16x4*)(s0 + 17 * SROW), l11 = *(const sp16x4*)(s0 + 17 * SROW + 64);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            o[e] = ((((float)h00[e] + (float)l00[e]) + ((float)h01[e] + (float)l01[e])) + (((float)h10[e] + (float)l10[e]) + ((float)h11[e] + (float)l11[e]))) * 0.25f;
+        }
+        sp16x4 ah, al;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sp16 hi, lo; split2(o[e], hi, lo); ah[e] = hi; al[e] = lo; }
+        int b0, p0;
+        tile_origin(t, b0, p0);
+        const int oy2 = (p0 / a.OW) >> 1, ox2 = ((p0 % a.OW) >> 1) + pp;
+        const long long ab = 4 * ((long long)b0 * ao.bstride + ((long long)oy2 * (a.OW >> 1) + ox2) * ao.ldy + cb) + cq * 8;      // bytes
+        typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, ah), rya, (unsigned)ab, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, al), rya, (unsigned)ab + 64u, 0, 0);
+      }
       if (NEXTN) {
         __syncthreads();                                         // the eight slabs hold the tile's 256 output channels (hi | lo, activated)
         const int r16 = lane & 15, kq = lane >> 4;
@@ -3319,14 +3373,14 @@ __global__ __launch_bounds__(512, 2) void conv1x1_sx_kernel(const ConvK a, unsig
         __syncthreads();                                         // every wave has read the slabs: the next tile may overwrite them; y1s is complete
         {
           constexpr int CPN = NEXTN / 4;                         // 16-byte chunks per pixel of the follower's output
-          const int m0 = t * 32;
-          const int b0 = m0 / a.OHW, p0 = m0 - b0 * a.OHW;
+          int b0, p0;
+          tile_origin(t, b0, p0);
 #pragma unroll
           for (int i = 0; i < (32 * CPN) / 512; ++i) {
             const int e = tid + 512 * i, px = e / CPN, ck = e - px * CPN;
-            int b = b0, p = p0 + px;
-            if (p >= a.OHW) { p -= a.OHW; ++b; }
-            const unsigned off = m0 + px < a.M ? (unsigned)(((long long)b * a.next_y_bstride + (long long)p * a.next_ldy) * 4 + ck * 16) : 0x80000000u;
+            int b, p;
+            const bool okn = tile_pixel(t, b0, p0, px, b, p);
+            const unsigned off = okn ? (unsigned)(((long long)b * a.next_y_bstride + (long long)p * a.next_ldy) * 4 + ck * 16) : 0x80000000u;
             __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_*)(y1s + px * YROW + ck * 16), ryn, off, 0, 0);
           }
         }
@@ -3369,19 +3423,35 @@ static bool dispatch_sx(const ConvK& k, const ConvArgs& a, long long x_bytes, lo
     yn_bytes = ((long long)(a.next_y.n - 1) * a.next_y.bstride + ((long long)a.next_y.h * a.next_y.w - 1) * a.next_y.ld + a.next_y.c) * 4;
   }
   if (y_bytes >= (1ll << 31) || r_bytes >= (1ll << 31) || yn_bytes >= (1ll << 31)) return false;
-  const long long ntiles = ((long long)k.M + 31) / 32;
+  // the averaged copy for the next stage's vd shortcut (ConvArgs::avg_y): 2 x 16 patch tiles, the two variants a stage ends with
+  const bool avg = a.avg_y.p != nullptr;
+  AvgOut ao{};
+  if (avg) {
+    const Tensor& v = a.avg_y;
+    if (!(v.dt == F16X2 && y.dt == F16X2 && res && !dual && (y.h & 1) == 0 && (y.w & 15) == 0 && v.h == y.h / 2 && v.w == y.w / 2 && v.c == y.c && v.n == y.n &&
+          v.ld % SPLIT_GROUP == 0 && ((uintptr_t)v.p & 15) == 0 && ((a.x.c == 64 && next && a.next_y.c == 128) || (a.x.c == 128 && !next)))) return false;
+    const long long vb = ((long long)(v.n - 1) * v.bstride + ((long long)v.h * v.w - 1) * v.ld + v.c) * 4;
+    if (vb >= (1ll << 31)) return false;
+    ao.y = (sp16*)v.p; ao.ldy = v.ld; ao.bstride = v.bstride; ao.y_bytes = (unsigned)vb;
+  }
+  const long long ntiles = avg ? (long long)y.n * (y.h / 2) * (y.w / 16) : ((long long)k.M + 31) / 32;
   if (ntiles >= (1ll << 30)) return false;
   const int ny = y.c / 256;
   // persistent, two 8-wave blocks per CU: 8 XCDs x nts tile streams x ny channel blocks
   const int nts = (int)std::max<long long>(1, std::min<long long>(64 / ny, (ntiles + 7) / 8));
   const dim3 grid((unsigned)(8 * nts * ny)), blk(512);
 #define RTD_SX(NGX, NG2, RES_, NX) hipLaunchKernelGGL((conv1x1_sx_kernel<NGX, NG2, RES_, NX>), grid, blk, 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, \
-                                                     (unsigned)y_bytes, (unsigned)x2_bytes, (int)ntiles, (unsigned)yn_bytes, ny)
+                                                     (unsigned)y_bytes, (unsigned)x2_bytes, (int)ntiles, (unsigned)yn_bytes, ny, ao)
   const int nx = next ? a.next_y.c : 0;
-  if (dual) { if (nx == 64) RTD_SX(2, 2, false, 64); else if (nx == 128) RTD_SX(2, 2, false, 128); else RTD_SX(2, 2, false, 0); }
+  if (avg) {
+    if (a.x.c == 64) hipLaunchKernelGGL((conv1x1_sx_kernel<2, 0, true, 128, false, true>), grid, blk, 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes,
+                                        (unsigned)x2_bytes, (int)ntiles, (unsigned)yn_bytes, ny, ao);
+    else hipLaunchKernelGGL((conv1x1_sx_kernel<4, 0, true, 0, false, true>), grid, blk, 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes,
+                            (unsigned)x2_bytes, (int)ntiles, (unsigned)yn_bytes, ny, ao);
+  } else if (dual) { if (nx == 64) RTD_SX(2, 2, false, 64); else if (nx == 128) RTD_SX(2, 2, false, 128); else RTD_SX(2, 2, false, 0); }
   else if (a.x.c == 64 && res) { if (nx == 64) RTD_SX(2, 0, true, 64); else if (nx == 128) RTD_SX(2, 0, true, 128); else RTD_SX(2, 0, true, 0); }
   else if (a.x.c == 64) { if (nx == 64) RTD_SX(2, 0, false, 64); else if (nx == 128) RTD_SX(2, 0, false, 128); else RTD_SX(2, 0, false, 0); }
-  else if (a.x.c == 256 && y.dt == F32) hipLaunchKernelGGL((conv1x1_sx_kernel<8, 0, false, 0, true>), grid, blk, 0, s, k, (unsigned)x_bytes, 0u, (unsigned)y_bytes, 0u, (int)ntiles, 0u, ny);
+  else if (a.x.c == 256 && y.dt == F32) hipLaunchKernelGGL((conv1x1_sx_kernel<8, 0, false, 0, true>), grid, blk, 0, s, k, (unsigned)x_bytes, 0u, (unsigned)y_bytes, 0u, (int)ntiles, 0u, ny, ao);
   else if (a.x.c == 256 && res) RTD_SX(8, 0, true, 0);
   else if (a.x.c == 256) RTD_SX(8, 0, false, 0);
   else if (res) RTD_SX(4, 0, true, 0);

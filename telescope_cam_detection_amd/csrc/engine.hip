@@ -40,6 +40,7 @@ struct PlanOpts {
   int up_fold = 1;      // read the FPN's upsampled lateral straight from the half-size tensor (ConvArgs::x_up2)
   int arena_reuse = 1;  // backbone stages recycle their activation buffers
   int stem_fused_split = 1;   // f16x3 engine: backbone.stem.0 straight from the uint8 frames (hi/lo pairs made on the fly from the bytes)
+  int avg_fuse = 1;           // f16x3 engine: a stage's last expand conv also writes the 2 x 2 average the next stage's vd shortcut reads (ConvArgs::avg_y)
   int stem_pool_fuse = 1;     // f16x3 engine: backbone.stem.2 and the 3x3 / stride-2 max-pool in one pass (the conv rows are never written)
   int sel_fused = 1;    // LayerNorm + score head + class max of the query selection in one launch
   int dec_fused = 1;    // 0 = one launch per decoder op
@@ -501,12 +502,13 @@ struct Builder {
     }
     a.opts = &e->conv_opts;
     a.prefer256 = e->cfg.profile == RTD_PROFILE_THROUGHPUT;
+    if (avg_pending) { a.avg_y = avg_pending_y; if (dry) a.avg_y.p = nullptr; avg_pending = false; }
     slab_need = std::max(slab_need, conv_split_slab_bytes(a));
     const double M = (double)y.pixels();
     const double kreal = (double)k * k * (real_cin ? real_cin : x.c) + (x2 ? x2->c : 0);
     const double flops = 2.0 * M * y.c * kreal + (next_y ? 2.0 * M * y.c * next_y->c : 0.0);
     const double bytes = (double)x.pixels() * x.c * dtype_size(x.dt) + tbytes(y) + (double)y.c * K * dtype_size(x.dt) +
-                         (res ? tbytes(*res) : 0.0) + (x2 ? tbytes(*x2) : 0.0) + (next_y ? tbytes(*next_y) : 0.0);
+                         (res ? tbytes(*res) : 0.0) + (x2 ? tbytes(*x2) : 0.0) + (next_y ? tbytes(*next_y) : 0.0) + (a.avg_y.c ? tbytes(a.avg_y) : 0.0);
     auto ap = std::make_shared<ConvArgs>(a);
     if (!dry) {
       // chain: the previous conv launch of the plan prefetches THIS filter while it runs (ConvArgs::pf)
@@ -516,6 +518,9 @@ struct Builder {
     }
     push(name, "conv_igemm", flops, bytes, [ap](hipStream_t s) { launch_conv(*ap, s); });
   }
+  // set by the plan builder right before the conv that should also write the 2 x 2 average of its output (ConvArgs::avg_y); consumed by conv()
+  bool avg_pending = false;
+  Tensor avg_pending_y;
   std::shared_ptr<ConvArgs> last_conv;
   // two-pass split-K workspace of this plan: sized for the plan's own batch (the slice count depends on per-image extents only, so every
   // batch size up to max_batch runs the same arithmetic), allocated once every conv is known and handed to all of them
@@ -643,6 +648,8 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   int cin = c.embedding_size;
   bool c1_done = false;                                         // this block's c1 already ran inside the previous block's last conv
   Tensor t1_next;
+  bool have_prepooled = false;                                  // the 2 x 2 average of the stage input already exists (avg_fuse)
+  Tensor prepooled;
   for (int si = 0; si < 4; ++si) {
     const int cout = c.hidden_sizes[si];
     // Buffers are recycled inside a stage (rtd_debug_option "arena_reuse"): the blocks' outputs ping-pong between two buffers
@@ -685,10 +692,15 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       if (has_sc) {
         // stride 2: AvgPool2d(2,2,ceil) then 1x1 (HF:rt_detr_resnet.py:199-213); extents are even here
         if (stride == 2) {
-          Tensor pooled = B.act(P, n, oh, ow, cin);
-          B.push(pfx + ".avgpool", "avgpool", 4.0 * pooled.pixels() * cin, Builder::tbytes(cur) + Builder::tbytes(pooled),
-                 [cur, pooled](hipStream_t s) { launch_avgpool2(cur, pooled, s); });
-          sc_in = pooled;
+          if (have_prepooled) {
+            sc_in = prepooled;                                 // written by the previous stage's last conv (ConvArgs::avg_y)
+            have_prepooled = false;
+          } else {
+            Tensor pooled = B.act(P, n, oh, ow, cin);
+            B.push(pfx + ".avgpool", "avgpool", 4.0 * pooled.pixels() * cin, Builder::tbytes(cur) + Builder::tbytes(pooled),
+                   [cur, pooled](hipStream_t s) { launch_avgpool2(cur, pooled, s); });
+            sc_in = pooled;
+          }
         }
         if ((P == BF16 || SP) && e->opts.sc_fold) {
           // shapes only: would the kernels take the folded launch?  Asked for ONE image whatever this plan's batch: every plan
@@ -736,6 +748,20 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
           if (conv_next_supported(probe)) {
             t1_next = (same_stage && e->opts.arena_reuse) ? view(tb1, oh, ow, mid_n, "") : B.act(P, n, oh, ow, mid_n);
             nx = &t1_next; nx_name = (same_stage ? nm("backbone.s%d.b%d", si, bi + 1) : nm("backbone.s%d.b0", si + 1)) + ".c1"; c1_done = true;
+          }
+        }
+        if (SP && e->opts.avg_fuse && last && si + 1 < 4 && !fold_sc && (oh & 1) == 0 && (ow & 1) == 0) {
+          // the next stage's vd shortcut reads AvgPool2d(2, 2) of `out`: let this launch write it (shapes for ONE image decide, like every fusion)
+          ConvArgs probe;
+          probe.opts = &e->conv_opts;
+          probe.x = t2; probe.x.p = (void*)16; probe.x.n = 1;
+          probe.y = out; probe.y.p = (void*)16; probe.y.n = 1;
+          probe.res = res; probe.res.p = (void*)16; probe.res.n = 1; probe.res_mode = RES_PRE;
+          if (nx) { probe.next_y = *nx; probe.next_y.p = (void*)16; probe.next_y.n = 1; }
+          if (conv_avg_supported(probe)) {
+            prepooled = B.act(P, n, oh / 2, ow / 2, cout);
+            have_prepooled = true;
+            B.avg_pending = true; B.avg_pending_y = prepooled;
           }
         }
         if (fold_sc) B.conv(pfx + ".c3", t2, out, 1, 1, 0, ACT_RELU, nullptr, RES_NONE, 0, &sc_in, pfx + ".sc", 0, nx, nx_name, ACT_RELU);
@@ -1774,7 +1800,7 @@ int rtd_debug_option(const char* name, int value) {
   // created afterwards (and the kernel-level rtd_op_* / rtd_bench_* entry points), never a live handle
   const struct { const char* n; int* p; } plan_opts[] = {
       {"dec_stamps", &g_opts.dec_stamps}, {"dec_fused", &g_opts.dec_fused}, {"side_stream", &g_opts.side_stream}, {"sel_fused", &g_opts.sel_fused},
-      {"stem_fused_split", &g_opts.stem_fused_split}, {"stem_pool_fuse", &g_opts.stem_pool_fuse}, {"sc_fold", &g_opts.sc_fold}, {"arena_reuse", &g_opts.arena_reuse},
+      {"stem_fused_split", &g_opts.stem_fused_split}, {"stem_pool_fuse", &g_opts.stem_pool_fuse}, {"avg_fuse", &g_opts.avg_fuse}, {"sc_fold", &g_opts.sc_fold}, {"arena_reuse", &g_opts.arena_reuse},
       {"up_fold", &g_opts.up_fold}, {"attn_split", &g_opts.attn_split}, {"c1_fuse", &g_opts.c1_fuse}, {"dec_split", &g_opts.dec_split},
       {"profile_twice", &g_profile_twice}, {"bench_rewarm", &g_bench_rewarm},
   };
