@@ -24,6 +24,25 @@ def test_crop_geometry_matches_reference_arithmetic():
     assert 0 < n_none < 6000
     assert crop_rect({"x1": 10.9, "y1": 10.9, "x2": 41.1, "y2": 41.9}, hw, 32, 20) is None       # 31 px after truncation
     assert crop_rect({"x1": 0, "y1": 0, "x2": 100, "y2": 50}, (60, 120), 32, 20) == (0, 0, 120, 60)
+    # literal vectors worked out by hand from the reference's lines (src/two_stage_pipeline_yolox.py:245-283), not from either restatement:
+    #  int() truncates toward zero (:245-248), the size check precedes the padding (:256), the padding is int(extent * pct / 100) (:262-263),
+    #  x1 / y1 clamp to [0, w - 1] / [0, h - 1] and x2 / y2 to [0, w] / [0, h] (:276-279), empty rectangles are rejected (:281)
+    hd = (1080, 1920)
+    # (-3.7, 5.2, 120.9, 90.1) in a 100 x 110 frame: ints (-3, 5, 120, 90), extents 123 x 85, pads int(24.6) = 24 / int(17.0) = 17 -> (-27, -12, 144, 107) -> clamped
+    assert crop_rect({"x1": -3.7, "y1": 5.2, "x2": 120.9, "y2": 90.1}, (100, 110), 32, 20) == (0, 0, 110, 100)
+    # 33.3 %: extents 101 x 121 -> pads int(33.633) = 33, int(40.293) = 40
+    assert crop_rect({"x1": 200.9, "y1": 300.2, "x2": 301.0, "y2": 421.9}, hd, 32, 33.3) == (167, 260, 334, 461)
+    # a box right of the frame keeps a one-pixel column: x1 clamps to w - 1 = 1919, x2 to w = 1920 (the reference crops it)
+    assert crop_rect({"x1": 2000, "y1": 100, "x2": 2100, "y2": 200}, hd, 32, 20) == (1919, 80, 1920, 220)
+    # ... and one below it a one-pixel row
+    assert crop_rect({"x1": 100, "y1": 1100, "x2": 200, "y2": 1200}, hd, 32, 20) == (80, 1079, 220, 1080)
+    # a box left of the frame: x2 clamps to 0 = x1 -> rejected
+    assert crop_rect({"x1": -300, "y1": 100, "x2": -200, "y2": 200}, hd, 32, 20) is None
+    # extent == min_crop_size passes (the check is `<`), one pixel less does not; pads int(12.8) = 12
+    assert crop_rect({"x1": 0, "y1": 0, "x2": 64, "y2": 64}, hd, 64, 20) == (0, 0, 76, 76)
+    assert crop_rect({"x1": 0, "y1": 0, "x2": 63.9, "y2": 64}, hd, 64, 20) is None
+    for case in ({"x1": -3.7, "y1": 5.2, "x2": 120.9, "y2": 90.1}, {"x1": 2000, "y1": 100, "x2": 2100, "y2": 200}, {"x1": -300, "y1": 100, "x2": -200, "y2": 200}):
+        assert s2o.crop_rect(case, hd, 32, 20) == crop_rect(case, hd, 32, 20)                  # the oracle's restatement agrees on them too
     b = CropBatcher(input_size=64)
     kept, rects = b.rects_for([{"bbox": {"x1": 5, "y1": 5, "x2": 10, "y2": 10}}, {"bbox": {"x1": 100, "y1": 100, "x2": 300, "y2": 260}}], hw)
     assert kept == [1] and rects == [(60, 68, 340, 292)]
