@@ -40,6 +40,7 @@ struct PlanOpts {
   int up_fold = 1;      // read the FPN's upsampled lateral straight from the half-size tensor (ConvArgs::x_up2)
   int arena_reuse = 1;  // backbone stages recycle their activation buffers
   int stem_fused_split = 1;   // f16x3 engine: backbone.stem.0 straight from the uint8 frames (hi/lo pairs made on the fly from the bytes)
+  int aifi_pair = 1;          // f16x3 engine, un-fused AIFI (encoders wider than 256 channels): its linears on the pair kernels instead of fp32 MFMAs
   int avg_fuse = 1;           // f16x3 engine: a stage's last expand conv also writes the 2 x 2 average the next stage's vd shortcut reads (ConvArgs::avg_y)
   int stem_pool_fuse = 1;     // f16x3 engine: backbone.stem.2 and the 3x3 / stride-2 max-pool in one pass (the conv rows are never written)
   int sel_fused = 1;    // LayerNorm + score head + class max of the query selection in one launch
@@ -852,17 +853,21 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   } else {
   Tensor xp = B.act(F32, n, L, 1, d);
   B.push("enc.aifi.addpos", "add", (double)xp.pixels() * d, 3 * Builder::tbytes(xp), [t0, pos, xp](hipStream_t s) { launch_add(t0, pos, xp, s); });
-  Tensor qk = B.linear("enc.aifi.qk", xp, 2 * d, F32, ACT_NONE);
-  Tensor vv = B.linear("enc.aifi.v", t0, d, F32, ACT_NONE);
+  // f16x3 plans run the five linears on the pair kernels (inputs converted to hi / lo rows, fp32 rows out; fc1 hands fc2 a pair tensor):
+  // on fp32 MFMAs they were 0.33 ms of R101 1280's step.  The attention itself stays exact fp32.
+  const bool aifi_pair = SP && e->opts.aifi_pair && d % SPLIT_GROUP == 0 && c.enc_ffn % SPLIT_GROUP == 0;
+  auto pin = [&](const char* nm_, const Tensor& x) { return aifi_pair ? B.to_split(std::string(nm_) + ".in_split", x) : x; };
+  Tensor qk = B.linear("enc.aifi.qk", pin("enc.aifi.qk", xp), 2 * d, F32, ACT_NONE);
+  Tensor vv = B.linear("enc.aifi.v", pin("enc.aifi.v", t0), d, F32, ACT_NONE);
   Tensor att = B.act(F32, n, L, 1, d);
   {
     const int heads = c.enc_heads;
     B.push("enc.aifi.attn", "attention", 4.0 * n * (double)L * L * d, Builder::tbytes(qk) + 2 * Builder::tbytes(vv),
            [qk, vv, att, heads](hipStream_t s) { launch_attention(qk, vv, att, heads, s); });
   }
-  Tensor ao = B.linear("enc.aifi.o", att, d, F32, ACT_NONE, &t0);
+  Tensor ao = B.linear("enc.aifi.o", pin("enc.aifi.o", att), d, F32, ACT_NONE, &t0);
   Tensor t1 = B.layernorm("enc.aifi.ln1", ao, F32);
-  Tensor f1 = B.linear("enc.aifi.fc1", t1, c.enc_ffn, F32, ACT_GELU);
+  Tensor f1 = B.linear("enc.aifi.fc1", pin("enc.aifi.fc1", t1), c.enc_ffn, aifi_pair ? F16X2 : F32, ACT_GELU);
   Tensor f2 = B.linear("enc.aifi.fc2", f1, d, F32, ACT_NONE, &t1);
   t2 = B.layernorm("enc.aifi.ln2", f2, P, "aifi_out");
   }
@@ -1800,7 +1805,7 @@ int rtd_debug_option(const char* name, int value) {
   // created afterwards (and the kernel-level rtd_op_* / rtd_bench_* entry points), never a live handle
   const struct { const char* n; int* p; } plan_opts[] = {
       {"dec_stamps", &g_opts.dec_stamps}, {"dec_fused", &g_opts.dec_fused}, {"side_stream", &g_opts.side_stream}, {"sel_fused", &g_opts.sel_fused},
-      {"stem_fused_split", &g_opts.stem_fused_split}, {"stem_pool_fuse", &g_opts.stem_pool_fuse}, {"avg_fuse", &g_opts.avg_fuse}, {"sc_fold", &g_opts.sc_fold}, {"arena_reuse", &g_opts.arena_reuse},
+      {"stem_fused_split", &g_opts.stem_fused_split}, {"stem_pool_fuse", &g_opts.stem_pool_fuse}, {"avg_fuse", &g_opts.avg_fuse}, {"aifi_pair", &g_opts.aifi_pair}, {"sc_fold", &g_opts.sc_fold}, {"arena_reuse", &g_opts.arena_reuse},
       {"up_fold", &g_opts.up_fold}, {"attn_split", &g_opts.attn_split}, {"c1_fuse", &g_opts.c1_fuse}, {"dec_split", &g_opts.dec_split},
       {"profile_twice", &g_profile_twice}, {"bench_rewarm", &g_bench_rewarm},
   };
