@@ -161,7 +161,9 @@ int64_t rtd_arena_bytes(rtd_handle h);
  *   sc_fold [1] projection shortcut folded into the block's last conv | up_fold [1] FPN upsample folded into the CSP's first conv |
  *   c1_fuse [1] a block's reduce conv computed inside the previous block's expand conv (bf16: stage 0/1; f16x3: stage 0 and the first block
  *   of stage 1) | attn_split [2] self-attention on fp16-pair MFMAs (bit 0 AIFI, bit 1 decoder) |
- *   arena_reuse [1] | stem_fused_split [1] (f16x3): stem.0 straight from the uint8 frames | side_stream [7: bit 0 query
+ *   arena_reuse [1] | stem_fused_split [1] (f16x3): stem.0 straight from the uint8 frames | stem_pool_fuse [1] (f16x3): stem.2 and the 3x3/s2
+ *   max-pool in one pass | avg_fuse [1] (f16x3): a stage's last expand conv also writes the next stage's vd-shortcut average |
+ *   aifi_pair [1] (f16x3): the un-fused AIFI's linears on the pair kernels | side_stream [7: bit 0 query
  *   selection on a second stream beside the value projection, bit 1 decoder input projections beside the PAN path, bit 2 encoder input
  *   projections beside stages 2 / 3 and AIFI] | dec_fused [1],
  *   dec_split [1: 0 fp32 MFMA, 2 hi-only filters], sel_fused [1] | dec_stamps [0]
