@@ -2398,7 +2398,7 @@ __global__ __launch_bounds__(256) void k_pool_fixup(const PoolOut po, int tiles_
   const bool up = j == 0 && ty > 0, left = k == 0 && tx > 0;
   if (!up && !left) return;
   const long long pix = (long long)b * po.bstride + ((long long)py * po.OW + px) * po.ldy;
-  float v[8], w[8];
+  float v[8];
   split_load8(po.y, pix, cc, v);
   const int grp = cc >> 5, cg = cc & 31;
   auto row_at = [&](int tl, int p) {      // side_row[tl][p][grp][hi | lo]
@@ -2422,7 +2422,6 @@ __global__ __launch_bounds__(256) void k_pool_fixup(const PoolOut po, int tiles_
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], (float)hh[e] + (float)ll[e]);
   }
-  (void)w;
   split_store8(po.y, pix, cc, v);
 }
 

@@ -610,7 +610,9 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     Tensor probe1 = probe.x; probe1.n = 1;          // asked for ONE image: every plan of a handle makes the same choice
     ConvArgs probe_one = probe; probe_one.x = probe1; probe_one.y.n = 1;
     Tensor pv1 = pvp; pv1.n = 1;
-    const bool fuse = SP && e->opts.stem_pool_fuse && conv_pool_supported(probe_one, pv1);
+    // (conv -> pool and the fused pass agree bit for bit, so the side buffers' 2 GiB descriptor limit may decide per batch size)
+    const long long pool_tiles = (long long)n * ((w + 31) / 32) * ((h + 7) / 8);
+    const bool fuse = SP && e->opts.stem_pool_fuse && conv_pool_supported(probe_one, pv1) && pool_tiles * 8192 < (1ll << 31);
     if (fuse) {
       h = ph; w = pw;
       cur = B.act(P, n, h, w, c.embedding_size, "stem");
