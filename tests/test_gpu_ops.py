@@ -267,7 +267,7 @@ def test_conv(L, dt, case):
             tol = dict(atol=2e-3, rtol=2e-3)       # bf16 products are exact in fp32; only accumulation order differs
         else:
             tol = dict(atol=2e-2, rtol=1e-2)       # + one bf16 rounding of the output
-        torch.testing.assert_close(got, y, **tol)
+        torch.testing.assert_close(got, y, **tol, msg=lambda m: f"conv_mode {mode} out_f32 {out_f32} {case}: {m}")
     _capi.debug_option("conv_mode", 0)
     _capi.debug_option("stream_slab", 1)
 
