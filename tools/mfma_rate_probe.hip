@@ -76,6 +76,17 @@ int main() {
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
       }
+      float ms = 0.f;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      CHECK(hipMemcpy(ho.data(), out, ho.size() * 8, hipMemcpyDeviceToHost));
+      double cyc = 0, rt = 0;
+      for (int w = 0; w < cus * waves; ++w) { cyc += ho[2 * w]; rt += ho[2 * w + 1]; }
+      cyc /= cus * waves; rt /= cus * waves;
+      const double mfmas_per_wave = (double)iters * 16;
+      const double ghz = cyc / (rt * 10.0);                      // 100 MHz real-time ticks -> ns
+      const double flops = mfmas_per_wave * cus * waves * 16.0 * 16.0 * 32.0 * 2.0;
+      printf("%-7s operands, %d waves/CU: %.1f shader clocks per MFMA per wave (per SIMD: %.1f), core clock %.3f GHz, kernel %.3f ms, %.0f TFLOP/s\n",
+             rnd ? "random" : "zero", waves, cyc / mfmas_per_wave, cyc / mfmas_per_wave / (waves / 4.0), ghz, ms, flops / (ms * 1e-3) / 1e12);
       if (waves == 4) {
         // dependent chains: NACC accumulators in rotation (1 = every MFMA waits for the previous one's result)
         auto chain = [&](auto kern, int nacc) {
@@ -89,17 +100,6 @@ int main() {
         };
         chain(k_mfma<1>, 1); chain(k_mfma<2>, 2); chain(k_mfma<3>, 3); chain(k_mfma<4>, 4); chain(k_mfma<8>, 8);
       }
-      float ms = 0.f;
-      CHECK(hipEventElapsedTime(&ms, e0, e1));
-      CHECK(hipMemcpy(ho.data(), out, ho.size() * 8, hipMemcpyDeviceToHost));
-      double cyc = 0, rt = 0;
-      for (int w = 0; w < cus * waves; ++w) { cyc += ho[2 * w]; rt += ho[2 * w + 1]; }
-      cyc /= cus * waves; rt /= cus * waves;
-      const double mfmas_per_wave = (double)iters * 16;
-      const double ghz = cyc / (rt * 10.0);                      // 100 MHz real-time ticks -> ns
-      const double flops = mfmas_per_wave * cus * waves * 16.0 * 16.0 * 32.0 * 2.0;
-      printf("%-7s operands, %d waves/CU: %.1f shader clocks per MFMA per wave (per SIMD: %.1f), core clock %.3f GHz, kernel %.3f ms, %.0f TFLOP/s\n",
-             rnd ? "random" : "zero", waves, cyc / mfmas_per_wave, cyc / mfmas_per_wave / (waves / 4.0), ghz, ms, flops / (ms * 1e-3) / 1e12);
     }
   }
   return 0;
