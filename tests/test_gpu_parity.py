@@ -775,10 +775,11 @@ def test_f16x3_non_square_frames_with_ragged_tiles_against_the_oracle():
     eng.close()
 
 
-@pytest.mark.parametrize("aname,size,bs", [("r34", (640, 640), 2), ("r101", (640, 640), 1), ("r18", (320, 320), 5)])
+@pytest.mark.parametrize("aname,size,bs", [("r34", (640, 640), 2), ("r101", (640, 640), 1), ("r18", (320, 320), 5), ("r50", (1280, 1280), 1), ("r50", (736, 1280), 2)])
 def test_f16x3_other_backbones_and_sizes_against_the_oracle(aname, size, bs):
-    """The variants the reference's config files name besides R50 (r18vd / r34vd basic blocks, r101vd) and a small input / odd batch: default
-    engine vs the oracle at the north-star tolerance (no golden file: the oracle itself is pinned to HF on the committed cases)."""
+    """The variants the reference's config files name besides R50 (r18vd / r34vd basic blocks, r101vd), a small input / odd batch, R50 at 1280 px
+    and on a 16:9 map (736 x 1280: every level non-square): default engine vs the oracle at the north-star tolerance (no golden file: the
+    oracle itself is pinned to HF on the committed cases)."""
     from telescope_cam_detection_amd.arch import ARCHS
     from telescope_cam_detection_amd.synth import noise_frame, scene_frame
     arch = ARCHS[aname]
