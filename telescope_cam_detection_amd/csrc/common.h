@@ -8,10 +8,10 @@
 
 namespace rtd {
 
-// F16X2 ("split"): every value is carried as two bf16, x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <= 2^-18 |x|).
+// F16X2 ("split"): every value is carried as two IEEE fp16, x = hi + lo with hi = fp16(x), lo = fp16(x - hi) (22 significant bits; see sp16 below).
 // Storage: a pixel's channels in groups of 32, each group 128 bytes = [32 x hi | 32 x lo]; 4 bytes per channel, so `ld`, `c` and
 // slice_c() count real channels exactly as for F32 (slices on multiples of 32 channels).  A K-step of the LDS-DMA conv kernels (128
-// bytes per pixel row) is then one channel group, and hi*hi + hi*lo + lo*hi runs as three bf16 MFMAs on the same staged bytes
+// bytes per pixel row) is then one channel group, and hi*hi + hi*lo + lo*hi runs as three fp16 MFMAs on the same staged bytes
 // (rtd_config.precision = RTD_PREC_F16X3: fp32-grade products at 3/16 of the fp32 MFMA cost).
 enum DType : int { BF16 = 0, F32 = 1, U8 = 2, I32 = 3, F16X2 = 4 };
 constexpr int SPLIT_GROUP = 32;   // channels per [hi | lo] group of a F16X2 tensor
@@ -238,8 +238,8 @@ struct DecLN {
 struct DecArgs {
   int mode;                 // 0 = prologue (enc_bbox head + ref init + next projections), 1 = layer, 2 = last layer (+ class head),
                             // 3 = AIFI prologue (x + pos -> q, K/V fragments), 4 = AIFI encoder layer
-  int attn_split;           // bf16 engine: self-attention on hi/lo bf16 MFMAs with K / V stored as split fragments (0: exact fp32 MFMAs, A/B + tests)
-  int split;                // 1: the linear layers run as 3 bf16 MFMAs on hi/lo splits of both operands (bf16 engine), 0: exact fp32 MFMA
+  int attn_split;           // bf16 / f16x3 engines: self-attention on hi/lo fp16 MFMAs with K / V stored as split fragments (0: exact fp32 MFMAs, A/B + tests)
+  int split;                // 1: the linear layers run as 3 fp16 MFMAs on hi/lo splits of both operands (bf16 / f16x3 engines), 0: exact fp32 MFMA
   int B, Q, D, heads, S, n_levels, n_points, ffn, C;
   float offset_scale;
   // per-row state (global, fp32)

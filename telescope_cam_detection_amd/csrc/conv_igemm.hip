@@ -986,7 +986,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void conv_igemm_wsx_ker
 // as 1014 tiles would: tools/conv_bench.py --only quant; 40^2 maps give 200 tiles for 256 CUs, 20^2 maps 100).  Here the host picks the
 // tile height so that the grid is close to a whole number of rounds of the chip (launch_conv_split), e.g. 208 x 128 for 80^2 x 256
 // channels: 494 blocks = 2 rounds of one block per CU, 96 % full.
-// Wave layout 1 x 4: every MFMA wave owns ALL MT pixel tiles and BN / 4 channels (any MT balances), v_mfma_f32_16x16x32_bf16, its
+// Wave layout 1 x 4: every MFMA wave owns ALL MT pixel tiles and BN / 4 channels (any MT balances), v_mfma_f32_16x16x32_f16, its
 // 2 (BN = 128) or 1 (BN = 64) filter fragment pairs live for the K-step, pixel fragments tile by tile.  Loader role, LDS image, swizzle and
 // barrier protocol as conv_igemm_wsx_kernel; the A part of a stage holds AROWS = MT x 16 rounded up to 32 rows.
 template <int STAGES, int BN, int MT>
@@ -2430,7 +2430,7 @@ __global__ __launch_bounds__(256) void k_pool_fixup(const PoolOut po, int tiles_
 // 128 x 64 implicit-GEMM tile, whose nine taps re-stage every input pixel and whose LDS traffic per MFMA is the highest of all tiles).
 //   * tile 8 x 16 output pixels; the (8+2) x (16+2) x 256-byte input patch is staged once by LDS-DMA (double buffered, source-side XOR swizzle:
 //     16-byte slot c of pixel pi holds chunk c ^ (pi & 15), so the 16 consecutive pixels of a B-fragment read hit 16 different bank groups);
-//   * wave = (16-channel group, row half): its 16 x 576 filter slice, hi and lo, lives in 144 VGPRs as v_mfma_f32_16x16x32_bf16 A operands;
+//   * wave = (16-channel group, row half): its 16 x 576 filter slice, hi and lo, lives in 144 VGPRs as v_mfma_f32_16x16x32_f16 A operands;
 //   * a patch-row fragment (one ds_read_b128 pair: hi, lo) serves up to three output rows (kh = patch row - output row): 72 fragment reads for
 //     216 MFMAs per wave and tile - the loop is MFMA-bound, not LDS-bound;
 //   * the tile's 128 x 64 outputs are collected in LDS as F16X2 rows and stored row-shaped (16 lanes = one pixel's 256-byte run).
@@ -2610,7 +2610,7 @@ static bool dispatch_reg(const ConvOpts& o, const ConvK& k, const ConvArgs& a, l
 // 32 (tools/stream_probe.hip: 44 us against 53-61 us for the stage-0 c3 byte mix)
 // NEXT (the block's NW waves = the N / 64 channel groups of ONE 32-pixel tile; N = 256 or 512): the following N -> N / 4 reduce conv
 // runs on the tile while the slabs still hold y: wave w computes output channels 16 w .. 16 w + 15 of the 32 pixels with N / 16
-// v_mfma_f32_16x16x32_bf16 (its 16 x N filter slice stays in registers), reading every wave's slab between two block barriers.
+// v_mfma_f32_16x16x32_f16 (its 16 x N filter slice stays in registers), reading every wave's slab between two block barriers.
 template <int NKK, int THREADS, bool DUAL = false, bool SLAB = true, bool NEXT = false>   // DUAL: the second half of K comes from ConvK::x2 (same channel count as x)
 __global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kernel(const ConvK a, unsigned x_bytes, unsigned r_bytes, unsigned y_bytes, unsigned x2_bytes, int CG, int ntiles, unsigned yn_bytes = 0) {
   static_assert(!NEXT || SLAB, "the fused reduce conv reads the waves' slabs");
@@ -2647,7 +2647,7 @@ __global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kern
   char* sl = slabs[SLAB ? wv : 0];
   char* sl_acc = sl + pl * SROW + h * 64;                      // this lane's 64 bytes in accumulator shape (pixel pl, channels 32h..)
   char* sl_row = sl + (lane >> 3) * SROW + (lane & 7) * 16;    // ... in row shape (pixel lane/8 + 8j, 16-byte chunk lane%8)
-  // NEXT: this wave's 16 x 256 slice of the following filter as v_mfma_f32_16x16x32_bf16 A operands (row lane & 15, k 32 s + 8 (lane >> 4) ..)
+  // NEXT: this wave's 16 x 256 slice of the following filter as v_mfma_f32_16x16x32_f16 A operands (row lane & 15, k 32 s + 8 (lane >> 4) ..)
   bf16x8 w1f[NS];
   f32x4 b1v = {0.f, 0.f, 0.f, 0.f};
   const __amdgpu_buffer_rsrc_t ryn = __builtin_amdgcn_make_buffer_rsrc((void*)(NEXT ? a.next_y : a.y), 0, NEXT ? yn_bytes : 0u, 0x00020000);
@@ -3116,13 +3116,13 @@ int conv_kpad_split(int K) { return 2 * ((K + SPLIT_GROUP - 1) / SPLIT_GROUP * S
 //     filter, hi and lo, in registers (4 x K/16 fragments); the block's 8 waves cover 256 channels of a 32-pixel tile, wider
 //     layers run several 256-channel blocks per tile on one XCD; persistent grid, tiles cyclic per tile stream;
 //   * pixel fragments come straight from global memory in MFMA B-operand shape (lane = pixel, 16 bytes of K; the 8 waves' copies
-//     hit in L1); three v_mfma_f32_32x32x16_bf16 per 16-deep chunk (w_hi x_lo, w_lo x_hi, w_hi x_hi);
+//     hit in L1); three v_mfma_f32_32x32x16_f16 per 16-deep chunk (w_hi x_lo, w_lo x_hi, w_hi x_hi);
 //   * filter rows are permuted at load time (MFMA row 8b+4h+r <- channel 16h+4b+r): a lane's 16 accumulators are 16 CONSECUTIVE
 //     channels of its pixel; residual and output cross a wave-private slab (32 rows x 128 bytes + skew) so that their global
 //     accesses are row-shaped (8 lanes x 16 bytes = one pixel's 128-byte run);
 //   * NEXTN (N == 256): the following 256 -> NEXTN reduce conv (the next block's c1) runs on the tile while the eight slabs
 //     hold y as hi/lo sp16 = exactly what that conv would read back from HBM: wave w takes 16 output channels (NEXTN = 64: of one
-//     16-pixel half) with 8 x 3 v_mfma_f32_16x16x32_bf16, its 16 x 256 filter slice (hi and lo) in registers, between two block
+//     16-pixel half) with 8 x 3 v_mfma_f32_16x16x32_f16, its 16 x 256 filter slice (hi and lo) in registers, between two block
 //     barriers.  The c1 launch and its read of the 4-bytes-per-channel y tensor (R50 bs 8 stage 0: 210 MB) disappear.
 // Arithmetic per output: K chunks in order into a zero accumulator (lo-terms first inside a chunk), + bias, + residual (hi + lo),
 // activation, one hi/lo rounding.  Kernel choice depends on the per-IMAGE extents only, so every batch size runs the same arithmetic.

@@ -131,7 +131,7 @@ __device__ __forceinline__ void split_rows(const float* Xs, int ldx, int K, sp16
 }
 
 // The split form of row_gemm: A = (Ah + Al) [16][K] bf16 in LDS, W = hi + lo bf16 fragments (DecLin, split layout), three
-// v_mfma_f32_16x16x32_bf16 per 32-deep chunk (lo*hi, hi*lo, hi*hi; fp32 accumulate) instead of 8 v_mfma_f32_16x16x4_f32:
+// v_mfma_f32_16x16x32_f16 per 32-deep chunk (lo*hi, hi*lo, hi*hi; fp32 accumulate) instead of 8 v_mfma_f32_16x16x4_f32:
 // 5x less MFMA time for the same filter bytes, products exact to ~2^-17.  A lane's fragments: A[row = lane & 15][32c + 8 (lane >> 4) .. +7],
 // W[n0 + (lane & 15)][same k].  Output: fp32 Ys and / or a hi/lo split (Yh, Yl) for a following GEMM.
 template <int ACT, bool WLO = true>   // WLO = false: the filter's lo half is neither loaded nor multiplied (hi-only filter, split activations)
@@ -410,8 +410,8 @@ __device__ void self_attention_rows(const DecArgs& a, const float* sQ, int ldq, 
   }
 }
 
-// The bf16 engine's form: the same transposed scheme on v_mfma_f32_16x16x32_bf16 with hi/lo splits of every operand (x = hi + lo to
-// 2^-17: hi*hi + hi*lo + lo*hi, fp32 accumulate), 12 bf16 MFMAs of 16 cycles per PAIR of key tiles instead of 32 fp32 MFMAs of 32 - the
+// The pair form (bf16 and f16x3 engines): the same transposed scheme on v_mfma_f32_16x16x32_f16 with hi/lo fp16 splits of every operand (x = hi + lo to
+// 2^-22: hi*hi + hi*lo + lo*hi, fp32 accumulate), 12 16-bit MFMAs of 16 cycles per PAIR of key tiles instead of 32 fp32 MFMAs of 32 - the
 // phase is MFMA-issue bound (two waves per SIMD; prefetch depth and tile-level parallelism changed nothing).
 //   S^T_e = K_e Q^T           : one MFMA covers the whole head dim (32); K fragments [hi | lo][lane][8]: key lane & 15, dims 8 (lane >> 4) ..
 //   O^T  += V_pair^T P_pair^T : the 32-deep contraction runs over the pair's keys in the order (tile e, key 4 kq + r) -> position
@@ -528,7 +528,7 @@ __device__ __forceinline__ void touch_weights(const DecLin& L, int part, int npa
   for (unsigned l = part + nparts * tid; l < lines; l += nparts * NT) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (dec_lds_ptr_t)dummy, 4, l << 7, 0, 0, 0);
 }
 
-// SPLIT: the linear layers take hi/lo bf16 splits of their operands (row_gemm_split); every fp32 A operand of K <= 256 is split
+// SPLIT: the linear layers take hi/lo fp16 splits of their operands (row_gemm_split); every fp32 A operand of K <= 256 is split
 // into the sXh/sXl staging rows right before its GEMM, the two wide ones (FFN hidden 1024, qpos hidden 512) are written as
 // splits by the producing GEMM straight into the sF region (same bytes as the fp32 rows they replace).
 template <int SPLIT>

@@ -33,9 +33,9 @@ struct PlanOpts {
   int dec_split = 1;    // bf16 / f16x3 engines run the fused decoder / AIFI linears as bf16 hi/lo splits (0: fp32 MFMA, 2: bf16 filters)
   int sc_fold = 1;      // fold a block's projection shortcut into its last conv (ConvArgs::x2)
   int c1_fuse = 1;      // bf16 plans run a stage-0 block's reduce conv inside the previous block's last conv
-  // self-attention on hi/lo bf16 MFMAs - bit 0 AIFI, bit 1 decoder.  Default: decoder only (logits agree with the fp32-MFMA attention
-  // to 1e-6).  In AIFI the softmax arguments reach tens and the 2^-16 product error becomes 1.7e-4 on the layer output: that layer
-  // stays on fp32 MFMAs (10 us per step)
+  // self-attention on hi/lo fp16 MFMAs - bit 0 AIFI, bit 1 decoder.  Default: decoder only (logits agree with the fp32-MFMA attention
+  // to 1e-6).  In AIFI the softmax arguments reach tens (measured with round 2's bf16 pairs: a 2^-16 product error became 1.7e-4 on the
+  // layer output): that layer stays on fp32 MFMAs (10 us per step)
   int attn_split = 2;
   int up_fold = 1;      // read the FPN's upsampled lateral straight from the half-size tensor (ConvArgs::x_up2)
   int arena_reuse = 1;  // backbone stages recycle their activation buffers
@@ -562,7 +562,7 @@ struct Builder {
 void build_graph(rtd_engine* e, Builder& B, int n) {
   const rtd_config& c = e->cfg;
   const int P = e->P;
-  const bool SP = P == F16X2;            // rtd_config.precision = RTD_PREC_F16X3: the trunk carries hi/lo bf16 pairs
+  const bool SP = P == F16X2;            // rtd_config.precision = RTD_PREC_F16X3: the trunk carries hi/lo fp16 pairs
   const int H = c.input_h, W = c.input_w;
   Plan* plan = B.plan;
   auto nm = [](const char* fmt, int a = 0, int b = 0) {
