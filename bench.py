@@ -25,7 +25,7 @@ stream, hipGraph and camera group, taking the K timed steps round-robin - the re
 per camera group sharing the GPU, main.py:1236-1291); every step is still one full bs-8 pass.
 
 --collate at N = 1: the RCCL collate step runs on a world-size-1 `nccl` group exactly as it does at N > 1 (same all_gather_into_tensor
-on the engine's stream over the zero-copy view of the result block), `value` includes it and `collate` reports its cost per step.
+over the zero-copy view of the result block, ordered behind the forward by the engine's event), `value` includes it and `collate` reports its cost per step.
 
 Prints ONE JSON line on rank 0 with the contract fields plus:
   roofline     - MFMA roofline of the dominant kernel family (conv_igemm), from HIP-event timings of every launch on the
@@ -56,13 +56,6 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16x3": 2500.0, "fp32": 157.3}   # /opt/ski
 MFMA_PER_PRODUCT = {"bf16": 1, "f16x3": 3, "fp32": 1}                  # MFMA flops issued per algorithmic flop
 HBM_PEAK_GBS = 8000.0
 CANON_GFLOP_PER_FRAME = {"r18": 60.53, "r50": 133.91}  # BASELINE.md 3 @640x640
-
-
-class _DevPtr:
-    """zero-copy torch view of a raw device pointer (the engine's result block)"""
-
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
 def csrc_sha() -> str:
@@ -165,7 +158,7 @@ def main():
 
     from telescope_cam_detection_amd import _capi
     from telescope_cam_detection_amd.arch import ARCHS
-    from telescope_cam_detection_amd.shard import collate_blocks
+    from telescope_cam_detection_amd.shard import collate_after
     from telescope_cam_detection_amd.synth import noise_frame
     from telescope_cam_detection_amd.weights import fold_weights, pack_blob, synth_weights
 
@@ -195,7 +188,9 @@ def main():
         # frame i of config c = default_rng(1000*c+i).integers(0,255,(H,W,3),uint8); camera k -> rank k
         frames_of = [[torch.from_numpy(noise_frame(2000 + (rank * S + si) * B + i, H, H)).cuda() for i in range(B)] for si in range(S)]
         prepared = [e.make_async_args(f) for e, f in zip(engs, frames_of)]
-        streams = [torch.cuda.ExternalStream(e.stream(), device=torch.device("cuda", local_rank)) for e in engs]
+        # torch-owned streams for what torch / RCCL enqueue beside an engine (crop batch, all-gather); the engines' own streams stay
+        # inside the library and are ordered against these through the library's events (shard.collate_after)
+        streams = [torch.cuda.Stream(device=torch.device("cuda", local_rank)) for e in engs]
         gathered = [torch.empty(world * B * Q * 6, dtype=torch.float32, device="cuda") for _ in range(S)] if collate else None
 
         def step(k):
@@ -204,10 +199,7 @@ def main():
             if crops is not None:
                 crops(engs[si], frames_of[si], streams[si])
             if collate:
-                ptr, n = engs[si].result_block()
-                block = torch.as_tensor(_DevPtr(ptr, n), device=f"cuda:{local_rank}")
-                with torch.cuda.stream(streams[si]):              # ordered after the forward on that engine's stream
-                    collate_blocks(block, out=gathered[si])
+                collate_after(engs[si], gathered[si], streams[si])   # all-gather ordered after this engine's forward, next forward after it
 
         for k in range(args.warmup):
             step(k)
@@ -255,7 +247,7 @@ def main():
             e.close()
         out["collate"] = {"ms_per_step_with": round(1000.0 * elapsed / args.steps, 4), "ms_per_step_without": round(1000.0 * el0 / args.steps, 4),
                           "all_gather_us_per_step": round(1e6 * (elapsed - el0) / args.steps, 1), "bytes_per_rank": B * Q * 6 * 4,
-                          "note": "torch.distributed all_gather_into_tensor (backend nccl = RCCL) on the engine's HIP stream over a zero-copy view of rtd_result_block"}
+                          "note": "torch.distributed all_gather_into_tensor (backend nccl = RCCL) over a zero-copy view of rtd_result_block, on a torch-owned stream ordered after the forward by the engine's own event (rtd_signal_stream / rtd_wait_stream)"}
         elapsed, engs, frames_of = measure(args.precision, S, crops_fn)       # handles for the profile / latency legs below
         eng, frames = engs[0], frames_of[0]
     if crop_info:

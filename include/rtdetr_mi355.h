@@ -56,7 +56,7 @@ typedef struct rtd_config {
   int32_t precision;        /* RTD_PREC_* : storage/MFMA type of conv + large token GEMMs */
   int32_t max_batch;        /* largest n accepted by rtd_infer* */
   int32_t input_h, input_w; /* <- `input_size` (:35); must be multiples of 32 */
-  int32_t use_graph;        /* 1: capture one hipGraph per batch size and replay it */
+  int32_t use_graph;        /* 1: one hipGraph per batch size, built node by node from the plan (never stream-captured), replayed per call */
   /* architecture (HF:rt_detr/configuration_rt_detr_resnet.py, rt_detr_v2/configuration_rt_detr_v2.py) */
   int32_t layer_type;       /* RTD_LAYER_* */
   int32_t depths[4];
@@ -118,14 +118,41 @@ int rtd_infer(rtd_handle h, int32_t n, const uint8_t* const* frames_bgr_hwc, con
 int rtd_infer_raw(rtd_handle h, int32_t n, const uint8_t* const* frames_bgr_hwc, const int32_t* hw,
                   int32_t frames_on_device, int32_t* labels, float* boxes, float* scores);
 
-/* Asynchronous device-resident variant used by the multi-camera shard and the benchmark:
- * enqueues preprocess + network + post-process on the handle's stream and returns.  The result block
- * stays on the device: [n][Q][6] fp32 rows (label, score, x1, y1, x2, y2) - the fixed-size block each
- * rank contributes to the all-gather.  frames must be device pointers. */
-int rtd_infer_async(rtd_handle h, int32_t n, const uint8_t* const* frames_dev, const int32_t* hw);
+/* Pipelined form of detect_batch (src/rtdetr_detector.py:307-403 called by the batcher, src/shared_inference_coordinator.py:250),
+ * also used by the multi-camera shard and the benchmark: rtd_infer_async enqueues upload + preprocess + network + post-process on the
+ * handle's stream and returns; rtd_collect blocks for THAT batch and returns rtd_infer's rows.  A handle holds ONE batch in flight
+ * (a second rtd_infer_async first waits for the previous batch).  Host frames (frames_on_device = 0) are copied into a pinned staging
+ * buffer of the handle before the call returns (the caller's buffers are free again) and reach HBM by one asynchronous DMA; device
+ * frames must stay alive until rtd_collect / rtd_sync.  Everything is plain HIP inside the library: no torch stream, event or
+ * allocator takes part.  The result block also stays on the device: [n][Q][6] fp32 rows (label, score, x1, y1, x2, y2) - the
+ * fixed-size block each rank contributes to the all-gather - see rtd_result_block. */
+int rtd_infer_async(rtd_handle h, int32_t n, const uint8_t* const* frames_bgr_hwc, const int32_t* hw, int32_t frames_on_device);
+int rtd_collect(rtd_handle h, float conf_threshold, int32_t wildlife_only, rtd_det* out, int32_t* counts);
 int rtd_result_block(rtd_handle h, float** dev_ptr, int64_t* n_floats);
 int rtd_sync(rtd_handle h);
-void* rtd_stream(rtd_handle h); /* hipStream_t of the handle */
+void* rtd_stream(rtd_handle h); /* hipStream_t of the handle: for profilers / HIP-event timing only - never wrap it in a torch stream */
+
+/* Build everything a later rtd_infer* of batch size n needs - plan, activation arena, one eager pass on blank frames, the hipGraph -
+ * so that the serving path only replays (RTDETRDetector.load_model prepares the sizes its caller declares; part of
+ * src/rtdetr_detector.py:132-173's "model ready after load_model").  A size that was not prepared is still built on first use. */
+int rtd_prepare(rtd_handle h, int32_t n);
+
+/* Ordering against a stream the CALLER owns (torch's current stream that produced device-resident frames,
+ * src/stream_capture_gpu_ffmpeg.py:253,277-278; the stream RCCL's all-gather runs on).  rtd_wait_stream: the handle's stream waits for
+ * everything enqueued on `producer_stream` so far.  rtd_signal_stream: `consumer_stream` waits for everything enqueued on the handle's
+ * stream so far.  Both use an event that belongs to the handle; streams are hipStream_t values (NULL = the legacy default stream). */
+int rtd_wait_stream(rtd_handle h, void* producer_stream);
+int rtd_signal_stream(rtd_handle h, void* consumer_stream);
+
+/* What the handle did so far - carried into error reports so that a failure describes itself (batching.BatchCoordinator.get_stats). */
+typedef struct rtd_stats {
+  int32_t struct_size;           /* = sizeof(rtd_stats) */
+  int32_t last_error_code;       /* RTD_E_* of the most recent failed call, 0 = none */
+  int32_t stream_capture_status; /* hipStreamIsCapturing of the handle's stream now: 0 none (the only value this library produces) */
+  int32_t in_flight;             /* 1: a submitted batch has not been collected */
+  int64_t plans, graphs, graph_nodes, graph_launches, eager_passes, submits, collects, failed_calls;
+} rtd_stats;
+int rtd_get_stats(rtd_handle h, rtd_stats* out);
 
 /* mutable attribute `model.to(device)` / teardown (src/inference_engine_yolox.py:743-744) */
 void rtd_destroy(rtd_handle h);

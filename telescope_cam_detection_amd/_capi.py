@@ -78,6 +78,12 @@ class RtdDet(C.Structure):
                 ("x2", C.c_float), ("y2", C.c_float)]
 
 
+class RtdStats(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("last_error_code", C.c_int32), ("stream_capture_status", C.c_int32), ("in_flight", C.c_int32),
+                ("plans", C.c_int64), ("graphs", C.c_int64), ("graph_nodes", C.c_int64), ("graph_launches", C.c_int64),
+                ("eager_passes", C.c_int64), ("submits", C.c_int64), ("collects", C.c_int64), ("failed_calls", C.c_int64)]
+
+
 class RtdLayerTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("kernel", C.c_char * 24), ("ms", C.c_float), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -89,8 +95,8 @@ _lib: Optional[C.CDLL] = None
 
 # every symbol include/rtdetr_mi355.h declares
 EXPORTS = [
-    "rtd_version", "rtd_create", "rtd_load_weights", "rtd_infer", "rtd_infer_raw", "rtd_infer_async",
-    "rtd_result_block", "rtd_sync", "rtd_stream", "rtd_destroy", "rtd_last_error", "rtd_debug_tensor",
+    "rtd_version", "rtd_create", "rtd_load_weights", "rtd_infer", "rtd_infer_raw", "rtd_infer_async", "rtd_collect", "rtd_prepare",
+    "rtd_result_block", "rtd_sync", "rtd_stream", "rtd_wait_stream", "rtd_signal_stream", "rtd_get_stats", "rtd_destroy", "rtd_last_error", "rtd_debug_tensor",
     "rtd_debug_force_topk", "rtd_profile", "rtd_arena_bytes", "rtd_debug_option", "rtd_op_conv", "rtd_op_conv_dual", "rtd_op_conv_next", "rtd_op_layernorm",
     "rtd_op_attention", "rtd_op_msdeform", "rtd_op_topk", "rtd_op_resize", "rtd_crop_resize_batch", "rtd_bench_conv", "rtd_bench_conv_pair", "rtd_bench_mfma_rate",
 ]
@@ -129,7 +135,12 @@ def lib() -> C.CDLL:
     L.rtd_load_weights.argtypes = [vp, vp, C.c_size_t]
     L.rtd_infer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), i32, f32, i32, vp, C.POINTER(i32)]
     L.rtd_infer_raw.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), i32, vp, vp, vp]
-    L.rtd_infer_async.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32)]
+    L.rtd_infer_async.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), i32]
+    L.rtd_collect.argtypes = [vp, f32, i32, vp, C.POINTER(i32)]
+    L.rtd_prepare.argtypes = [vp, i32]
+    L.rtd_wait_stream.argtypes = [vp, vp]
+    L.rtd_signal_stream.argtypes = [vp, vp]
+    L.rtd_get_stats.argtypes = [vp, C.POINTER(RtdStats)]
     L.rtd_result_block.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.rtd_sync.argtypes = [vp]
     L.rtd_stream.argtypes = [vp]
@@ -171,8 +182,18 @@ class RtdError(RuntimeError):
         self.code = code
 
 
+def _stats_of(handle) -> dict:
+    st = RtdStats()
+    if not handle or lib().rtd_get_stats(handle, C.byref(st)) != RTD_OK:
+        return {}
+    return {k: int(getattr(st, k)) for k, _ in RtdStats._fields_ if k != "struct_size"}
+
+
 def _raise(code: int, handle) -> None:
     msg = (lib().rtd_last_error(handle) or b"").decode(errors="replace")
+    st = _stats_of(handle)
+    if st:          # a failure describes itself: what the handle had done when it happened, and whether its stream is in capture state
+        msg += " | handle: " + ", ".join(f"{k}={v}" for k, v in st.items())
     if code == RTD_E_OOM:
         import torch
         # the only exception the reference's degrade path reacts to (src/inference_engine_yolox.py:607)
@@ -206,7 +227,7 @@ class Engine:
     """Thin RAII wrapper of one rtd_handle."""
 
     def __init__(self, arch: Arch, blob: bytes, device: int = 0, precision: int = PREC_BF16, max_batch: int = 8,
-                 input_size=(640, 640), use_graph: bool = True, profile: int = PROFILE_LATENCY):
+                 input_size=(640, 640), use_graph: bool = True, profile: int = PROFILE_LATENCY, prepare=()):
         self.arch = arch
         self.num_queries = arch.num_queries
         self.max_batch = max_batch
@@ -223,6 +244,17 @@ class Engine:
                 _raise(rc, self._h)
             finally:
                 self.close()
+        for n in sorted({int(b) for b in prepare}):        # plan + arena + hipGraph of every declared batch size: the serving path only replays
+            try:
+                self.prepare(n)
+            except BaseException:
+                self.close()
+                raise
+
+    def prepare(self, n: int):
+        rc = lib().rtd_prepare(self._h, int(n))
+        if rc != RTD_OK:
+            _raise(rc, self._h)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -276,20 +308,48 @@ class Engine:
             _raise(rc, self._h)
         return labels, boxes, scores
 
-    def infer_async(self, frames_dev):
-        n, ptrs, hw, keep = self._frame_args(frames_dev, True)
-        rc = lib().rtd_infer_async(self._h, n, ptrs, hw)
+    def infer_async(self, frames, on_device: bool = True):
+        """Enqueue one batch and return.  Host frames are staged inside the library (pinned buffer + one DMA): the arrays may be
+        released at once; device frames must stay alive until collect() / sync()."""
+        n, ptrs, hw, keep = self._frame_args(frames, on_device)
+        rc = lib().rtd_infer_async(self._h, n, ptrs, hw, int(on_device))
         if rc != RTD_OK:
             _raise(rc, self._h)
+        return n
+
+    def collect(self, conf: float, wildlife_only: bool):
+        """Wait for the batch of the last infer_async and return what infer() returns for it."""
+        out = np.zeros((self.max_batch, self.num_queries), dtype=DET_DTYPE)
+        counts = (C.c_int32 * self.max_batch)()
+        rc = lib().rtd_collect(self._h, float(conf), int(bool(wildlife_only)), out.ctypes.data, counts)
+        if rc != RTD_OK:
+            _raise(rc, self._h)
+        return out, counts
 
     def make_async_args(self, frames_dev):
         """Pre-marshal (n, ptrs, hw) once so a benchmark loop does no Python work per step."""
         return self._frame_args(frames_dev, True)
 
     def infer_async_prepared(self, args):
-        rc = lib().rtd_infer_async(self._h, args[0], args[1], args[2])
+        rc = lib().rtd_infer_async(self._h, args[0], args[1], args[2], 1)
         if rc != RTD_OK:
             _raise(rc, self._h)
+
+    def wait_stream(self, producer_stream: int):
+        """The engine's stream waits for everything enqueued so far on `producer_stream` (a raw hipStream_t value, e.g.
+        torch.cuda.current_stream().cuda_stream; 0 = the default stream)."""
+        rc = lib().rtd_wait_stream(self._h, C.c_void_p(int(producer_stream) or None))
+        if rc != RTD_OK:
+            _raise(rc, self._h)
+
+    def signal_stream(self, consumer_stream: int):
+        """`consumer_stream` waits for everything enqueued so far on the engine's stream."""
+        rc = lib().rtd_signal_stream(self._h, C.c_void_p(int(consumer_stream) or None))
+        if rc != RTD_OK:
+            _raise(rc, self._h)
+
+    def stats(self) -> dict:
+        return _stats_of(self._h)
 
     def result_block(self):
         p = C.c_void_p()

@@ -99,11 +99,15 @@ class _Lane:
     Detectors with the pipelined pair (RTDETRDetector.detect_batch_async / detect_batch_collect: the work runs on the detector's own
     HIP stream between the two calls) overlap with the other lanes; a plain `detect_batch` object simply does its work in `finish`."""
 
+    REBUILD_AFTER = 3        # consecutive failed batches after which the lane rebuilds its detector (a wedged engine must not be reused forever)
+
     def __init__(self, detector: Any):
         self.detector = detector
         self.idle = threading.Semaphore(1)
         self._overlapped = hasattr(detector, "detect_batch_async") and hasattr(detector, "detect_batch_collect")
         self._held = None
+        self.fail_streak = 0
+        self.rebuilds = 0
 
     def begin(self, frames: list) -> None:
         self._held = self.detector.detect_batch_async(frames) if self._overlapped else frames
@@ -111,6 +115,31 @@ class _Lane:
     def finish(self) -> list:
         held, self._held = self._held, None
         return self.detector.detect_batch_collect(held) if self._overlapped else self.detector.detect_batch(held)
+
+    def succeeded(self) -> None:
+        self.fail_streak = 0
+
+    def failed(self) -> None:
+        """Called by whoever holds the lane (former or finisher) when its batch raised.  After REBUILD_AFTER failures in a row the
+        detector is loaded afresh - a new engine handle, new streams, new graphs - and the old engine is closed."""
+        self._held = None
+        self.fail_streak += 1
+        if self.fail_streak < self.REBUILD_AFTER or not hasattr(self.detector, "load_model"):
+            return
+        old = getattr(getattr(self.detector, "model", None), "engine", None)
+        try:
+            ok = self.detector.load_model(max_retries=1)
+        except Exception as e:                               # load_model of the drop-in never raises; a foreign detector might
+            logger.error(f"batch coordinator: rebuilding a detector raised: {e}")
+            ok = False
+        self.rebuilds += 1
+        self.fail_streak = 0
+        if ok and old is not None and old is not getattr(getattr(self.detector, "model", None), "engine", None):
+            try:
+                old.close()
+            except Exception:
+                pass
+        logger.warning(f"batch coordinator: detector rebuilt after {self.REBUILD_AFTER} failed batches in a row ({'ok' if ok else 'FAILED'})")
 
 
 class BatchCoordinator:
@@ -138,6 +167,10 @@ class BatchCoordinator:
         self._flying: deque = deque()                                # (lane, asks, t_begin) in submission order
         self._flying_cv = threading.Condition()
         self._threads: List[threading.Thread] = []
+        # failures: counted, and the FIRST one kept verbatim (the reference answers [] and logs; a silent "no detections" must be visible)
+        self.failed_batches = 0
+        self.failed_frames = 0
+        self.first_error: Optional[str] = None
         # meter
         self.total_batches = 0
         self.total_frames = 0
@@ -210,6 +243,8 @@ class BatchCoordinator:
             try:
                 lane.begin([a.frame for a in asks])
             except Exception as e:
+                self._note_failure("begin", e, len(asks))
+                lane.failed()
                 lane.idle.release()
                 logger.error(f"batch coordinator: could not start a batch of {len(asks)}: {e}", exc_info=True)
                 for a in asks:
@@ -235,10 +270,13 @@ class BatchCoordinator:
                 if len(results) != len(asks):
                     raise RuntimeError(f"detector returned {len(results)} results for {len(asks)} frames")
             except Exception as e:
+                self._note_failure("finish", e, len(asks))
+                lane.failed()
                 logger.error(f"batch coordinator: batch of {len(asks)} failed: {e}", exc_info=True)
                 results = [[] for _ in asks]
                 failed = True
             else:
+                lane.succeeded()
                 failed = False
             finally:
                 lane.idle.release()
@@ -250,11 +288,23 @@ class BatchCoordinator:
                 self.total_batch_time_ms += (time.monotonic() - t_begin) * 1000.0
                 self.batch_sizes.append(len(asks))
 
+    def _note_failure(self, where: str, e: BaseException, n_frames: int) -> None:
+        self.failed_batches += 1
+        self.failed_frames += n_frames
+        if self.first_error is None:
+            self.first_error = f"{where}: {type(e).__name__}: {e}"
+
+    def failure_stats(self) -> Dict[str, Any]:
+        """Build-specific (the reference's coordinator only logs): how many batches were answered with [] and why the first one was."""
+        return {"failed_batches": self.failed_batches, "failed_frames": self.failed_frames, "first_error": self.first_error,
+                "detector_rebuilds": sum(l.rebuilds for l in self._lanes)}
+
     def get_stats(self) -> Dict[str, Any]:
         if not self.enable_metrics or self.total_batches == 0:
-            return {"enabled": False, "total_batches": 0, "total_frames": 0}
+            return {"enabled": False, "total_batches": 0, "total_frames": 0, **self.failure_stats()}
         busy_s = self.total_batch_time_ms / 1000.0
         return {
+            **self.failure_stats(),
             "enabled": True,
             "total_batches": self.total_batches,
             "total_frames": self.total_frames,
@@ -264,6 +314,15 @@ class BatchCoordinator:
             "throughput_fps": round(self.total_frames / busy_s, 1) if busy_s > 0 else 0,
             "queue_depth": len(self._inbox),
         }
+
+
+def _accepts(cls, keyword: str) -> bool:
+    import inspect
+    try:
+        params = inspect.signature(cls.__init__).parameters
+    except (TypeError, ValueError):
+        return False
+    return keyword in params or any(p.kind == p.VAR_KEYWORD for p in params.values())
 
 
 def make_rtdetr_coordinator(config: Dict[str, Any], coordinator_cls=None, detector_cls=None):
@@ -290,6 +349,9 @@ def make_rtdetr_coordinator(config: Dict[str, Any], coordinator_cls=None, detect
     # several detectors share the GPU: their kernels lean towards throughput (rtd_config.profile); the reference's own
     # detector class knows no such argument and is never built with depth > 1
     prof = {"profile": "throughput"} if depth > 1 else {}
+    prof["prepare_batches"] = tuple(range(1, max_batch + 1))   # every batch size the former can cut: planned, warmed and graphed inside load_model
+    if detector_cls is not None and not _accepts(detector_cls, "prepare_batches"):
+        prof.pop("prepare_batches")
     if "precision" in rt:                               # build-specific key detection.rtdetr.precision: f16x3 (default) | bf16 | fp32
         prof["precision"] = rt["precision"]
     try:

@@ -2,9 +2,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <stdexcept>
 #include <string>
+#include <tuple>
+#include <type_traits>
+#include <utility>
+#include <vector>
 
 namespace rtd {
 
@@ -69,6 +74,50 @@ struct Error : std::runtime_error {
       throw ::rtd::Error(_c, std::string(#expr) + ": " + hipGetErrorString(_e) + " at " __FILE__ ":" + std::to_string(__LINE__)); \
     }                                                                                  \
   } while (0)
+
+// ------------------------------------------------------------------------------------------
+// Kernel launches.  Every launcher of the library goes through rtd_launch().  On a live stream it is hipLaunchKernelGGL.  While a plan's
+// hipGraph is being BUILT (engine.hip build_exec: a GraphBuild is active on the calling thread) nothing is enqueued and no stream is
+// involved: the launch becomes a kernel node, chained behind the last node of its lane (lane 0 = the engine's stream, lane 1 = its side
+// stream; fork / join markers of the plan become dependency edges).  The library therefore NEVER puts a stream into capture mode: the
+// states HIP attaches to capturing streams and to events recorded on them (hipErrorStreamCaptureUnsupported, hipErrorCapturedEvent - the
+// failures rounds 2 and 3 met in processes that also run torch's allocator and RCCL's watchdog on other threads) cannot arise from here.
+struct GraphBuild {
+  hipGraph_t graph = nullptr;
+  hipStream_t lane_stream[2] = {nullptr, nullptr};
+  std::vector<hipGraphNode_t> tail[2];      // nodes the lane's next node depends on
+  int nodes = 0;
+  void add_kernel(void* fn, dim3 grid, dim3 block, unsigned shmem, void** params, hipStream_t s) {
+    const int lane = (s == lane_stream[1] && lane_stream[1] != nullptr) ? 1 : 0;
+    if (lane == 0 && s != lane_stream[0]) throw Error(3, "graph build: a launch names a stream that is neither lane of the plan");
+    hipKernelNodeParams kp;
+    memset(&kp, 0, sizeof kp);
+    kp.func = fn; kp.gridDim = grid; kp.blockDim = block; kp.sharedMemBytes = shmem; kp.kernelParams = params; kp.extra = nullptr;
+    hipGraphNode_t node = nullptr;
+    const hipError_t er = hipGraphAddKernelNode(&node, graph, tail[lane].empty() ? nullptr : tail[lane].data(), tail[lane].size(), &kp);
+    if (er != hipSuccess) { (void)hipGetLastError(); throw Error(3, std::string("hipGraphAddKernelNode: ") + hipGetErrorString(er)); }
+    tail[lane].assign(1, node);
+    ++nodes;
+  }
+  void fork() { for (hipGraphNode_t n : tail[0]) tail[1].push_back(n); }     // the side lane waits for everything on the main lane so far
+  void join() { for (hipGraphNode_t n : tail[1]) tail[0].push_back(n); tail[1].clear(); }   // the main lane waits for the side lane
+};
+extern __thread GraphBuild* t_graph_build;   // engine.hip
+extern __thread long long t_launches;        // launches (or nodes) issued by this thread: build_exec checks node count == eager launch count
+
+template <typename... KArgs, typename... Args>
+inline void rtd_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned shmem, hipStream_t s, Args&&... args) {
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "rtd_launch: argument count differs from the kernel's parameter count");
+  ++t_launches;
+  if (GraphBuild* gb = t_graph_build) {
+    std::tuple<std::remove_cv_t<KArgs>...> vals{static_cast<KArgs>(std::forward<Args>(args))...};   // the node copies the values now
+    void* ptrs[sizeof...(KArgs) + 1];
+    std::apply([&](auto&... v) { size_t i = 0; ((ptrs[i++] = (void*)&v), ...); (void)i; }, vals);
+    gb->add_kernel((void*)kernel, grid, block, shmem, ptrs, s);
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, shmem, s, static_cast<KArgs>(std::forward<Args>(args))...);
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // kernel launch wrappers (implemented in conv_igemm.hip / ops.hip)

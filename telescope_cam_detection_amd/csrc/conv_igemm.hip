@@ -1909,13 +1909,13 @@ static bool dispatch_glds(const ConvOpts& o, const ConvK& k, bool ok, bool prefe
   if ((o.conv_mode == 0 && !prefer256 && mt * ntn < o.ws64_max_blocks && k.N > 64) || o.conv_mode == 10) {
     const long long ntn64 = (k.N + 63) / 64;
     g.k.ntn = (int)ntn64;
-    hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 64>), dim3((unsigned)(mt * ntn64)), dim3(512), 0, s, g);
+    rtd_launch((conv_igemm_ws_kernel<T, 4, 64>), dim3((unsigned)(mt * ntn64)), dim3(512), 0, s, g);
     return true;
   }
   if (k.x2) {
     // dual-input launches exist in the wave-specialised kernel only (every conv_mode): 4 stages on small grids, 2 above
-    if (mt * ntn < o.ws2_min_blocks) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
-    else hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+    if (mt * ntn < o.ws2_min_blocks) rtd_launch((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+    else rtd_launch((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
     return true;
   }
   if (sizeof(T) == 2 && o.wsa_min_ntn > 0 && (o.conv_mode == 0 || o.conv_mode == 8) && k.KH == 1 && k.KW == 1 && k.stride == 1 && k.pad == 0 &&
@@ -1928,9 +1928,9 @@ static bool dispatch_glds(const ConvOpts& o, const ConvK& k, bool ok, bool prefe
     const dim3 grid((unsigned)(mt * groups));
     g.y_bytes = y_bytes;
     switch (k.Kpad / (128 / (int)sizeof(T))) {
-      case 1: hipLaunchKernelGGL((conv_igemm_wsa_kernel<T, 1>), grid, dim3(512), 0, s, g, npb); return true;
-      case 2: hipLaunchKernelGGL((conv_igemm_wsa_kernel<T, 2>), grid, dim3(512), 0, s, g, npb); return true;
-      case 4: hipLaunchKernelGGL((conv_igemm_wsa_kernel<T, 4>), grid, dim3(512), 0, s, g, npb); return true;
+      case 1: rtd_launch((conv_igemm_wsa_kernel<T, 1>), grid, dim3(512), 0, s, g, npb); return true;
+      case 2: rtd_launch((conv_igemm_wsa_kernel<T, 2>), grid, dim3(512), 0, s, g, npb); return true;
+      case 4: rtd_launch((conv_igemm_wsa_kernel<T, 4>), grid, dim3(512), 0, s, g, npb); return true;
       default: break;                             // K = 192: the independent-tile kernels
     }
   }
@@ -1938,15 +1938,15 @@ static bool dispatch_glds(const ConvOpts& o, const ConvK& k, bool ok, bool prefe
     const long long mt256 = (k.M + 255) / 256;
     const int min256 = prefer256 ? 100 : o.ws256_min_blocks;
     if (o.conv_mode == 7 || (o.conv_mode == 0 && min256 > 0 && mt256 * ntn >= min256)) {
-      hipLaunchKernelGGL((conv_igemm_ws256_kernel<T>), dim3((unsigned)(mt256 * ntn)), dim3(512), 0, s, g);
+      rtd_launch((conv_igemm_ws256_kernel<T>), dim3((unsigned)(mt256 * ntn)), dim3(512), 0, s, g);
       return true;
     }
   }
   // loader / MFMA wave roles win at every grid size (tools/profile_layers.py): grids beyond one block per CU run 2 blocks per CU with
   // 2 stages, smaller grids 1 block per CU with 4 stages (3 tiles of DMA in flight); conv_mode 3 / 4 force either
   const bool four = o.conv_mode == 3 || (o.conv_mode != 4 && mt * ntn < o.ws2_min_blocks);
-  if (four) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
-  else hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+  if (four) rtd_launch((conv_igemm_ws_kernel<T, 4>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
+  else rtd_launch((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
   return true;
 }
 
@@ -2580,10 +2580,10 @@ static bool dispatch_reg(const ConvOpts& o, const ConvK& k, const ConvArgs& a, l
   if (ntiles < 256 || ntiles >= (1ll << 30)) return false;        // small maps: the implicit-GEMM tiles fill the chip better
   // persistent blocks, two per CU (LDS: 2 patch buffers + the store slabs)
   const unsigned gx = (unsigned)std::min<long long>(ntiles, x.c == 64 ? 256 : 512);
-  if (x.c == 32 && y.c == 32) hipLaunchKernelGGL((conv3x3_reg_kernel<32, 1, 1>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, 0u);
-  else if (x.c == 32) hipLaunchKernelGGL((conv3x3_reg_kernel<32, 2, 1>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, 0u);
-  else if (y.c == 64 && with_res) hipLaunchKernelGGL((conv3x3_reg_kernel<64, 1, 2, true>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, (unsigned)r_bytes);
-  else if (y.c == 64) hipLaunchKernelGGL((conv3x3_reg_kernel<64, 1, 2>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, 0u);
+  if (x.c == 32 && y.c == 32) rtd_launch((conv3x3_reg_kernel<32, 1, 1>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, 0u);
+  else if (x.c == 32) rtd_launch((conv3x3_reg_kernel<32, 2, 1>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, 0u);
+  else if (y.c == 64 && with_res) rtd_launch((conv3x3_reg_kernel<64, 1, 2, true>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, (unsigned)r_bytes);
+  else if (y.c == 64) rtd_launch((conv3x3_reg_kernel<64, 1, 2>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, 0u);
   else return false;
   return true;
 }
@@ -2951,15 +2951,15 @@ static bool dispatch_stream(const ConvOpts& o, const ConvK& k, const ConvArgs& a
       // one 8-wave block per CU; whole rounds of wave tiles, so that no wave of a block has one tile more than another
       const long long rounds = (ntiles * ny + 2047) / 2048;
       const unsigned gx = (unsigned)std::max<long long>(1, (ntiles + 8 * rounds - 1) / (8 * rounds));
-      hipLaunchKernelGGL((conv1x1_stream2_kernel<16, 2, 512>), dim3(gx, ny), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes, (int)ntiles);
+      rtd_launch((conv1x1_stream2_kernel<16, 2, 512>), dim3(gx, ny), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes, (int)ntiles);
       return true;
     }
     if (y.c == 64) {        // 52 KB of LDS per 4-wave block: 3 blocks per CU
       const unsigned gx = (unsigned)std::min<long long>((ntiles + 3) / 4, 768);
-      hipLaunchKernelGGL((conv1x1_stream2_kernel<16, 1, 256>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes, (int)ntiles);
+      rtd_launch((conv1x1_stream2_kernel<16, 1, 256>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes, (int)ntiles);
     } else {                // 105 KB per 8-wave block: one block per CU
       const unsigned gx = (unsigned)std::min<long long>((ntiles + 7) / 8, 256);
-      hipLaunchKernelGGL((conv1x1_stream2_kernel<16, 2, 512>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes, (int)ntiles);
+      rtd_launch((conv1x1_stream2_kernel<16, 2, 512>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes, (int)ntiles);
     }
     return true;
   }
@@ -2983,11 +2983,11 @@ static bool dispatch_stream(const ConvOpts& o, const ConvK& k, const ConvArgs& a
     const long long yn_bytes = ((long long)(a.next_y.n - 1) * a.next_y.bstride + ((long long)a.next_y.h * a.next_y.w - 1) * a.next_y.ld + a.next_y.c) * 2;
     if (yn_bytes >= (1ll << 31)) return false;
     const unsigned gxn = (unsigned)std::min<long long>(ntiles, NW == 8 ? 256 : (dual ? 512 : 768));   // 4-wave blocks: 2 (K = 128) or 3 (K = 64) waves per SIMD
-    if (NW == 8) hipLaunchKernelGGL((conv1x1_stream_kernel<8, 512, false, true, true>), dim3(gxn), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes,
+    if (NW == 8) rtd_launch((conv1x1_stream_kernel<8, 512, false, true, true>), dim3(gxn), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes,
                                     (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles, (unsigned)yn_bytes);
-    else if (dual) hipLaunchKernelGGL((conv1x1_stream_kernel<8, 256, true, true, true>), dim3(gxn), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes,
+    else if (dual) rtd_launch((conv1x1_stream_kernel<8, 256, true, true, true>), dim3(gxn), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes,
                                  (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles, (unsigned)yn_bytes);
-    else hipLaunchKernelGGL((conv1x1_stream_kernel<4, 256, false, true, true>), dim3(gxn), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes,
+    else rtd_launch((conv1x1_stream_kernel<4, 256, false, true, true>), dim3(gxn), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes,
                             (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles, (unsigned)yn_bytes);
     return true;
   }
@@ -2997,11 +2997,11 @@ static bool dispatch_stream(const ConvOpts& o, const ConvK& k, const ConvArgs& a
 #define RTD_STREAM(NKK, THREADS, DUAL)                                                                                                \
   do {                                                                                                                                \
     if (o.stream_slab)                                                                                                                \
-      hipLaunchKernelGGL((conv1x1_stream_kernel<NKK, THREADS, DUAL, true>), dim3(gx), dim3(THREADS), 0, s, k, (unsigned)x_bytes,      \
-                         (unsigned)r_bytes, (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles);                                  \
+      rtd_launch((conv1x1_stream_kernel<NKK, THREADS, DUAL, true>), dim3(gx), dim3(THREADS), 0, s, k, (unsigned)x_bytes,      \
+                         (unsigned)r_bytes, (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles, 0u);                              \
     else                                                                                                                              \
-      hipLaunchKernelGGL((conv1x1_stream_kernel<NKK, THREADS, DUAL, false>), dim3(gx), dim3(THREADS), 0, s, k, (unsigned)x_bytes,     \
-                         (unsigned)r_bytes, (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles);                                  \
+      rtd_launch((conv1x1_stream_kernel<NKK, THREADS, DUAL, false>), dim3(gx), dim3(THREADS), 0, s, k, (unsigned)x_bytes,     \
+                         (unsigned)r_bytes, (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles, 0u);                              \
   } while (0)
   if (K == 64) {
     if (NW == 8) RTD_STREAM(4, 512, false);
@@ -3031,8 +3031,8 @@ static void dispatch(const ConvK& k, bool smallc, hipStream_t s) {
   do {                                                                                            \
     kk.ntn = (k.N + BN - 1) / BN;                                                                 \
     const long long blocks = (long long)((k.M + BM - 1) / BM) * kk.ntn;                           \
-    if (smallc) hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, true>), dim3((unsigned)blocks), dim3(256), 0, s, kk); \
-    else hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, false>), dim3((unsigned)blocks), dim3(256), 0, s, kk);       \
+    if (smallc) rtd_launch((conv_igemm_kernel<T, BM, BN, true>), dim3((unsigned)blocks), dim3(256), 0, s, kk); \
+    else rtd_launch((conv_igemm_kernel<T, BM, BN, false>), dim3((unsigned)blocks), dim3(256), 0, s, kk);       \
   } while (0)
   if (cfg == 0) RTD_LAUNCH(128, 128);
   else if (cfg == 1) RTD_LAUNCH(128, 64);
@@ -3439,18 +3439,18 @@ static bool dispatch_sx(const ConvK& k, const ConvArgs& a, long long x_bytes, lo
   // persistent, two 8-wave blocks per CU: 8 XCDs x nts tile streams x ny channel blocks
   const int nts = (int)std::max<long long>(1, std::min<long long>(64 / ny, (ntiles + 7) / 8));
   const dim3 grid((unsigned)(8 * nts * ny)), blk(512);
-#define RTD_SX(NGX, NG2, RES_, NX) hipLaunchKernelGGL((conv1x1_sx_kernel<NGX, NG2, RES_, NX>), grid, blk, 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, \
+#define RTD_SX(NGX, NG2, RES_, NX) rtd_launch((conv1x1_sx_kernel<NGX, NG2, RES_, NX>), grid, blk, 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, \
                                                      (unsigned)y_bytes, (unsigned)x2_bytes, (int)ntiles, (unsigned)yn_bytes, ny, ao)
   const int nx = next ? a.next_y.c : 0;
   if (avg) {
-    if (a.x.c == 64) hipLaunchKernelGGL((conv1x1_sx_kernel<2, 0, true, 128, false, true>), grid, blk, 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes,
+    if (a.x.c == 64) rtd_launch((conv1x1_sx_kernel<2, 0, true, 128, false, true>), grid, blk, 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes,
                                         (unsigned)x2_bytes, (int)ntiles, (unsigned)yn_bytes, ny, ao);
-    else hipLaunchKernelGGL((conv1x1_sx_kernel<4, 0, true, 0, false, true>), grid, blk, 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes,
+    else rtd_launch((conv1x1_sx_kernel<4, 0, true, 0, false, true>), grid, blk, 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes,
                             (unsigned)x2_bytes, (int)ntiles, (unsigned)yn_bytes, ny, ao);
   } else if (dual) { if (nx == 64) RTD_SX(2, 2, false, 64); else if (nx == 128) RTD_SX(2, 2, false, 128); else RTD_SX(2, 2, false, 0); }
   else if (a.x.c == 64 && res) { if (nx == 64) RTD_SX(2, 0, true, 64); else if (nx == 128) RTD_SX(2, 0, true, 128); else RTD_SX(2, 0, true, 0); }
   else if (a.x.c == 64) { if (nx == 64) RTD_SX(2, 0, false, 64); else if (nx == 128) RTD_SX(2, 0, false, 128); else RTD_SX(2, 0, false, 0); }
-  else if (a.x.c == 256 && y.dt == F32) hipLaunchKernelGGL((conv1x1_sx_kernel<8, 0, false, 0, true>), grid, blk, 0, s, k, (unsigned)x_bytes, 0u, (unsigned)y_bytes, 0u, (int)ntiles, 0u, ny, ao);
+  else if (a.x.c == 256 && y.dt == F32) rtd_launch((conv1x1_sx_kernel<8, 0, false, 0, true>), grid, blk, 0, s, k, (unsigned)x_bytes, 0u, (unsigned)y_bytes, 0u, (int)ntiles, 0u, ny, ao);
   else if (a.x.c == 256 && res) RTD_SX(8, 0, true, 0);
   else if (a.x.c == 256) RTD_SX(8, 0, false, 0);
   else if (res) RTD_SX(4, 0, true, 0);
@@ -3601,8 +3601,8 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
     const long long ntiles = (long long)x.n * tiles_x * tiles_y;
     if (tiles_x * tiles_y >= 32 && ntiles < (1ll << 30) && y_bytes < (1ll << 31)) {
       const unsigned gx = (unsigned)std::min<long long>(ntiles, 256);        // persistent, one block per CU
-      if (y.c == 32) hipLaunchKernelGGL((conv3x3_reg_split_kernel<1>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, PoolOut{});
-      else hipLaunchKernelGGL((conv3x3_reg_split_kernel<2>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, PoolOut{});
+      if (y.c == 32) rtd_launch((conv3x3_reg_split_kernel<1>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, PoolOut{});
+      else rtd_launch((conv3x3_reg_split_kernel<2>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, PoolOut{});
       HIP_CHECK(hipGetLastError());
       return;
     }
@@ -3614,7 +3614,7 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
     const long long ntiles = (long long)x.n * tiles_x * tiles_y;
     if (tiles_x * tiles_y >= 128 && ntiles < (1ll << 30) && y_bytes < (1ll << 31)) {
       const unsigned gx = (unsigned)std::min<long long>(ntiles, 256);        // persistent, one block per CU
-      hipLaunchKernelGGL(conv3x3_reg_split64_kernel, dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles);
+      rtd_launch(conv3x3_reg_split64_kernel, dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles);
       HIP_CHECK(hipGetLastError());
       return;
     }
@@ -3632,7 +3632,7 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
     HIP_CHECK(hipGetLastError());
     if (S > 1) {
       const long long items = (long long)korig.M * (korig.N >> 3);
-      hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, korig, (const float*)a.ws.slab, S);
+      rtd_launch(k_splitk_reduce, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, korig, (const float*)a.ws.slab, S);
       HIP_CHECK(hipGetLastError());
     }
   };
@@ -3658,7 +3658,7 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
     const long long blocks = ((k.M + 16 * best_mt - 1) / (16 * best_mt)) * k.ntn * S;
     const dim3 grid((unsigned)blocks), blk(512);
     bool launched = true;
-#define RTD_WSF(ST, BNN, MTT) hipLaunchKernelGGL((conv_igemm_wsf_kernel<ST, BNN, MTT>), grid, blk, 0, s, g)
+#define RTD_WSF(ST, BNN, MTT) rtd_launch((conv_igemm_wsf_kernel<ST, BNN, MTT>), grid, blk, 0, s, g)
 #define RTD_WSF_MT(ST, BNN)                                                                                     \
     switch (best_mt) {                                                                                         \
       case 4: RTD_WSF(ST, BNN, 4); break; case 5: RTD_WSF(ST, BNN, 5); break; case 6: RTD_WSF(ST, BNN, 6); break;   \
@@ -3699,19 +3699,19 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)(((k.M + bm - 1) / bm) * ntn)), blk(512);
     if (stamped) {     // diagnostic build: block stamps
       g.slab = a.ws.slab;
-      if (best == 4) hipLaunchKernelGGL((conv_igemm_wsq_kernel<7, 7, true>), grid, blk, 0, s, g);
-      else hipLaunchKernelGGL((conv_igemm_wsq_kernel<8, 8, true>), grid, blk, 0, s, g);
+      if (best == 4) rtd_launch((conv_igemm_wsq_kernel<7, 7, true>), grid, blk, 0, s, g);
+      else rtd_launch((conv_igemm_wsq_kernel<8, 8, true>), grid, blk, 0, s, g);
       finish();
       return;
     }
     switch (best) {
-      case 0: hipLaunchKernelGGL((conv_igemm_wsq_kernel<5, 5>), grid, blk, 0, s, g); break;
-      case 1: hipLaunchKernelGGL((conv_igemm_wsq_kernel<6, 5>), grid, blk, 0, s, g); break;
-      case 2: hipLaunchKernelGGL((conv_igemm_wsq_kernel<6, 6>), grid, blk, 0, s, g); break;
-      case 3: hipLaunchKernelGGL((conv_igemm_wsq_kernel<7, 6>), grid, blk, 0, s, g); break;
-      case 4: hipLaunchKernelGGL((conv_igemm_wsq_kernel<7, 7>), grid, blk, 0, s, g); break;
-      case 5: hipLaunchKernelGGL((conv_igemm_wsq_kernel<8, 7>), grid, blk, 0, s, g); break;
-      default: hipLaunchKernelGGL((conv_igemm_wsq_kernel<8, 8>), grid, blk, 0, s, g); break;
+      case 0: rtd_launch((conv_igemm_wsq_kernel<5, 5>), grid, blk, 0, s, g); break;
+      case 1: rtd_launch((conv_igemm_wsq_kernel<6, 5>), grid, blk, 0, s, g); break;
+      case 2: rtd_launch((conv_igemm_wsq_kernel<6, 6>), grid, blk, 0, s, g); break;
+      case 3: rtd_launch((conv_igemm_wsq_kernel<7, 6>), grid, blk, 0, s, g); break;
+      case 4: rtd_launch((conv_igemm_wsq_kernel<7, 7>), grid, blk, 0, s, g); break;
+      case 5: rtd_launch((conv_igemm_wsq_kernel<8, 7>), grid, blk, 0, s, g); break;
+      default: rtd_launch((conv_igemm_wsq_kernel<8, 8>), grid, blk, 0, s, g); break;
     }
     finish();
     return;
@@ -3722,8 +3722,8 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
   const long long blocks = mt * k.ntn * S;
   const bool four = blocks < o.split_ws2_min_blocks;
   const dim3 grid((unsigned)blocks), blk(512);
-  if (n64) { if (four) hipLaunchKernelGGL((conv_igemm_wsx_kernel<4, 64>), grid, blk, 0, s, g); else hipLaunchKernelGGL((conv_igemm_wsx_kernel<2, 64>), grid, blk, 0, s, g); }
-  else { if (four) hipLaunchKernelGGL((conv_igemm_wsx_kernel<4, 128>), grid, blk, 0, s, g); else hipLaunchKernelGGL((conv_igemm_wsx_kernel<2, 128>), grid, blk, 0, s, g); }
+  if (n64) { if (four) rtd_launch((conv_igemm_wsx_kernel<4, 64>), grid, blk, 0, s, g); else rtd_launch((conv_igemm_wsx_kernel<2, 64>), grid, blk, 0, s, g); }
+  else { if (four) rtd_launch((conv_igemm_wsx_kernel<4, 128>), grid, blk, 0, s, g); else rtd_launch((conv_igemm_wsx_kernel<2, 128>), grid, blk, 0, s, g); }
   finish();
 }
 
@@ -3769,10 +3769,10 @@ void launch_conv_pool(const ConvArgs& a, const Tensor& pooled, void* side, hipSt
   po.side_row = (sp16*)side; po.row_bytes = (unsigned)(ntiles * 8192);
   po.side_col = (sp16*)((char*)side + ntiles * 8192); po.col_bytes = (unsigned)(ntiles * 1024);
   const unsigned gx = (unsigned)std::min<long long>(ntiles, 256);
-  hipLaunchKernelGGL((conv3x3_reg_split_kernel<2, true>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, 0u, tiles_x, tiles_y, (int)ntiles, po);
+  rtd_launch((conv3x3_reg_split_kernel<2, true>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, 0u, tiles_x, tiles_y, (int)ntiles, po);
   HIP_CHECK(hipGetLastError());
   const long long items = ntiles * 19 * (64 / 8);
-  hipLaunchKernelGGL(k_pool_fixup, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, po, tiles_x, tiles_y, (int)ntiles, 64);
+  rtd_launch(k_pool_fixup, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, po, tiles_x, tiles_y, (int)ntiles, 64);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -910,7 +910,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES, 2) void select_score_kernel(const S
 void launch_select_score(const SelArgs& a, hipStream_t s) {
   RTD_CHECK(a.score.K == 256 && a.score.N == a.C && a.rows_per_image > 0, 1, "select_score: 256-wide rows");
   const long long tiles = (a.rows + DR - 1) / DR;
-  hipLaunchKernelGGL(select_score_kernel, dim3((unsigned)((tiles + SEL_WAVES - 1) / SEL_WAVES)), dim3(64 * SEL_WAVES), 0, s, a);
+  rtd_launch(select_score_kernel, dim3((unsigned)((tiles + SEL_WAVES - 1) / SEL_WAVES)), dim3(64 * SEL_WAVES), 0, s, a);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -938,7 +938,7 @@ __global__ void k_gather_ln(const float* __restrict__ x, long long ldx, int rows
 void launch_gather_ln(const float* x, int64_t ldx, int rows_per_image, const int32_t* idx, int B, int Q, const DecLN& ln, float* dst, int64_t ldd,
                       hipStream_t s) {
   const int total = B * Q;
-  hipLaunchKernelGGL(k_gather_ln, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, x, (long long)ldx, rows_per_image, idx, total, Q, ln, dst, (long long)ldd);
+  rtd_launch(k_gather_ln, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, x, (long long)ldx, rows_per_image, idx, total, Q, ln, dst, (long long)ldd);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -946,9 +946,9 @@ void launch_dec_layer(const DecArgs& a, hipStream_t s) {
   RTD_CHECK(a.D == 256 && a.D / a.heads == 32 && a.ffn <= 1024 && a.C <= 512, 1, "fused decoder: d_model 256, head dim 32, ffn <= 1024");
   RTD_CHECK(a.n_levels == 3 && a.n_points == 4 && a.heads == NW, 1, "fused decoder: 3 levels x 4 points, 8 heads");
   const int tiles = (a.Q + DR - 1) / DR;
-  if (a.split == 2) hipLaunchKernelGGL(dec_layer_kernel<2>, dim3(a.B * tiles), dim3(NT), 0, s, a);
-  else if (a.split) hipLaunchKernelGGL(dec_layer_kernel<1>, dim3(a.B * tiles), dim3(NT), 0, s, a);
-  else hipLaunchKernelGGL(dec_layer_kernel<0>, dim3(a.B * tiles), dim3(NT), 0, s, a);
+  if (a.split == 2) rtd_launch(dec_layer_kernel<2>, dim3(a.B * tiles), dim3(NT), 0, s, a);
+  else if (a.split) rtd_launch(dec_layer_kernel<1>, dim3(a.B * tiles), dim3(NT), 0, s, a);
+  else rtd_launch(dec_layer_kernel<0>, dim3(a.B * tiles), dim3(NT), 0, s, a);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -35,12 +35,12 @@ __global__ void k_to_f32(const T* __restrict__ src, float* __restrict__ dst, int
 }
 void launch_f32_to(const float* src, void* dst, int dt, int64_t n, hipStream_t s) {
   if (n == 0) return;
-  DISPATCH_T(dt, hipLaunchKernelGGL(k_f32_to<T>, dim3(blocks_for(n, 256)), dim3(256), 0, s, src, (T*)dst, n));
+  DISPATCH_T(dt, rtd_launch(k_f32_to<T>, dim3(blocks_for(n, 256)), dim3(256), 0, s, src, (T*)dst, n));
   HIP_CHECK(hipGetLastError());
 }
 void launch_to_f32(const void* src, int dt, float* dst, int64_t n, hipStream_t s) {
   if (n == 0) return;
-  DISPATCH_T(dt, hipLaunchKernelGGL(k_to_f32<T>, dim3(blocks_for(n, 256)), dim3(256), 0, s, (const T*)src, dst, n));
+  DISPATCH_T(dt, rtd_launch(k_to_f32<T>, dim3(blocks_for(n, 256)), dim3(256), 0, s, (const T*)src, dst, n));
   HIP_CHECK(hipGetLastError());
 }
 
@@ -69,13 +69,13 @@ __global__ void k_split_to_f32(const sp16* __restrict__ src, int64_t lds_, float
 void launch_f32_to_split(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows, int C, hipStream_t s) {
   if (rows == 0) return;
   RTD_CHECK(C % SPLIT_GROUP == 0 && lds_ % 4 == 0 && ldd % SPLIT_GROUP == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, 1, "f32 -> split: 32-channel groups, 16-byte rows");
-  hipLaunchKernelGGL(k_f32_to_split, dim3(blocks_for(rows * (C / 8), 256)), dim3(256), 0, s, src, lds_, (sp16*)dst, ldd, rows, C);
+  rtd_launch(k_f32_to_split, dim3(blocks_for(rows * (C / 8), 256)), dim3(256), 0, s, src, lds_, (sp16*)dst, ldd, rows, C);
   HIP_CHECK(hipGetLastError());
 }
 void launch_split_to_f32(const void* src, int64_t lds_, float* dst, int64_t ldd, int64_t rows, int C, hipStream_t s) {
   if (rows == 0) return;
   RTD_CHECK(C % SPLIT_GROUP == 0 && lds_ % SPLIT_GROUP == 0 && ldd % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, 1, "split -> f32: 32-channel groups, 16-byte rows");
-  hipLaunchKernelGGL(k_split_to_f32, dim3(blocks_for(rows * (C / 8), 256)), dim3(256), 0, s, (const sp16*)src, lds_, dst, ldd, rows, C);
+  rtd_launch(k_split_to_f32, dim3(blocks_for(rows * (C / 8), 256)), dim3(256), 0, s, (const sp16*)src, lds_, dst, ldd, rows, C);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -128,7 +128,7 @@ void launch_layernorm(const Tensor& x, const Tensor* res, const float* g, const 
   if (res) RTD_CHECK(res->c == dim && res->pixels() == rows && res->bstride == (int64_t)res->h * res->w * res->ld, 1, "layernorm: residual");
   const dim3 grid((rows + 3) / 4), blk(256);
 #define LN_GO(TX, TR, TY)                                                                                   \
-  hipLaunchKernelGGL((k_layernorm<TX, TR, TY>), grid, blk, 0, s, (const TX*)x.p, x.ld,                       \
+  rtd_launch((k_layernorm<TX, TR, TY>), grid, blk, 0, s, (const TX*)x.p, x.ld,                       \
                      (const TR*)(res ? res->p : nullptr), res ? res->ld : 0, g, b, (TY*)y.p, y.ld, rows, dim, eps)
   const int rdt = res ? res->dt : x.dt;
   const int key = (x.dt == F32) * 4 + (rdt == F32) * 2 + (y.dt == F32);
@@ -162,7 +162,7 @@ void launch_add(const Tensor& a, const Tensor& b, const Tensor& y, hipStream_t s
   RTD_CHECK((b.n == 1 || b.n == a.n) && (int64_t)b.h * b.w * b.c == per && y.pixels() == a.pixels(), 1, "add: shape");
   const dim3 grid(blocks_for(total, 256)), blk(256);
   const int bb = (b.n == 1 && a.n != 1);
-#define ADD_GO(TA, TB, TY) hipLaunchKernelGGL((k_add<TA, TB, TY>), grid, blk, 0, s, (const TA*)a.p, (const TB*)b.p, (TY*)y.p, per, total, bb)
+#define ADD_GO(TA, TB, TY) rtd_launch((k_add<TA, TB, TY>), grid, blk, 0, s, (const TA*)a.p, (const TB*)b.p, (TY*)y.p, per, total, bb)
   const int key = (a.dt == F32) * 4 + (b.dt == F32) * 2 + (y.dt == F32);
   switch (key) {
     case 0: ADD_GO(bf16, bf16, bf16); break;
@@ -345,24 +345,24 @@ void launch_maxpool3x3s2(const Tensor& x, const Tensor& y, hipStream_t s) {
     RTD_CHECK(x.c % SPLIT_GROUP == 0 && x.ld % SPLIT_GROUP == 0 && y.ld % SPLIT_GROUP == 0 && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0, 1, "maxpool: split layout");
     if (y.h % 2 == 0 && y.w % 2 == 0) {
       const int64_t total2 = (int64_t)y.n * (y.h / 2) * (y.w / 2) * (y.c / 8);
-      hipLaunchKernelGGL(k_maxpool_split_2x2, dim3(blocks_for(total2, 256)), dim3(256), 0, s, (const sp16*)x.p, (sp16*)y.p, x.n, x.h, x.w, x.c, x.ld, y.h, y.w, y.ld);
+      rtd_launch(k_maxpool_split_2x2, dim3(blocks_for(total2, 256)), dim3(256), 0, s, (const sp16*)x.p, (sp16*)y.p, x.n, x.h, x.w, x.c, x.ld, y.h, y.w, y.ld);
       HIP_CHECK(hipGetLastError());
       return;
     }
     const int64_t total = (int64_t)y.n * y.h * y.w * (y.c / 8);
-    hipLaunchKernelGGL(k_maxpool_split, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const sp16*)x.p, (sp16*)y.p, x.n, x.h, x.w, x.c, x.ld, y.h, y.w, y.ld);
+    rtd_launch(k_maxpool_split, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const sp16*)x.p, (sp16*)y.p, x.n, x.h, x.w, x.c, x.ld, y.h, y.w, y.ld);
     HIP_CHECK(hipGetLastError());
     return;
   }
   if (x.dt == BF16 && x.c % 8 == 0 && x.ld % 8 == 0 && y.ld % 8 == 0 && y.h % 2 == 0 && y.w % 2 == 0 && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0) {
     const int64_t total2 = (int64_t)y.n * (y.h / 2) * (y.w / 2) * (y.c / 8);
-    hipLaunchKernelGGL(k_maxpool_bf16_2x2, dim3(blocks_for(total2, 256)), dim3(256), 0, s, (const bf16*)x.p, (bf16*)y.p, x.n, x.h, x.w, x.c,
+    rtd_launch(k_maxpool_bf16_2x2, dim3(blocks_for(total2, 256)), dim3(256), 0, s, (const bf16*)x.p, (bf16*)y.p, x.n, x.h, x.w, x.c,
                        x.ld, y.h, y.w, y.ld);
     HIP_CHECK(hipGetLastError());
     return;
   }
   const int64_t total = (int64_t)y.n * y.h * y.w * (y.c / 4);
-  DISPATCH_T(x.dt, hipLaunchKernelGGL(k_maxpool<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const T*)x.p, (T*)y.p,
+  DISPATCH_T(x.dt, rtd_launch(k_maxpool<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const T*)x.p, (T*)y.p,
                                       x.n, x.h, x.w, x.c, x.ld, y.h, y.w, y.ld));
   HIP_CHECK(hipGetLastError());
 }
@@ -416,7 +416,7 @@ void launch_avgpool2(const Tensor& x, const Tensor& y, hipStream_t s) {
     RTD_CHECK(x.h % 2 == 0 && x.w % 2 == 0 && y.h == x.h / 2 && y.w == x.w / 2, 1, "avgpool: even extents only");
     RTD_CHECK(x.bstride == (int64_t)x.h * x.w * x.ld && y.bstride == (int64_t)y.h * y.w * y.ld && (((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0, 1, "avgpool: dense images");
     const int64_t total = (int64_t)y.n * y.h * y.w * (y.c / 8);
-    hipLaunchKernelGGL(k_avgpool2_split, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const sp16*)x.p, (sp16*)y.p, x.n, x.h, x.w, x.c, x.ld, y.ld);
+    rtd_launch(k_avgpool2_split, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const sp16*)x.p, (sp16*)y.p, x.n, x.h, x.w, x.c, x.ld, y.ld);
     HIP_CHECK(hipGetLastError());
     return;
   }
@@ -426,7 +426,7 @@ void launch_avgpool2(const Tensor& x, const Tensor& y, hipStream_t s) {
   RTD_CHECK(x.bstride == (int64_t)x.h * x.w * x.ld && y.bstride == (int64_t)y.h * y.w * y.ld, 1, "avgpool: dense images");
   RTD_CHECK((((uintptr_t)x.p | (uintptr_t)y.p) & 15) == 0, 1, "avgpool: alignment");
   const int64_t total = (int64_t)y.n * y.h * y.w * (y.c / V);
-  DISPATCH_T(x.dt, hipLaunchKernelGGL(k_avgpool2<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const T*)x.p, (T*)y.p, x.n,
+  DISPATCH_T(x.dt, rtd_launch(k_avgpool2<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const T*)x.p, (T*)y.p, x.n,
                                       x.h, x.w, x.c, x.ld, y.ld));
   HIP_CHECK(hipGetLastError());
 }
@@ -456,7 +456,7 @@ void launch_upsample2x(const Tensor& x, const Tensor& y, hipStream_t s) {
   RTD_CHECK(x.dt == y.dt && x.c == y.c && x.c % 4 == 0 && y.h == 2 * x.h && y.w == 2 * x.w && x.n == y.n, 1, "upsample: shape");
   RTD_CHECK(x.bstride == (int64_t)x.h * x.w * x.ld && y.bstride == (int64_t)y.h * y.w * y.ld, 1, "upsample: dense images");
   const int64_t total = (int64_t)y.n * y.h * y.w * (y.c / 4);
-  DISPATCH_T(x.dt, hipLaunchKernelGGL(k_upsample2x<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const T*)x.p,
+  DISPATCH_T(x.dt, rtd_launch(k_upsample2x<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const T*)x.p,
                                       (T*)y.p, x.n, x.h, x.w, x.c, x.ld, y.ld));
   HIP_CHECK(hipGetLastError());
 }
@@ -643,13 +643,13 @@ void launch_attention(const Tensor& qk, const Tensor& v, const Tensor& o, int he
   const dim3 grid((L + 63) / 64, heads, B), blk(256);
   if (qk.dt == F32 && L >= 64 && (hd == 32 || hd == 48 || hd == 64) && qk.ld % 4 == 0 && v.ld % 4 == 0 && o.ld % 4 == 0 &&
       (((uintptr_t)qk.p | (uintptr_t)v.p | (uintptr_t)o.p) & 15) == 0) {
-    if (hd == 32) hipLaunchKernelGGL(k_attention_mfma_f32<32>, grid, blk, 0, s, (const float*)qk.p, qk.ld, (const float*)v.p, v.ld, (float*)o.p, o.ld, L, D);
-    else if (hd == 48) hipLaunchKernelGGL(k_attention_mfma_f32<48>, grid, blk, 0, s, (const float*)qk.p, qk.ld, (const float*)v.p, v.ld, (float*)o.p, o.ld, L, D);
-    else hipLaunchKernelGGL(k_attention_mfma_f32<64>, grid, blk, 0, s, (const float*)qk.p, qk.ld, (const float*)v.p, v.ld, (float*)o.p, o.ld, L, D);
+    if (hd == 32) rtd_launch(k_attention_mfma_f32<32>, grid, blk, 0, s, (const float*)qk.p, qk.ld, (const float*)v.p, v.ld, (float*)o.p, o.ld, L, D);
+    else if (hd == 48) rtd_launch(k_attention_mfma_f32<48>, grid, blk, 0, s, (const float*)qk.p, qk.ld, (const float*)v.p, v.ld, (float*)o.p, o.ld, L, D);
+    else rtd_launch(k_attention_mfma_f32<64>, grid, blk, 0, s, (const float*)qk.p, qk.ld, (const float*)v.p, v.ld, (float*)o.p, o.ld, L, D);
     HIP_CHECK(hipGetLastError());
     return;
   }
-#define ATT_GO(HD) DISPATCH_T(qk.dt, hipLaunchKernelGGL((k_attention<T, HD>), grid, blk, 0, s, (const T*)qk.p, qk.ld, (const T*)v.p, v.ld, (T*)o.p, o.ld, L, D))
+#define ATT_GO(HD) DISPATCH_T(qk.dt, rtd_launch((k_attention<T, HD>), grid, blk, 0, s, (const T*)qk.p, qk.ld, (const T*)v.p, v.ld, (T*)o.p, o.ld, L, D))
   if (hd == 32) ATT_GO(32);
   else if (hd == 48) ATT_GO(48);
   else if (hd == 64) ATT_GO(64);
@@ -675,7 +675,7 @@ __global__ void k_set_rows(T* __restrict__ y, int64_t ld, int C, const int32_t* 
 void launch_set_rows(const Tensor& y, const int32_t* rows, int nrows, int rows_per_image, const float* vec, hipStream_t s) {
   if (nrows == 0) return;
   const int64_t total = (int64_t)y.n * nrows * y.c;
-  DISPATCH_T(y.dt, hipLaunchKernelGGL(k_set_rows<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (T*)y.p, y.ld, y.c, rows,
+  DISPATCH_T(y.dt, rtd_launch(k_set_rows<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (T*)y.p, y.ld, y.c, rows,
                                       nrows, rows_per_image, vec, y.n));
   HIP_CHECK(hipGetLastError());
 }
@@ -696,7 +696,7 @@ __global__ void k_rowmax(const float* __restrict__ x, int64_t ld, int C, int64_t
 void launch_rowmax(const Tensor& x, float* out, hipStream_t s) {
   RTD_CHECK(x.dt == F32, 1, "rowmax: fp32 logits expected");
   const int64_t rows = x.pixels();
-  hipLaunchKernelGGL(k_rowmax, dim3(blocks_for(rows * 16, 256)), dim3(256), 0, s, (const float*)x.p, x.ld, x.c, rows, out);
+  rtd_launch(k_rowmax, dim3(blocks_for(rows * 16, 256)), dim3(256), 0, s, (const float*)x.p, x.ld, x.c, rows, out);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -896,8 +896,8 @@ __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ keys, i
 }
 void launch_topk(const float* keys, int B, int N, int K, int32_t* idx, float* vals, hipStream_t s) {
   RTD_CHECK(K >= 1 && K <= 1024 && K <= N, 1, "topk: K must be in [1, min(1024, N)]");
-  if (N <= 32768) hipLaunchKernelGGL(k_topk<true>, dim3(B), dim3(1024), 0, s, keys, N, K, idx, vals);
-  else hipLaunchKernelGGL(k_topk<false>, dim3(B), dim3(1024), 0, s, keys, N, K, idx, vals);
+  if (N <= 32768) rtd_launch(k_topk<true>, dim3(B), dim3(1024), 0, s, keys, N, K, idx, vals);
+  else rtd_launch(k_topk<false>, dim3(B), dim3(1024), 0, s, keys, N, K, idx, vals);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -921,7 +921,7 @@ void launch_gather_rows(const Tensor& src, const int32_t* idx, int rows_per_imag
   RTD_CHECK(src.c == C && src.n == B && src.h * src.w == rows_per_image, 1, "gather: shape");
   const int64_t total = (int64_t)B * Q * C;
   const dim3 grid(blocks_for(total, 256)), blk(256);
-#define G_GO(TS, TD) hipLaunchKernelGGL((k_gather_rows<TS, TD>), grid, blk, 0, s, (const TS*)src.p, src.ld, rows_per_image, idx, Q, C, (TD*)dst.p, dst.ld, B)
+#define G_GO(TS, TD) rtd_launch((k_gather_rows<TS, TD>), grid, blk, 0, s, (const TS*)src.p, src.ld, rows_per_image, idx, Q, C, (TD*)dst.p, dst.ld, B)
   if (src.dt == BF16 && dst.dt == BF16) G_GO(bf16, bf16);
   else if (src.dt == BF16) G_GO(bf16, float);
   else if (dst.dt == BF16) G_GO(float, bf16);
@@ -958,7 +958,7 @@ void launch_ref_init(const Tensor& boxdelta, const float* anchors, const int32_t
                      hipStream_t s) {
   RTD_CHECK(boxdelta.dt == F32 && boxdelta.c == 4, 1, "ref_init: fp32 [.,4] deltas expected");
   const int64_t total = boxdelta.pixels();
-  hipLaunchKernelGGL(k_ref_init, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const float*)boxdelta.p, boxdelta.ld, anchors,
+  rtd_launch(k_ref_init, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const float*)boxdelta.p, boxdelta.ld, anchors,
                      idx, S, ref_unact8, ref8, total);
   HIP_CHECK(hipGetLastError());
 }
@@ -972,7 +972,7 @@ __global__ void k_box_refine(const float* __restrict__ delta, int64_t ldd, float
 void launch_box_refine(const Tensor& delta, float* ref8, hipStream_t s) {
   RTD_CHECK(delta.dt == F32 && delta.c == 4, 1, "box_refine: fp32 [.,4] deltas expected");
   const int64_t total = delta.pixels();
-  hipLaunchKernelGGL(k_box_refine, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const float*)delta.p, delta.ld, ref8, total);
+  rtd_launch(k_box_refine, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const float*)delta.p, delta.ld, ref8, total);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1040,7 +1040,7 @@ void launch_msdeform(const Tensor& value, int value_coff, const Tensor& offaw, c
   const int64_t items = (int64_t)B * Q * heads;
   const dim3 grid(blocks_for(items, 8)), blk(256);
   const char* vp = (const char*)value.p + (size_t)value_coff * dtype_size(value.dt);
-#define MS_GO(TV, TO) hipLaunchKernelGGL((k_msdeform<TV, TO>), grid, blk, 0, s, (const TV*)vp, value.ld, value.bstride, (const float*)offaw.p, offaw.ld, ref8, (TO*)out.p, out.ld, Q, heads, n_levels, n_points, level_hw_start, offset_scale, items)
+#define MS_GO(TV, TO) rtd_launch((k_msdeform<TV, TO>), grid, blk, 0, s, (const TV*)vp, value.ld, value.bstride, (const float*)offaw.p, offaw.ld, ref8, (TO*)out.p, out.ld, Q, heads, n_levels, n_points, level_hw_start, offset_scale, items)
   if (value.dt == BF16 && out.dt == BF16) MS_GO(bf16, bf16);
   else if (value.dt == BF16) MS_GO(bf16, float);
   else if (out.dt == BF16) MS_GO(float, bf16);
@@ -1061,7 +1061,7 @@ __global__ void k_pp_scores(const float* __restrict__ logits, int64_t ld, int C,
 void launch_postprocess_scores(const Tensor& logits, float* scores, hipStream_t s) {
   RTD_CHECK(logits.dt == F32, 1, "postprocess: fp32 logits expected");
   const int64_t rows = logits.pixels();
-  hipLaunchKernelGGL(k_pp_scores, dim3(blocks_for(rows * logits.c, 256)), dim3(256), 0, s, (const float*)logits.p, logits.ld,
+  rtd_launch(k_pp_scores, dim3(blocks_for(rows * logits.c, 256)), dim3(256), 0, s, (const float*)logits.p, logits.ld,
                      logits.c, rows, scores);
   HIP_CHECK(hipGetLastError());
 }
@@ -1089,7 +1089,7 @@ __global__ void k_pp_gather(const float* __restrict__ topv, const int32_t* __res
 void launch_postprocess_gather(const float* topv, const int32_t* topi, const float* ref8, const float* scale_wh, int B, int Q,
                                int C, float* block6, hipStream_t s) {
   const int64_t total = (int64_t)B * Q;
-  hipLaunchKernelGGL(k_pp_gather, dim3(blocks_for(total, 256)), dim3(256), 0, s, topv, topi, ref8, scale_wh, Q, C, block6, total);
+  rtd_launch(k_pp_gather, dim3(blocks_for(total, 256)), dim3(256), 0, s, topv, topi, ref8, scale_wh, Q, C, block6, total);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1116,7 +1116,7 @@ __global__ void k_preprocess_identity(const FrameArgs fa, int H, int W, T* __res
 void launch_preprocess_identity(const FrameArgs& fa, int H, int W, const Tensor& y, float* scale_wh_dev, hipStream_t s) {
   RTD_CHECK(y.c == 8 && y.ld == 8 && y.h == H && y.w == W && y.n >= fa.n, 1, "preprocess: output must be [n,H,W,8]");
   const int64_t total = (int64_t)fa.n * H * W;
-  DISPATCH_T(y.dt, hipLaunchKernelGGL(k_preprocess_identity<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, fa, H, W, (T*)y.p, scale_wh_dev, total));
+  DISPATCH_T(y.dt, rtd_launch(k_preprocess_identity<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, fa, H, W, (T*)y.p, scale_wh_dev, total));
   HIP_CHECK(hipGetLastError());
 }
 __global__ void k_set_scale(const FrameArgs fa, float* __restrict__ scale_wh) {
@@ -1124,7 +1124,7 @@ __global__ void k_set_scale(const FrameArgs fa, float* __restrict__ scale_wh) {
   if (i < 2 * fa.n) scale_wh[i] = fa.scale_wh[i];
 }
 void launch_set_scale(const FrameArgs& fa, float* scale_wh_dev, hipStream_t s) {
-  hipLaunchKernelGGL(k_set_scale, dim3(1), dim3(2 * RTD_MAX_BATCH), 0, s, fa, scale_wh_dev);
+  rtd_launch(k_set_scale, dim3(1), dim3(2 * RTD_MAX_BATCH), 0, s, fa, scale_wh_dev);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1177,9 +1177,9 @@ void launch_resize_pil(const uint8_t* src, int sh, int sw, uint8_t* tmp, const T
                        hipStream_t s) {
   const int dh = y.h, dw = y.w;
   RTD_CHECK(y.c == 8 && y.ld == 8 && image < y.n, 1, "resize: output must be [n,H,W,8]");
-  hipLaunchKernelGGL(k_resize_h, dim3(blocks_for((int64_t)sh * dw, 256)), dim3(256), 0, s, src, sh, sw, tmp, dw, c);
+  rtd_launch(k_resize_h, dim3(blocks_for((int64_t)sh * dw, 256)), dim3(256), 0, s, src, sh, sw, tmp, dw, c);
   char* yp = (char*)y.p + (size_t)image * y.bstride * dtype_size(y.dt);
-  DISPATCH_T(y.dt, hipLaunchKernelGGL(k_resize_v<T>, dim3(blocks_for((int64_t)dh * dw, 256)), dim3(256), 0, s, tmp, sh, dw, (T*)yp, dh, c));
+  DISPATCH_T(y.dt, rtd_launch(k_resize_v<T>, dim3(blocks_for((int64_t)dh * dw, 256)), dim3(256), 0, s, tmp, sh, dw, (T*)yp, dh, c));
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1190,7 +1190,7 @@ __global__ void k_set_frame_table(const FrameArgs fa, const uint8_t** __restrict
   if (i < fa.n) table[i] = fa.ptr[i];
 }
 void launch_set_frame_table(const FrameArgs& fa, const uint8_t** table_dev, float* scale_wh_dev, hipStream_t s) {
-  hipLaunchKernelGGL(k_set_frame_table, dim3(1), dim3(2 * RTD_MAX_BATCH), 0, s, fa, table_dev, scale_wh_dev);
+  rtd_launch(k_set_frame_table, dim3(1), dim3(2 * RTD_MAX_BATCH), 0, s, fa, table_dev, scale_wh_dev);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1212,8 +1212,8 @@ __global__ void k_resize_v_u8(const uint8_t* __restrict__ tmp, int sh, int dw, u
   o[0] = (uint8_t)clip8(s0); o[1] = (uint8_t)clip8(s1); o[2] = (uint8_t)clip8(s2);
 }
 void launch_resize_pil_u8(const uint8_t* src, int sh, int sw, uint8_t* tmp, uint8_t* dst, int dh, int dw, const ResizeCoef& c, hipStream_t s) {
-  hipLaunchKernelGGL(k_resize_h, dim3(blocks_for((int64_t)sh * dw, 256)), dim3(256), 0, s, src, sh, sw, tmp, dw, c);
-  hipLaunchKernelGGL(k_resize_v_u8, dim3(blocks_for((int64_t)dh * dw, 256)), dim3(256), 0, s, tmp, sh, dw, dst, dh, c);
+  rtd_launch(k_resize_h, dim3(blocks_for((int64_t)sh * dw, 256)), dim3(256), 0, s, src, sh, sw, tmp, dw, c);
+  rtd_launch(k_resize_v_u8, dim3(blocks_for((int64_t)dh * dw, 256)), dim3(256), 0, s, tmp, sh, dw, dst, dh, c);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1378,7 +1378,7 @@ void launch_stem0_u8(const uint8_t* const* table_dev, int n, int H, int W, const
   RTD_CHECK(y.dt == F16X2 && y.c == 32 && y.h == OH && y.w == OW && y.n >= n && y.ld % SPLIT_GROUP == 0 &&
                 (act == ACT_RELU || act == ACT_NONE || act == ACT_SILU), 1, "stem0_u8: output must be F16X2 [n, H/2, W/2, 32]");
   const int tiles_x = (OW + 31) / 32, tiles_y = (OH + 7) / 8;
-  hipLaunchKernelGGL(stem0_u8_kernel, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, table_dev, H, W, (const sp16*)w, Kpad, bias, (sp16*)y.p,
+  rtd_launch(stem0_u8_kernel, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, s, table_dev, H, W, (const sp16*)w, Kpad, bias, (sp16*)y.p,
                      (long long)y.bstride, (long long)y.ld, OH, OW, tiles_x, tiles_y, act);
   HIP_CHECK(hipGetLastError());
 }
@@ -1424,7 +1424,7 @@ void launch_crop_resize(const CropBatch& cb, int n, int out_size, const float me
   CropNorm nm;
   for (int k = 0; k < 3; ++k) { nm.mean[k] = mean[k]; nm.inv_std[k] = 1.0f / stdv[k]; }
   const int64_t total = (int64_t)n * out_size * out_size;
-  hipLaunchKernelGGL(k_crop_resize, dim3(blocks_for(total, 256)), dim3(256), 0, s, cb, n, out_size, nm, out);
+  rtd_launch(k_crop_resize, dim3(blocks_for(total, 256)), dim3(256), 0, s, cb, n, out_size, nm, out);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -84,6 +84,7 @@ class RTDETRDetector:
         max_batch: int = 8,
         use_graph: bool = True,
         profile: str = "latency",
+        prepare_batches=None,
     ):
         self.config_path = config_path
         self.model_path = model_path
@@ -98,6 +99,9 @@ class RTDETRDetector:
         # "latency": this detector usually has the GPU to itself; "throughput": several detectors keep batches in flight on one
         # GPU (batching.BatchCoordinator with pipeline_depth > 1) - see rtd_config.profile in include/rtdetr_mi355.h
         self.profile = profile
+        # batch sizes whose plan + hipGraph load_model builds up front (None: 1 and max_batch); a batcher declares every size it may form,
+        # so that the serving path only ever replays a graph.  Other sizes still work: they are built on first use.
+        self.prepare_batches = prepare_batches
 
         # The engine lives on the device named at load time.  The reference's degrade path later WRITES `detector.device = "cpu"`,
         # `detector.input_size = ...` and calls `detector.model.to("cpu")` (src/inference_engine_yolox.py:726-748); those writes must
@@ -128,6 +132,7 @@ class RTDETRDetector:
                 engine = _capi.Engine(arch, blob, device=dev, precision=_capi.precision_code(self.precision), max_batch=self.max_batch,
                                       input_size=tuple(self.input_size), use_graph=self.use_graph,
                                       profile=_capi.PROFILE_THROUGHPUT if str(self.profile).lower() == "throughput" else _capi.PROFILE_LATENCY)
+                self._prepare(engine)
             except (RuntimeError, OSError) as e:              # the reference retries this set (:190-198); IOError is OSError
                 if k + 1 == tries:
                     logger.error("RT-DETR (MI355X): giving up on %s after %d attempt(s): %s", self.model_path, tries, e, exc_info=True)
@@ -149,6 +154,20 @@ class RTDETRDetector:
                         self.conf_threshold)
             return True
         return False
+
+    def _prepare(self, engine) -> None:
+        """Plan, arena and hipGraph of every declared batch size, now - the serving path then only replays.  A size whose arena does not
+        fit is left to its first use (where the caller's OOM handling applies, src/inference_engine_yolox.py:607-623): it must not
+        fail the load of a detector whose smaller batches work."""
+        import torch
+
+        sizes = self.prepare_batches if self.prepare_batches is not None else (1, self.max_batch)
+        for b in sorted({int(b) for b in sizes if 1 <= int(b) <= self.max_batch}):
+            try:
+                engine.prepare(b)
+            except torch.cuda.OutOfMemoryError as e:
+                logger.warning("RT-DETR (MI355X): batch size %d not prepared at load time (%s); it will be built on first use", b, str(e)[:160])
+                break
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -185,8 +204,8 @@ class RTDETRDetector:
         the engine runs on its own non-blocking stream, which synchronises with nothing by itself: make it wait for that work."""
         import torch
 
-        dev = torch.device("cuda", self._dev_index)
-        torch.cuda.ExternalStream(eng.stream(), device=dev).wait_stream(torch.cuda.current_stream(dev))
+        # an event of the LIBRARY is recorded on torch's stream and waited for on the engine's: torch never sees the engine's stream
+        eng.wait_stream(torch.cuda.current_stream(torch.device("cuda", self._dev_index)).cuda_stream)
 
     def _infer(self, frames: list) -> List[np.ndarray]:
         arrs, on_dev = [], []
@@ -239,48 +258,38 @@ class RTDETRDetector:
     def detect_batch_async(self, frames: List[Union[np.ndarray, "torch.Tensor"]]):
         """Enqueue one batch (<= max_batch frames) on this detector's stream and return a ticket at once; `detect_batch_collect`
         blocks for that batch only.  With two detectors a coordinator keeps two batches in flight: one batch's kernels fill the
-        CUs the other's small grids leave idle (bench.py --streams 2 / 3: +33 % / +46 % frames/s on one MI355X)."""
-        import torch
+        CUs the other's small grids leave idle (bench.py --streams 2 / 3: +33 % / +46 % frames/s on one MI355X).
 
+        Everything between the two calls is the library's own HIP work (rtd_infer_async: pinned staging + one DMA for host frames;
+        rtd_collect: D2H of the result block): no torch stream, event or allocator takes part, so this path cannot interact with
+        whatever else the process does through torch."""
         if self.model is None:
             raise RuntimeError("Model not loaded")
         eng = self.model.engine
         if len(frames) > eng.max_batch:
             raise ValueError(f"detect_batch_async takes at most max_batch={eng.max_batch} frames")
-        dev_index = self._dev_index
-        stream = torch.cuda.ExternalStream(eng.stream(), device=torch.device("cuda", dev_index))
-        stream.wait_stream(torch.cuda.current_stream(torch.device("cuda", dev_index)))    # device frames: whatever produced them comes first
-        dev = []
-        with torch.cuda.stream(stream):                  # uploads are ordered before the forward on the engine's own stream
-            for f in frames:
-                a, on_dev = self._as_frame(f)
-                if on_dev:
-                    dev.append(a)
-                else:
-                    dev.append(torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(f"cuda:{dev_index}", non_blocking=True))
+        arrs, on_dev = [], []
+        for f in frames:
+            a, d = self._as_frame(f)
+            arrs.append(a)
+            on_dev.append(d)
+        if any(on_dev) and not all(on_dev):
+            arrs = [a.cpu().numpy() if d else a for a, d in zip(arrs, on_dev)]
+            on_dev = [False] * len(arrs)
+        dev = bool(on_dev) and all(on_dev)
         if dev:
-            eng.infer_async(dev)
-        return {"n": len(dev), "frames": dev, "conf": self.conf_threshold, "wildlife": self.wildlife_only}
+            self._order_after_producer(eng)              # device frames: whatever produced them comes first
+        if arrs:
+            eng.infer_async(arrs, on_device=dev)
+        return {"n": len(arrs), "frames": arrs if dev else None, "conf": self.conf_threshold, "wildlife": self.wildlife_only}
 
     def detect_batch_collect(self, ticket) -> List[List[Dict[str, Any]]]:
-        import torch
-
-        from .shard import block_to_detections
-
         n = ticket["n"]
         if n == 0:
             return []
-        eng = self.model.engine
-        eng.sync()
-        ptr, nfl = eng.result_block()
-        dev_index = self._dev_index
-
-        class _Ptr:
-            __cuda_array_interface__ = {"shape": (nfl,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-
-        block = torch.as_tensor(_Ptr(), device=f"cuda:{dev_index}")[: n * eng.num_queries * 6].cpu().numpy()
+        rows, counts = self.model.engine.collect(ticket["conf"], ticket["wildlife"])
         ticket["frames"] = None
-        return block_to_detections(block.reshape(n, eng.num_queries, 6), ticket["conf"], ticket["wildlife"])
+        return [self._format(rows[i, : counts[i]]) for i in range(n)]
 
     def is_wildlife_relevant(self, class_id: int) -> bool:
         return class_id in WILDLIFE_CLASSES

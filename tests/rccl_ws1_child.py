@@ -1,8 +1,8 @@
 """Child process of tests/test_rccl_collate.py (never imported by pytest: no test_ prefix).
 
 Forms a world-size-1 `nccl` (= RCCL) process group on cuda:0 and runs the collate step of bench.py's N > 1 path exactly as bench.py
-issues it: rtd_infer_async -> torch.as_tensor over the zero-copy view of rtd_result_block -> all_gather_into_tensor on the
-engine's own HIP stream (torch.cuda.ExternalStream).  Prints one JSON line; exit code 0 = the gathered block equals the result
+issues it (shard.collate_after): rtd_infer_async -> rtd_signal_stream(torch-owned stream) -> all_gather_into_tensor over the zero-copy
+view of rtd_result_block on that stream -> rtd_wait_stream.  Prints one JSON line; exit code 0 = the gathered block equals the result
 block bit for bit on every repetition."""
 import json
 import os
@@ -27,10 +27,9 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 
-    from bench import _DevPtr
     from telescope_cam_detection_amd import _capi
     from telescope_cam_detection_amd.arch import ARCHS
-    from telescope_cam_detection_amd.shard import cameras_of_rank, collate_blocks
+    from telescope_cam_detection_amd.shard import DevBlock, cameras_of_rank, collate_after
     from telescope_cam_detection_amd.synth import noise_frame, scene_frame
     from telescope_cam_detection_amd.weights import fold_weights, pack_blob, synth_weights
 
@@ -38,7 +37,7 @@ def main():
     B, H, Q = 2, 640, arch.num_queries
     eng = _capi.Engine(arch, pack_blob(fold_weights(arch, synth_weights(arch, 0))), device=0, precision=_capi.PREC_F16X3, max_batch=B,
                        input_size=(H, H), use_graph=True)
-    stream = torch.cuda.ExternalStream(eng.stream(), device=torch.device("cuda", 0))
+    stream = torch.cuda.Stream(device=torch.device("cuda", 0))      # torch's own: the engine's stream never reaches torch or RCCL
     gathered = torch.full((dist.get_world_size() * B * Q * 6,), float("nan"), dtype=torch.float32, device="cuda")
     ok, reps = True, 4
     for rep in range(reps):
@@ -46,12 +45,13 @@ def main():
         torch.cuda.synchronize()
         args = eng.make_async_args(frames)
         eng.infer_async_prepared(args)
-        ptr, n = eng.result_block()
-        block = torch.as_tensor(_DevPtr(ptr, n), device="cuda:0")
-        with torch.cuda.stream(stream):                      # ordered after the forward on the engine's stream, as in bench.py
-            collate_blocks(block, out=gathered)
+        collate_after(eng, gathered, stream)                 # as in bench.py
+        if rep % 2 == 1:
+            eng.infer_async_prepared(args)                   # the next forward is ordered behind the all-gather: same frames, same block
         eng.sync()
         torch.cuda.synchronize()
+        ptr, n = eng.result_block()
+        block = torch.as_tensor(DevBlock(ptr, n), device="cuda:0")
         want = block.clone().cpu().numpy()
         got = gathered.cpu().numpy()
         # independent check of the block itself: the synchronous path on the same frames

@@ -857,9 +857,9 @@ def test_device_frames_are_ordered_after_the_stream_that_produced_them():
 
 
 def test_no_captured_event_state_leaks_to_later_events_of_the_process():
-    """the fork / join markers of a side-stream plan record capture-only events (created for the capture, destroyed after
-    hipStreamEndCapture); the handle's long-lived events are only ever recorded on live streams.  After an engine with forked plans was
-    captured, replayed and closed, events created by anyone else in the process (here: torch) must record and query cleanly."""
+    """Round 4: a plan's hipGraph is BUILT node by node (csrc/common.h GraphBuild) - the library never captures a stream, so neither a
+    stream nor an event of the process can carry capture state because of it.  After engines with forked plans were graphed, replayed and
+    closed, the handle reports no capture state and events created by anyone else (here: torch) record and query cleanly."""
     from telescope_cam_detection_amd import _capi
     from telescope_cam_detection_amd.arch import ARCHS
     from telescope_cam_detection_amd.synth import scene_frame
@@ -869,8 +869,11 @@ def test_no_captured_event_state_leaks_to_later_events_of_the_process():
     _capi.debug_option("side_stream", 7)
     for _ in range(3):
         eng = make_engine(arch, w, frames, (160, 224), "f16x3", use_graph=True)
-        for n in (2, 1, 2):                                    # two plans captured, then a replay
+        for n in (2, 1, 2):                                    # two plans graphed, then a replay
             eng.infer_raw(frames[:n])
+        st = eng.stats()
+        assert st["graphs"] == 2 and st["graph_launches"] == 3 and st["stream_capture_status"] == 0 and st["failed_calls"] == 0, st
+        assert st["graph_nodes"] > 40                          # both lanes' kernels are nodes of the built graphs
         eng.close()
         evs = [torch.cuda.Event(enable_timing=(i % 2 == 0)) for i in range(64)]
         for ev in evs:
