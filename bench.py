@@ -238,15 +238,15 @@ def main():
                               "fp32": "exact fp32 MFMAs"}[args.precision]},
         "rccl_ranks": rccl_ranks,
     }
-    if collate and world == 1:
-        # the same K steps without the collate step: the all-gather's cost per step on this GPU (world size 1: RCCL's launch + local copy)
+    if collate:
+        # the same K steps without the collate step: the all-gather's cost per step at THIS world size (world size 1: RCCL's launch + local copy)
         for e in engs:
             e.close()
         el0, e0, _ = measure(args.precision, S, crops_fn, collate=False)
         for e in e0:
             e.close()
         out["collate"] = {"ms_per_step_with": round(1000.0 * elapsed / args.steps, 4), "ms_per_step_without": round(1000.0 * el0 / args.steps, 4),
-                          "all_gather_us_per_step": round(1e6 * (elapsed - el0) / args.steps, 1), "bytes_per_rank": B * Q * 6 * 4,
+                          "all_gather_us_per_step": round(1e6 * (elapsed - el0) / args.steps, 1), "bytes_per_rank": B * Q * 6 * 4, "rccl_ranks": rccl_ranks,
                           "note": "torch.distributed all_gather_into_tensor (backend nccl = RCCL) over a zero-copy view of rtd_result_block, on a torch-owned stream ordered after the forward by the engine's own event (rtd_signal_stream / rtd_wait_stream)"}
         elapsed, engs, frames_of = measure(args.precision, S, crops_fn)       # handles for the profile / latency legs below
         eng, frames = engs[0], frames_of[0]
@@ -287,7 +287,7 @@ def main():
             sha = csrc_sha()
             tag = f"{args.arch}_{H}_bs{B}_{args.precision}"
             sfx = "" if tag == "r50_640_bs8_f16x3" else f"_{args.arch}_{H}_bs{B}"
-            with open(os.path.join(ROOT, "profiles", f"r03_pmc_hbm_traffic{sfx}.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", f"r04_pmc_hbm_traffic{sfx}.json")) as fh:
                 pmc = json.load(fh)
             if pmc.get("csrc_sha") == sha and pmc.get("config") == tag and dom == "conv_igemm":
                 allf = [v for k, v in pmc.items() if isinstance(v, dict) and "launches" in v]
@@ -295,18 +295,18 @@ def main():
                 tb = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in fams)
                 nl = sum(v["launches"] for v in fams)
                 out["roofline"]["traffic"] = round(tb / nl / 1e6, 2)
-                out["roofline"]["traffic_unit"] = f"MB HBM per launch (PMC, profiles/r03_pmc_hbm_traffic{sfx}.json @ csrc {sha})"
+                out["roofline"]["traffic_unit"] = f"MB HBM per launch (PMC, profiles/r04_pmc_hbm_traffic{sfx}.json @ csrc {sha})"
                 out["roofline"]["alg_mbytes_per_launch_unfused"] = round(d["bytes"] / d["launches"] / 1e6, 2)
                 step_bytes = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in allf)
                 out["hbm"] = {"gbytes_per_step_pmc": round(step_bytes / 1e9, 3), "gbytes_per_s": round(step_bytes / elapsed * args.steps / 1e9, 1),
                               "frac_of_peak": round(step_bytes / elapsed * args.steps / 1e9 / HBM_PEAK_GBS, 4), "peak_gbytes_per_s": HBM_PEAK_GBS,
                               "note": "whole step: PMC bytes of one steady step (FETCH_SIZE x 2 + WRITE_SIZE) / this run's ms_per_step"}
-            with open(os.path.join(ROOT, "profiles", f"r03_rocprofv3_kernel_summary{sfx}.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", f"r04_rocprofv3_kernel_summary{sfx}.json")) as fh:
                 rp = json.load(fh)
             if rp.get("csrc_sha") == sha and rp.get("config") == tag:
                 out["roofline"]["avg_launch_us_rocprofv3"] = rp["conv_igemm_all"]["avg_us"]
                 out["roofline"]["achieved_rocprofv3"] = round(d["flops"] / (rp["conv_igemm_all"]["us_per_step"] * 1e-6) / 1e12, 2)
-            with open(os.path.join(ROOT, "profiles", f"r03_pmc_mfma_util{sfx}.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", f"r04_pmc_mfma_util{sfx}.json")) as fh:
                 mu = json.load(fh)
             if mu.get("csrc_sha") == sha and mu.get("config") == tag:
                 out["roofline"]["mfma_busy_frac_pmc"] = mu["conv_igemm_all"]["mfma_util"]
@@ -415,6 +415,26 @@ def main():
             out["cpu_baseline"] = {"value": round(nb * reps / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
                                    "sample": f"CPU oracle (fp32 eager PyTorch restatement of the reference path), RT-DETR-{args.arch.upper()} "
                                              f"{H}x{H} bs={nb}, {reps} timed batches after 1 warm-up, torch threads={cores}"}
+            # BASELINE configs[0] by the reference's own protocol (tests/test_inference.py:76-115): R18 640x640, ONE frame per call, 10 warm-ups,
+            # then timed single-frame calls with mean/std/min/max/p50/p95/p99 - the CPU figure beside detect_host_ms.r18_640x640
+            print("[bench] cpu baseline R18 bs=1 ...", file=sys.stderr, flush=True)
+            a18 = ARCHS["r18"]
+            w18 = synth_weights(a18, 0)
+            fr18 = np.random.default_rng(7640).integers(0, 255, (640, 640, 3), dtype=np.uint8)
+            for _ in range(10):
+                orc.detect_batch(a18, w18, [fr18], (640, 640))
+            ts = []
+            for _ in range(30):
+                t1 = time.perf_counter()
+                orc.detect_batch(a18, w18, [fr18], (640, 640))
+                ts.append((time.perf_counter() - t1) * 1e3)
+            ts = np.asarray(ts)
+            out["cpu_baseline_r18_bs1"] = {
+                **{k: round(float(v), 2) for k, v in (("mean", ts.mean()), ("std", ts.std()), ("min", ts.min()), ("max", ts.max()),
+                                                      ("p50", np.percentile(ts, 50)), ("p95", np.percentile(ts, 95)), ("p99", np.percentile(ts, 99)))},
+                "fps": round(1000.0 / float(ts.mean()), 2), "unit": "ms per frame", "cores": cores, "kind": "port",
+                "sample": f"CPU oracle, RT-DETR-R18 640x640, one uint8 BGR frame per call (detect_batch of 1), 10 warm-ups + 30 timed calls, "
+                          f"torch threads={cores}; the GPU side of the same protocol is detect_host_ms.r18_640x640"}
         print(json.dumps(out), flush=True)
     if rccl_ranks:
         dist.barrier()

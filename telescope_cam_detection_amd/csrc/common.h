@@ -213,6 +213,7 @@ bool conv_split_supported(const ConvArgs& a);   // F16X2 input: does the split k
 int conv_npad(int N);
 // stem.2 + the 3x3 / stride-2 max-pool in one pass (f16x3 engine): `a` = the conv whose output would be pooled into `pooled`
 bool conv_avg_supported(const ConvArgs& a);      // can this launch (shapes for ONE image) carry ConvArgs::avg_y?
+bool conv_sx_batch_fits(const ConvArgs& a);      // ... and do the tensors of THIS plan's batch fit the streaming kernel's 2 GiB descriptors?
 bool conv_pool_supported(const ConvArgs& a, const Tensor& pooled);
 size_t conv_pool_side_bytes(const ConvArgs& a);
 void launch_conv_pool(const ConvArgs& a, const Tensor& pooled, void* side, hipStream_t s);
@@ -357,7 +358,9 @@ void launch_split_to_f32(const void* src, int64_t lds, float* dst, int64_t ldd, 
 // channel sits at channel offset `pix_off` (= pixel index * ld); the lo half is SPLIT_GROUP elements further
 __device__ __forceinline__ long long split_off(long long pix_off, int c) { return 2 * pix_off + ((c >> 5) << 6) + (c & 31); }
 __device__ __forceinline__ void split2(float v, sp16& hi, sp16& lo) {
-  v = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);   // saturate instead of inf (hi = inf would make lo = NaN)
+  // saturate instead of inf (hi = inf would make lo = NaN) - but a NaN stays a NaN (v_med3 would turn it into a finite bound and hide
+  // an upstream fault from every isfinite check; the host mirror _capi.to_split keeps it as well)
+  v = (v != v) ? v : __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
   hi = (sp16)v;
   lo = (sp16)(v - (float)hi);
 }

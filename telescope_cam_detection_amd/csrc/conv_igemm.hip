@@ -3074,6 +3074,19 @@ bool conv_dual_supported(const ConvArgs& a) {
 // N = 512 (K = 128) -> 128 channels.  Asked per plan (batch size): the fused and the separate form use the same filter tensors and
 // give bit-identical outputs, so plans of different batch sizes may differ.
 static bool sx_shape_ok(const ConvArgs& a);
+// The streaming kernel addresses every tensor through a 2 GiB buffer descriptor and counts tiles in 30 bits: limits that depend on the
+// BATCH, unlike every shape test (which looks at one image).  The plan builder asks this with the plan's real batch before it relies on a
+// fusion that only the streaming kernel implements (ConvArgs::avg_y); dispatch_sx applies the same limits.
+bool conv_sx_batch_fits(const ConvArgs& a) {
+  auto span = [](const Tensor& t) { return ((long long)(t.n - 1) * t.bstride + ((long long)t.h * t.w - 1) * t.ld + t.c) * 4; };
+  const Tensor& y = a.y;
+  if (span(y) >= (1ll << 31)) return false;
+  if (a.res_mode != RES_NONE && span(a.res) >= (1ll << 31)) return false;
+  if (a.next_y.p && span(a.next_y) >= (1ll << 31)) return false;
+  if (a.avg_y.p && span(a.avg_y) >= (1ll << 31)) return false;
+  const long long ntiles = a.avg_y.p ? (long long)y.n * (y.h / 2) * (y.w / 16) : ((long long)y.n * y.h * y.w + 31) / 32;
+  return ntiles < (1ll << 30);
+}
 bool conv_avg_supported(const ConvArgs& a) {
   const Tensor& x = a.x;
   const Tensor& y = a.y;
@@ -3592,6 +3605,7 @@ static void launch_conv_split(const ConvArgs& a, hipStream_t s) {
   // thin 1x1 expand convs on wide grids (stage-0 / stage-1 c3): the streaming kernel, with the next block's reduce conv riding on it
   if (dispatch_sx(k, a, x_bytes, x2_bytes, s)) { HIP_CHECK(hipGetLastError()); return; }
   RTD_CHECK(a.next_y.p == nullptr, 1, "conv (f16x3): a fused following conv exists in the streaming kernel only");
+  RTD_CHECK(a.avg_y.p == nullptr, 1, "conv (f16x3): the fused vd-shortcut average exists in the streaming kernel only (the plan must fall back to the avg-pool launch)");
   // Direct 3x3 kernels for the narrow layers on wide maps.  Chosen on the per-IMAGE tile count: every batch size runs the same arithmetic
   // (batch invariance is bit-exact).  32 input channels (stem.1, stem.2): every input pixel is staged once instead of nine times
   if (o.conv_reg && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !dual && a.res_mode == RES_NONE && x.c == 32 && (y.c == 32 || y.c == 64) &&

@@ -515,7 +515,7 @@ struct Builder {
     a.opts = &e->conv_opts;
     a.prefer256 = e->cfg.profile == RTD_PROFILE_THROUGHPUT;
     if (avg_pending) { a.avg_y = avg_pending_y; if (dry) a.avg_y.p = nullptr; avg_pending = false; }
-    slab_need = std::max(slab_need, conv_split_slab_bytes(a));
+    slab_need[lane] = std::max(slab_need[lane], conv_split_slab_bytes(a));
     const double M = (double)y.pixels();
     const double kreal = (double)k * k * (real_cin ? real_cin : x.c) + (x2 ? x2->c : 0);
     const double flops = 2.0 * M * y.c * kreal + (next_y ? 2.0 * M * y.c * next_y->c : 0.0);
@@ -526,7 +526,7 @@ struct Builder {
       // chain: the previous conv launch of the plan prefetches THIS filter while it runs (ConvArgs::pf)
       if (last_conv) { last_conv->pf = w.w; last_conv->pf_bytes = (size_t)w.Npad * w.Kpad * (x.dt == F32 ? 4 : 2); }
       last_conv = ap;
-      convs.push_back(ap);
+      convs.push_back({ap, lane});
     }
     push(name, "conv_igemm", flops, bytes, [ap](hipStream_t s) { launch_conv(*ap, s); });
   }
@@ -535,15 +535,18 @@ struct Builder {
   Tensor avg_pending_y;
   std::shared_ptr<ConvArgs> last_conv;
   // two-pass split-K workspace of this plan: sized for the plan's own batch (the slice count depends on per-image extents only, so every
-  // batch size up to max_batch runs the same arithmetic), allocated once every conv is known and handed to all of them
-  std::vector<std::shared_ptr<ConvArgs>> convs;
-  size_t slab_need = 0;
+  // batch size up to max_batch runs the same arithmetic), allocated once every conv is known.  ONE SLAB PER LANE: launches of a lane are
+  // sequential, but lane 1 (the side stream) runs beside lane 0 - two splitting convs on different lanes must never share partial sums.
+  std::vector<std::pair<std::shared_ptr<ConvArgs>, int>> convs;
+  size_t slab_need[2] = {0, 0};
   void finish_workspace() {
-    if (!slab_need) return;
-    ConvWorkspace ws;
-    ws.slab = (float*)alloc(slab_need);
-    ws.slab_bytes = slab_need;
-    for (auto& c : convs) c->ws = ws;
+    ConvWorkspace ws[2];
+    for (int l = 0; l < 2; ++l) {
+      if (!slab_need[l]) continue;
+      ws[l].slab = (float*)alloc(slab_need[l]);
+      ws[l].slab_bytes = slab_need[l];
+    }
+    for (auto& c : convs) c.first->ws = ws[c.second];
   }
   Tensor linear(const std::string& name, const Tensor& x, int N, int odt, int act, const Tensor* res = nullptr,
                 const std::string& tname = "") {
@@ -772,7 +775,14 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
           probe.y = out; probe.y.p = (void*)16; probe.y.n = 1;
           probe.res = res; probe.res.p = (void*)16; probe.res.n = 1; probe.res_mode = RES_PRE;
           if (nx) { probe.next_y = *nx; probe.next_y.p = (void*)16; probe.next_y.n = 1; }
-          if (conv_avg_supported(probe)) {
+          // ... except the 2 GiB descriptor limits, which depend on the batch: beyond them (R50 / R101 at 1280 px from batch 41 on) this
+          // plan keeps the separate avg-pool launch - bit-identical results (test_f16x3_fused_vd_shortcut_average_equals_the_avgpool_launch)
+          ConvArgs whole = probe;
+          whole.x.n = whole.y.n = whole.res.n = n;
+          if (nx) whole.next_y.n = n;
+          whole.avg_y = out; whole.avg_y.p = (void*)16; whole.avg_y.n = n; whole.avg_y.h = oh / 2; whole.avg_y.w = ow / 2;
+          whole.avg_y.ld = cout; whole.avg_y.bstride = (int64_t)(oh / 2) * (ow / 2) * cout;
+          if (conv_avg_supported(probe) && conv_sx_batch_fits(whole)) {
             prepooled = B.act(P, n, oh / 2, ow / 2, cout);
             have_prepooled = true;
             B.avg_pending = true; B.avg_pending_y = prepooled;

@@ -379,6 +379,35 @@ def test_conv_split_f16x3(L, case):
     _capi.debug_option("reset", 0)
 
 
+@pytest.mark.parametrize("shape", [(1, 40, 40, 64, 128, 1), (1, 160, 160, 64, 256, 1), (1, 24, 24, 64, 64, 3)])
+def test_a_nan_stays_a_nan_through_the_pair_format(L, shape):
+    """split2 saturates at +-65504 instead of producing inf - but a NaN must stay a NaN, on the device (epilogue of every
+    pair kernel: tiled, streaming, direct 3x3 paths) as in the host mirror `_capi.to_split`: otherwise an upstream fault would be
+    laundered into a finite bound and no isfinite check could see it.  An overflow still saturates."""
+    from telescope_cam_detection_amd import _capi
+    B, H, W, Cin, Cout, k = shape
+    x = torch.ones(B, H, W, Cin) * 0.5
+    x[0, 3, 5, 7] = float("nan")
+    x[0, 9, 2, 1] = 3.0e38                                     # beyond fp16: saturates to 65504 in both mirrors
+    xs = _capi.to_split(x.numpy())
+    back = _capi.from_split(xs)
+    assert np.isnan(back[0, 3, 5, 7]) and back[0, 9, 2, 1] == 65504.0 and np.isfinite(np.delete(back.reshape(-1), (3 * W + 5) * Cin + 7)).all()
+    w = torch.zeros(Cout, Cin, k, k)
+    for c in range(Cout):
+        w[c, c % Cin, k // 2, k // 2] = 1.0                    # output channel c copies input channel c % Cin (centre tap)
+    wd = w.permute(0, 2, 3, 1).contiguous().cuda()
+    bd = torch.zeros(Cout).cuda()
+    xd = torch.from_numpy(xs.view(np.int16)).cuda()
+    yd = torch.full((B, H, W, 2 * Cout), -1, dtype=torch.int16, device="cuda")
+    ck(L, L.rtd_op_conv(_capi.DT_F16X2, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, yd.data_ptr(), B, H, W, Cin, Cout, k, k, 1, k // 2, 0, 0, 0))
+    got = _capi.from_split(yd.cpu().numpy().view(np.uint16))
+    nan_at = np.argwhere(np.isnan(got))
+    assert len(nan_at) > 0 and all(tuple(i[:3]) == (0, 3, 5) or k == 3 for i in nan_at)        # visible where it was put (3x3: also its window)
+    assert np.isnan(got[0, 3, 5, 7])
+    assert got[0, 9, 2, 1] == 65504.0                          # overflow saturates, finite
+    assert got[0, 20, 20, 3] == 0.5
+
+
 SX_NEXT_CASES = [
     # B, H, W, Cin, C2 (0 = no second input), Cnext, act, res_mode, next_act
     (2, 160, 160, 64, 64, 64, "relu", 0, "relu"),    # stage-0 block 0: c3 + folded shortcut, next block's c1 fused

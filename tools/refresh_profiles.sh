@@ -1,11 +1,11 @@
 #!/bin/bash
 # Regenerates every measurement committed under profiles/ on the GPU box (one gpurun call each; a part that times out stops the script):
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r03 r50'      (default config: R50 640^2 bs 8, f16x3)
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r03 r101'     (BASELINE configs[2]: R101 1280^2 bs 4)
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r03 lines'    (the other bench lines)
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r04 r50'      (default config: R50 640^2 bs 8, f16x3)
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r04 r101'     (BASELINE configs[2]: R101 1280^2 bs 4)
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r04 lines'    (the other bench lines)
 # then, back in the container, tools/summarize_profiles.py turns the CSVs into profiles/<round>_*.json (commands at the end of this file)
 set -u
-R=${1:-r03}
+R=${1:-r04}
 WHAT=${2:-r50}
 export TMPDIR=/tmp
 O=gpurun_out/$R
@@ -47,7 +47,7 @@ else
 fi
 find $O -name "*.csv" | head -40
 # back in the container (kernel sources unchanged since the run):
-#   T=gpurun_out/r03; P=profiles/r03
+#   T=gpurun_out/r04; P=profiles/r04
 #   python tools/summarize_profiles.py trace $(ls $T/trace/runc/*kernel_trace.csv) ${P}_rocprofv3_kernel_summary.json
 #   python tools/summarize_profiles.py pmc $(ls $T/pmc_fetch/runc/*counter_collection.csv) $(ls $T/pmc_write/runc/*counter_collection.csv) ${P}_pmc_hbm_traffic.json
 #   python tools/summarize_profiles.py mfma $(ls $T/pmc_mfma/runc/*counter_collection.csv) ${P}_pmc_mfma_util.json
