@@ -227,32 +227,55 @@ __device__ void row_gemm_split(const sp16* Ah, const sp16* Al, int lda, const De
   }
 }
 
-// in-place LayerNorm of Xs[16][D] (D <= 256, D % 4 == 0); each wave owns DR / NW rows
-__device__ void row_ln(float* Xs, int ldx, int D, const DecLN& P, int wave, int lane) {
-  for (int r = wave * (DR / NW); r < (wave + 1) * (DR / NW); ++r) {
-    float v[4];
-    float s = 0.f;
+// in-place LayerNorm of Xs[16][D] (D <= 256, D % 4 == 0); each wave owns DR / NW rows.  The affine parameters come in registers: the caller
+// requests them (ln_fetch) BEFORE the GEMM that produces the rows, so their L2 round trip (~1.5 us of this 2.5 us phase when it was issued
+// here, tools/dec_stamps.py) runs under that GEMM.  Same arithmetic, same order: bit-identical rows.
+struct LNRegs { float g[4], b[4]; };
+__device__ __forceinline__ LNRegs ln_fetch(const DecLN& P, int D, int lane) {
+  LNRegs R;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    R.g[i] = c < D ? P.g[c] : 0.f;
+    R.b[i] = c < D ? P.b[c] : 0.f;
+  }
+  return R;
+}
+__device__ __forceinline__ void row_ln(float* Xs, int ldx, int D, const LNRegs& P, int wave, int lane) {
+  constexpr int RPW = DR / NW;                                  // rows per wave: their reductions are independent and interleave
+  float v[RPW][4], s[RPW];
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    const int r = wave * RPW + j;
+    s[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = lane + 64 * i;
-      v[i] = c < D ? Xs[r * ldx + c] : 0.f;
-      s += v[i];
+      v[j][i] = c < D ? Xs[r * ldx + c] : 0.f;
+      s[j] += v[j][i];
     }
-    s = wave_sum64(s);
-    const float mean = s / (float)D;
-    float sq = 0.f;
+  }
+  float mean[RPW], sq[RPW];
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) mean[j] = wave_sum64(s[j]) / (float)D;
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    sq[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = lane + 64 * i;
-      const float d = c < D ? v[i] - mean : 0.f;
-      sq += d * d;
+      const float d = c < D ? v[j][i] - mean[j] : 0.f;
+      sq[j] += d * d;
     }
-    sq = wave_sum64(sq);
-    const float rstd = rsqrtf(sq / (float)D + 1e-5f);
+  }
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    const int r = wave * RPW + j;
+    const float rstd = rsqrtf(wave_sum64(sq[j]) / (float)D + 1e-5f);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = lane + 64 * i;
-      if (c < D) Xs[r * ldx + c] = (v[i] - mean) * rstd * P.g[c] + P.b[c];
+      if (c < D) Xs[r * ldx + c] = (v[j][i] - mean[j]) * rstd * P.g[i] + P.b[i];
     }
   }
 }
@@ -623,10 +646,11 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     __syncthreads();
     DEC_STAMP(12);  // self-attention
     // ---- self-attention output projection + residual + LN1 (HF:v2.py:395-405) ---------------------
+    const LNRegs ln1 = ln_fetch(a.ln1, D, lane);
     DEC_GEMM(ACT_NONE, sA, LDH, a.o, sH, LDH, sH, LDH, a.op);      // x = hs + att @ Wo   (in place: each element read then written by one lane)
     __syncthreads();
     DEC_STAMP(1);   // o_proj
-    row_ln(sH, LDH, D, a.ln1, wave, lane);
+    row_ln(sH, LDH, D, ln1, wave, lane);
     __syncthreads();
     DEC_STAMP(2);   // ln1
   }
@@ -646,9 +670,10 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     __syncthreads();
     DEC_STAMP(4);   // sampling
     // ---- output projection + residual + LN2 (HF:v2.py:221,418-421) ----------------------------------
+    const LNRegs ln2 = ln_fetch(a.ln2, D, lane);
     DEC_GEMM(ACT_NONE, sA, LDH, a.op, sH, LDH, sH, LDH, a.fc2);
     __syncthreads();
-    row_ln(sH, LDH, D, a.ln2, wave, lane);
+    row_ln(sH, LDH, D, ln2, wave, lane);
     __syncthreads();
     DEC_STAMP(5);   // op + ln2
   }
@@ -666,11 +691,12 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     DEC_TOUCH(a.bb0);
     __syncthreads();
     DEC_STAMP(6);   // fc1
+    const LNRegs ln3 = ln_fetch(a.ln3, D, lane);
     if (SPLIT) row_gemm_split<ACT_NONE, (SPLIT != 2) >(sFh, sFl, LDFB, a.fc2, sH, LDH, sH, LDH, nullptr, nullptr, 0, wave, lane, rot);
     else row_gemm<ACT_NONE>(sF, LDF, a.fc2, sH, LDH, sH, LDH, wave, lane, rot);
     DEC_TOUCH(a.bb1);
     __syncthreads();
-    row_ln(sH, LDH, D, a.ln3, wave, lane);
+    row_ln(sH, LDH, D, ln3, wave, lane);
     __syncthreads();
     DEC_STAMP(7);   // fc2 + ln3
   }
