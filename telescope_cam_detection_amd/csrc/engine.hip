@@ -1014,7 +1014,7 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
     const int32_t* forced = e->forced_idx; const int32_t* flag = e->force_flag;
     B.push("dec.enc_topk", "topk", 0.0, (double)n * S * 4 * 6, [mx, n, S, Q, tk](hipStream_t s) { launch_topk(mx, n, S, Q, tk, nullptr, s); });
     // test hook (rtd_debug_force_topk): overrides the selection with the caller's indices.  Not part of the product graph: the op is
-    // skipped - and absent from the captured hipGraph - until the hook is used on this handle
+    // skipped - and absent from the built hipGraph - until the hook is used on this handle
     B.push("dec.force_topk", "select", 0.0, 0.0, [tk, forced, flag, n, Q](hipStream_t s) {
       launch_force_idx(tk, forced, flag, n * Q, s);
     });
