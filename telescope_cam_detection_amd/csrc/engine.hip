@@ -78,7 +78,7 @@ struct Op {
   const char* kernel;
   double flops, bytes;
   std::function<void(hipStream_t)> run;
-  bool debug_only = false;   // runs (and is captured) only on handles that asked for it (rtd_debug_force_topk)
+  bool debug_only = false;   // runs (and becomes a graph node) only on handles that asked for it (rtd_debug_force_topk)
   // lane 1 = the engine's side stream: independent work that runs BESIDE the main stream's (the query-selection chain - enc_output,
   // scoring, top-k, gather: narrow grids, 150 us - next to the value projection of all decoder layers: 210 us).  kind: 0 launch,
   // 1 fork (side waits for everything enqueued on main so far), 2 join (main waits for the side stream)
