@@ -316,6 +316,8 @@ struct DecArgs {
   float* logits;            // mode 2: [B*Q, C]
   void* out_bf16;           // mode 4: write the output tokens as bf16 here instead of fp32 hs_out (nullptr = fp32)
   float* stamps;            // diagnostic: [blocks][16] phase end times (10 ns units) or nullptr
+  int probe;                // diagnostic, timing only (results wrong), rtd_debug_option "dec_stamps" bits 1 / 2: the linear layers skip their MFMAs (filter
+                            // stream alone) / their filter loads (arithmetic alone): tools/dec_stamps.py RTD_DEC_PROBE
   // weights
   DecLin o, offaw, op, fc1, fc2, bb0, bb1, bb2, qp0, qp1, qk, v, cls;
   DecLN ln1, ln2, ln3;

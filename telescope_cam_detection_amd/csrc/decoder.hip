@@ -136,8 +136,8 @@ __device__ __forceinline__ void split_rows(const float* Xs, int ldx, int K, sp16
 // W[n0 + (lane & 15)][same k].  Output: fp32 Ys and / or a hi/lo split (Yh, Yl) for a following GEMM.
 template <int ACT, bool WLO = true>   // WLO = false: the filter's lo half is neither loaded nor multiplied (hi-only filter, split activations)
 __device__ void row_gemm_split(const sp16* Ah, const sp16* Al, int lda, const DecLin& L, float* Ys, int ldy, const float* Rs, int ldr,
-                               sp16* Yh, sp16* Yl, int ldyb, int wave, int lane, int rot) {
-  constexpr int PF = 2;   // K steps of filter fragments in flight per wave (3 changed nothing: measured in round 2)
+                               sp16* Yh, sp16* Yl, int ldyb, int wave, int lane, int rot, int probe = 0) {
+  constexpr int PF = 2;   // K steps of filter fragments in flight per wave (round 2: 3 changed nothing; round 4: 4 needs 128 VGPRs of fragments - 256 + 704 B of scratch, 140 us per layer)
   const int ntiles = (L.N + 15) >> 4;
   const int r16 = lane & 15, q = lane >> 4;
   const sp16* ah = Ah + r16 * lda + 8 * q;
@@ -195,10 +195,11 @@ __device__ void row_gemm_split(const sp16* Ah, const sp16* Al, int lda, const De
       for (int u = 0; u < PF; ++u) {
         if (it + u < nsteps) {
           __builtin_amdgcn_sched_barrier(0);
-          mma(wh0[u], wl0[u], wh1[u], wl1[u], cur);
+          if (!(probe & 1)) mma(wh0[u], wl0[u], wh1[u], wl1[u], cur);
+          else { acc0[0] += (float)wh0[u][1][7] + (float)wl1[u][1][7]; acc1[0] += (float)wh1[u][1][7] + (float)wl0[u][1][7]; }   // probe: waits for the step's loads, no MFMA
           cur = nxt(cur);
           __builtin_amdgcn_sched_barrier(0);
-          if (it + u + PF < nsteps) { load(wh0[u], wl0[u], wh1[u], wl1[u], pf); pf = nxt(pf); }
+          if (it + u + PF < nsteps && !(probe & 2)) { load(wh0[u], wl0[u], wh1[u], wl1[u], pf); pf = nxt(pf); }
         }
       }
     }
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (SPLIT) {                                                                                             \
       split_rows(X, LDXS, (LW).K, sXh, sXl, LDX, tid);                                                       \
       __syncthreads();                                                                                       \
-      row_gemm_split<ACT, (SPLIT != 2) >(sXh, sXl, LDX, LW, Y, LDY, R, LDRS, nullptr, nullptr, 0, wave, lane, rot);         \
+      row_gemm_split<ACT, (SPLIT != 2) >(sXh, sXl, LDX, LW, Y, LDY, R, LDRS, nullptr, nullptr, 0, wave, lane, rot, a.probe);         \
     } else {                                                                                                 \
       row_gemm<ACT>(X, LDXS, LW, Y, LDY, R, LDRS, wave, lane, rot);                                          \
     }                                                                                                        \
@@ -682,8 +683,8 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (SPLIT) {
       split_rows(sH, LDH, a.fc1.K, sXh, sXl, LDX, tid);
       __syncthreads();
-      if (a.mode == 4) row_gemm_split<ACT_GELU, (SPLIT != 2) >(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
-      else row_gemm_split<ACT_RELU, (SPLIT != 2) >(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot);
+      if (a.mode == 4) row_gemm_split<ACT_GELU, (SPLIT != 2) >(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot, a.probe);
+      else row_gemm_split<ACT_RELU, (SPLIT != 2) >(sXh, sXl, LDX, a.fc1, nullptr, 0, nullptr, 0, sFh, sFl, LDFB, wave, lane, rot, a.probe);
     } else {
       if (a.mode == 4) row_gemm<ACT_GELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane, rot);
       else row_gemm<ACT_RELU>(sH, LDH, a.fc1, sF, LDF, nullptr, 0, wave, lane, rot);
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     __syncthreads();
     DEC_STAMP(6);   // fc1
     const LNRegs ln3 = ln_fetch(a.ln3, D, lane);
-    if (SPLIT) row_gemm_split<ACT_NONE, (SPLIT != 2) >(sFh, sFl, LDFB, a.fc2, sH, LDH, sH, LDH, nullptr, nullptr, 0, wave, lane, rot);
+    if (SPLIT) row_gemm_split<ACT_NONE, (SPLIT != 2) >(sFh, sFl, LDFB, a.fc2, sH, LDH, sH, LDH, nullptr, nullptr, 0, wave, lane, rot, a.probe);
     else row_gemm<ACT_NONE>(sF, LDF, a.fc2, sH, LDH, sH, LDH, wave, lane, rot);
     DEC_TOUCH(a.bb1);
     __syncthreads();
@@ -768,10 +769,10 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
     if (SPLIT) {
       split_rows(sR, LDR, a.qp0.K, sXh, sXl, LDX, tid);
       __syncthreads();
-      row_gemm_split<ACT_RELU, (SPLIT != 2) >(sXh, sXl, LDX, a.qp0, nullptr, 0, nullptr, 0, sQh, sQl, LDQB, wave, lane, rot);
+      row_gemm_split<ACT_RELU, (SPLIT != 2) >(sXh, sXl, LDX, a.qp0, nullptr, 0, nullptr, 0, sQh, sQl, LDQB, wave, lane, rot, a.probe);
       DEC_TOUCH(a.v);
       __syncthreads();
-      row_gemm_split<ACT_NONE, (SPLIT != 2) >(sQh, sQl, LDQB, a.qp1, sP, LDH, nullptr, 0, nullptr, nullptr, 0, wave, lane, rot);
+      row_gemm_split<ACT_NONE, (SPLIT != 2) >(sQh, sQl, LDQB, a.qp1, sP, LDH, nullptr, 0, nullptr, nullptr, 0, wave, lane, rot, a.probe);
     } else {
       row_gemm<ACT_RELU>(sR, LDR, a.qp0, sT, LDQ, nullptr, 0, wave, lane, rot);
       DEC_TOUCH(a.v);

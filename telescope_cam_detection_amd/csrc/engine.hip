@@ -1113,7 +1113,8 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
       a.bb0 = lin(nm("dec.bbox.%d.0", i), dm, dm); a.bb1 = lin(nm("dec.bbox.%d.1", i), dm, dm); a.bb2 = lin(nm("dec.bbox.%d.2", i), 4, dm);
       if (last) a.cls = lin("dec.cls", C, dm);
       else { a.qk = lin(nm("dec.l%d.sa.qk", i + 1), 2 * dm, dm); a.v = lin(nm("dec.l%d.sa.v", i + 1), dm, dm); }
-      if (e->opts.dec_stamps && i == std::min(2, NL - 1)) {
+      a.probe = e->opts.dec_stamps >> 1;                           // diagnostic (timing only): bits 1 / 2 of "dec_stamps"
+      if ((e->opts.dec_stamps & 1) && i == std::min(2, NL - 1)) {
         const int blocks = n * ((Q + 15) / 16);
         Tensor st = B.act(F32, 1, blocks, 1, 16, "dec_stamps");
         a.stamps = (float*)st.p;

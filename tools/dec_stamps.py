@@ -8,7 +8,8 @@ from telescope_cam_detection_amd.arch import ARCHS
 from telescope_cam_detection_amd.synth import noise_frame
 from telescope_cam_detection_amd.weights import fold_weights, pack_blob, synth_weights
 arch = ARCHS["r50"]; B = 8
-_capi.debug_option("dec_stamps", 1)
+# RTD_DEC_PROBE: 1 = the linear layers skip their MFMAs (filter stream alone), 2 = skip their filter loads (arithmetic alone); results are wrong, timings only
+_capi.debug_option("dec_stamps", 1 + 2 * int(os.environ.get("RTD_DEC_PROBE", "0")))
 eng = _capi.Engine(arch, pack_blob(fold_weights(arch, synth_weights(arch, 0))), 0, _capi.precision_code(os.environ.get("RTD_PREC", "f16x3")), B, (640, 640), use_graph=False)
 frames = [noise_frame(i, 640, 640) for i in range(B)]
 for _ in range(3):
