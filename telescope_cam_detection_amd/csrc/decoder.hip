@@ -642,8 +642,10 @@ __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
 
   if (has_attn) {
     // ---- self-attention (q in sT, K/V fragments from the previous launch) -> sA ----------------------------
-    if (SPLIT && a.attn_split) self_attention_rows_split(a, sT, LDQ, sA, LDH, b, tiles, wave, lane);
-    else self_attention_rows(a, sT, LDQ, sA, LDH, b, tiles, wave, lane);
+    for (int head = wave; head < a.heads; head += NW) {          // one head per wave and turn (NW == heads: one turn)
+      if (SPLIT && a.attn_split) self_attention_rows_split(a, sT, LDQ, sA, LDH, b, tiles, head, lane);
+      else self_attention_rows(a, sT, LDQ, sA, LDH, b, tiles, head, lane);
+    }
     __syncthreads();
     DEC_STAMP(12);  // self-attention
     // ---- self-attention output projection + residual + LN1 (HF:v2.py:395-405) ---------------------
@@ -971,7 +973,7 @@ void launch_gather_ln(const float* x, int64_t ldx, int rows_per_image, const int
 
 void launch_dec_layer(const DecArgs& a, hipStream_t s) {
   RTD_CHECK(a.D == 256 && a.D / a.heads == 32 && a.ffn <= 1024 && a.C <= 512, 1, "fused decoder: d_model 256, head dim 32, ffn <= 1024");
-  RTD_CHECK(a.n_levels == 3 && a.n_points == 4 && a.heads == NW, 1, "fused decoder: 3 levels x 4 points, 8 heads");
+  RTD_CHECK(a.n_levels == 3 && a.n_points == 4 && a.heads % NW == 0, 1, "fused decoder: 3 levels x 4 points, heads a multiple of the wave count");
   const int tiles = (a.Q + DR - 1) / DR;
   if (a.split == 2) rtd_launch(dec_layer_kernel<2>, dim3(a.B * tiles), dim3(NT), 0, s, a);
   else if (a.split) rtd_launch(dec_layer_kernel<1>, dim3(a.B * tiles), dim3(NT), 0, s, a);
