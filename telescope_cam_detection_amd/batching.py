@@ -99,7 +99,8 @@ class _Lane:
     Detectors with the pipelined pair (RTDETRDetector.detect_batch_async / detect_batch_collect: the work runs on the detector's own
     HIP stream between the two calls) overlap with the other lanes; a plain `detect_batch` object simply does its work in `finish`."""
 
-    REBUILD_AFTER = 3        # consecutive failed batches after which the lane rebuilds its detector (a wedged engine must not be reused forever)
+    REBUILD_AFTER = 3        # consecutive ENGINE failures after which the lane rebuilds its detector (a wedged engine must not be reused forever)
+    MAX_REBUILDS = 3         # ... at most this often: a detector that keeps failing after three fresh engines is not helped by a fourth
 
     def __init__(self, detector: Any):
         self.detector = detector
@@ -108,6 +109,7 @@ class _Lane:
         self._held = None
         self.fail_streak = 0
         self.rebuilds = 0
+        self.rebuild_seconds = 0.0
 
     def begin(self, frames: list) -> None:
         self._held = self.detector.detect_batch_async(frames) if self._overlapped else frames
@@ -119,27 +121,54 @@ class _Lane:
     def succeeded(self) -> None:
         self.fail_streak = 0
 
-    def failed(self) -> None:
-        """Called by whoever holds the lane (former or finisher) when its batch raised.  After REBUILD_AFTER failures in a row the
-        detector is loaded afresh - a new engine handle, new streams, new graphs - and the old engine is closed."""
+    @staticmethod
+    def engine_fault(e: BaseException) -> bool:
+        """True for failures that say something about the ENGINE's state (a HIP runtime error, a call-order error).  A malformed
+        frame (TypeError / ValueError, RTD_E_INVALID), an allocation failure (torch.cuda.OutOfMemoryError: a fresh engine would fail
+        the same way, with the old arenas still resident) and a detector that miscounts its results are the input's or the caller's
+        business: they are answered with [] and never cost a rebuild."""
+        try:
+            from ._capi import RTD_E_HIP, RTD_E_STATE, RtdError
+        except Exception:                                    # a foreign detector without the library: any RuntimeError counts
+            return isinstance(e, RuntimeError)
+        if isinstance(e, RtdError):
+            return e.code in (RTD_E_HIP, RTD_E_STATE)
+        return False
+
+    def failed(self, e: Optional[BaseException] = None) -> None:
+        """Called by whoever holds the lane (former or finisher) when its batch raised.  After REBUILD_AFTER engine failures in a row
+        the old engine is closed FIRST (its weights, arenas and graphs are gone before the new ones are allocated) and the detector is
+        loaded afresh - a new handle, new streams, new graphs.  The rebuild runs on the calling pipeline thread: its duration is
+        measured and logged, and it happens at most MAX_REBUILDS times per lane."""
         self._held = None
+        if e is not None and not self.engine_fault(e):
+            return
         self.fail_streak += 1
         if self.fail_streak < self.REBUILD_AFTER or not hasattr(self.detector, "load_model"):
             return
-        old = getattr(getattr(self.detector, "model", None), "engine", None)
+        self.fail_streak = 0
+        if self.rebuilds >= self.MAX_REBUILDS:
+            logger.error(f"batch coordinator: detector still failing after {self.rebuilds} rebuilds; keeping it as it is")
+            return
+        t0 = time.monotonic()
+        model = getattr(self.detector, "model", None)
+        old = getattr(model, "engine", None)
+        if old is not None:
+            try:
+                self.detector.model = None                   # detect() / detect_batch() answer [] while there is no engine
+                old.close()
+            except Exception as ce:
+                logger.error(f"batch coordinator: closing the failed engine raised: {ce}")
         try:
             ok = self.detector.load_model(max_retries=1)
-        except Exception as e:                               # load_model of the drop-in never raises; a foreign detector might
-            logger.error(f"batch coordinator: rebuilding a detector raised: {e}")
+        except Exception as le:                              # load_model of the drop-in never raises; a foreign detector might
+            logger.error(f"batch coordinator: rebuilding a detector raised: {le}")
             ok = False
         self.rebuilds += 1
-        self.fail_streak = 0
-        if ok and old is not None and old is not getattr(getattr(self.detector, "model", None), "engine", None):
-            try:
-                old.close()
-            except Exception:
-                pass
-        logger.warning(f"batch coordinator: detector rebuilt after {self.REBUILD_AFTER} failed batches in a row ({'ok' if ok else 'FAILED'})")
+        dt = time.monotonic() - t0
+        self.rebuild_seconds += dt
+        logger.warning(f"batch coordinator: detector rebuilt after {self.REBUILD_AFTER} engine failures in a row "
+                       f"({'ok' if ok else 'FAILED'}, {dt:.2f} s, rebuild {self.rebuilds} of at most {self.MAX_REBUILDS})")
 
 
 class BatchCoordinator:
@@ -231,12 +260,17 @@ class BatchCoordinator:
     def _form(self):
         turn = 0
         while self.running:
+            lane = self._lanes[turn]
+            # the lane FIRST, then the frames: while every lane is busy the frames stay in the inbox, where the drop-oldest rule
+            # applies to them - the reference's loop cuts its next batch only after the previous one has been answered
+            # (src/shared_inference_coordinator.py:176-190; traces in tests/golden/host_coordinator.json)
+            if not lane.idle.acquire(timeout=0.1):
+                continue
             asks = self._inbox.take(self.max_batch_size, self.max_batch_wait_ms)
             if not asks:
+                lane.idle.release()
                 continue
-            lane = self._lanes[turn]
             turn = (turn + 1) % len(self._lanes)
-            lane.idle.acquire()                                      # its previous batch has been finished
             t_begin = time.monotonic()
             if self.enable_metrics:
                 self.wait_times_ms.extend((t_begin - a.t_in) * 1000.0 for a in asks)
@@ -244,7 +278,7 @@ class BatchCoordinator:
                 lane.begin([a.frame for a in asks])
             except Exception as e:
                 self._note_failure("begin", e, len(asks))
-                lane.failed()
+                lane.failed(e)
                 lane.idle.release()
                 logger.error(f"batch coordinator: could not start a batch of {len(asks)}: {e}", exc_info=True)
                 for a in asks:
@@ -265,21 +299,24 @@ class BatchCoordinator:
                         continue
                     return
                 lane, asks, t_begin = self._flying.popleft()
+            failed = False
             try:
-                results = lane.finish()
-                if len(results) != len(asks):
-                    raise RuntimeError(f"detector returned {len(results)} results for {len(asks)} frames")
+                results = list(lane.finish())
             except Exception as e:
                 self._note_failure("finish", e, len(asks))
-                lane.failed()
+                lane.failed(e)
                 logger.error(f"batch coordinator: batch of {len(asks)} failed: {e}", exc_info=True)
                 results = [[] for _ in asks]
                 failed = True
             else:
                 lane.succeeded()
-                failed = False
-            finally:
-                lane.idle.release()
+                if len(results) != len(asks):
+                    # the reference pairs requests and results with zip (src/shared_inference_coordinator.py:253): the leading
+                    # requests get their lists; here the ones left over are answered too (with []), and the miscount is on record
+                    self._note_failure("finish", RuntimeError(f"detector returned {len(results)} results for {len(asks)} frames"), 0)
+                    logger.error(f"batch coordinator: detector returned {len(results)} results for {len(asks)} frames")
+                    results = results[:len(asks)] + [[] for _ in range(len(asks) - len(results))]
+            # every callback of the batch has fired before the lane is handed back: the next batch reaches the detector afterwards
             for a, dets in zip(asks, results):
                 a.reply(dets)
             if self.enable_metrics and not failed:
@@ -287,6 +324,7 @@ class BatchCoordinator:
                 self.total_frames += len(asks)
                 self.total_batch_time_ms += (time.monotonic() - t_begin) * 1000.0
                 self.batch_sizes.append(len(asks))
+            lane.idle.release()
 
     def _note_failure(self, where: str, e: BaseException, n_frames: int) -> None:
         self.failed_batches += 1
@@ -297,7 +335,8 @@ class BatchCoordinator:
     def failure_stats(self) -> Dict[str, Any]:
         """Build-specific (the reference's coordinator only logs): how many batches were answered with [] and why the first one was."""
         return {"failed_batches": self.failed_batches, "failed_frames": self.failed_frames, "first_error": self.first_error,
-                "detector_rebuilds": sum(l.rebuilds for l in self._lanes)}
+                "detector_rebuilds": sum(l.rebuilds for l in self._lanes),
+                "detector_rebuild_seconds": round(sum(l.rebuild_seconds for l in self._lanes), 3)}
 
     def get_stats(self) -> Dict[str, Any]:
         if not self.enable_metrics or self.total_batches == 0:

@@ -49,7 +49,7 @@ def test_requests_are_batched_and_routed_to_their_callbacks():
     # the reference's keys (src/shared_inference_coordinator.py:318-338) plus this build's failure account
     assert set(stats) == {"enabled", "total_batches", "total_frames", "avg_batch_size", "avg_batch_time_ms",
                           "avg_wait_time_ms", "throughput_fps", "queue_depth",
-                          "failed_batches", "failed_frames", "first_error", "detector_rebuilds"}
+                          "failed_batches", "failed_frames", "first_error", "detector_rebuilds", "detector_rebuild_seconds"}
     assert stats["failed_batches"] == 0 and stats["first_error"] is None
 
 
@@ -184,33 +184,100 @@ def test_make_coordinator_follows_reference_config_keys():
     assert System(cfg)._initialize_shared_coordinator() == "reference-path"     # yolox: reference behaviour untouched
 
 
-def test_a_lane_rebuilds_its_detector_after_three_failed_batches_in_a_row():
-    class Wedged(FakeDetector):
-        def __init__(self):
-            super().__init__()
-            self.loads = 0
-            self.broken = True
+class Wedged(FakeDetector):
+    """fails with `error()` until load_model has run `heal_after` times"""
 
-        def load_model(self, max_retries=3):
-            self.loads += 1
-            self.broken = False
-            return True
+    def __init__(self, error, heal_after=1):
+        super().__init__()
+        self.loads = 0
+        self.error = error
+        self.heal_after = heal_after
+        self.model = None
 
-        def detect_batch(self, frames):
-            if self.broken:
-                raise RuntimeError("stream stuck")
-            return super().detect_batch(frames)
+    def load_model(self, max_retries=3):
+        self.loads += 1
+        return True
 
-    det = Wedged()
+    def detect_batch(self, frames):
+        if self.loads < self.heal_after:
+            raise self.error()
+        return super().detect_batch(frames)
+
+
+def _one_by_one(c, n, res):
+    for i in range(n):
+        ev = threading.Event()
+        c.infer_async(frame(i), lambda d, i=i, ev=ev: (res.__setitem__(i, d), ev.set()))
+        assert ev.wait(2.0)
+
+
+def test_a_lane_rebuilds_its_detector_after_three_engine_failures_in_a_row():
+    from telescope_cam_detection_amd._capi import RTD_E_HIP, RtdError
+    det = Wedged(lambda: RtdError(RTD_E_HIP, "stream stuck"))
     res = {}
     with BatchCoordinator(det, max_batch_size=1, max_batch_wait_ms=1.0) as c:
-        for i in range(5):
-            ev = threading.Event()
-            c.infer_async(frame(i), lambda d, i=i, ev=ev: (res.__setitem__(i, d), ev.set()))
-            assert ev.wait(2.0)
+        _one_by_one(c, 5, res)
         st = c.get_stats()
     assert [res[i] for i in range(3)] == [[], [], []] and res[3][0]["class_id"] == 3 and res[4][0]["class_id"] == 4
     assert det.loads == 1 and st["detector_rebuilds"] == 1 and st["failed_batches"] == 3 and "stream stuck" in st["first_error"]
+    assert st["detector_rebuild_seconds"] >= 0.0
+
+
+def test_malformed_frames_and_allocation_failures_never_cost_a_rebuild():
+    """a camera that keeps delivering bad frames (TypeError / ValueError from the detector's frame checks,
+    RTD_E_INVALID from the library), an out-of-memory batch and plain RuntimeErrors of a foreign detector are answered with [] and
+    counted - the engine, its arenas and graphs stay as they are."""
+    import torch
+    from telescope_cam_detection_amd._capi import RTD_E_INVALID, RTD_E_OOM, RtdError
+    errors = [lambda: TypeError("unsupported frame type <class 'str'>"), lambda: ValueError("frame is not HWC uint8"),
+              lambda: RtdError(RTD_E_INVALID, "frame 0: 0 x 0"), lambda: torch.cuda.OutOfMemoryError("HIP out of memory"),
+              lambda: RtdError(RTD_E_OOM, "arena"), lambda: RuntimeError("boom")]
+    for make in errors:
+        det = Wedged(make, heal_after=1)
+        res = {}
+        with BatchCoordinator(det, max_batch_size=1, max_batch_wait_ms=1.0) as c:
+            _one_by_one(c, 7, res)
+            st = c.get_stats()
+        assert all(res[i] == [] for i in range(7)), make()
+        assert det.loads == 0 and st["detector_rebuilds"] == 0 and st["failed_batches"] == 7, (make(), st)
+
+
+def test_rebuilds_are_capped():
+    from telescope_cam_detection_amd._capi import RTD_E_STATE, RtdError
+    from telescope_cam_detection_amd.batching import _Lane
+    det = Wedged(lambda: RtdError(RTD_E_STATE, "no weights"), heal_after=10 ** 6)
+    res = {}
+    n = _Lane.REBUILD_AFTER * (_Lane.MAX_REBUILDS + 3)
+    with BatchCoordinator(det, max_batch_size=1, max_batch_wait_ms=1.0) as c:
+        _one_by_one(c, n, res)
+        st = c.get_stats()
+    assert all(res[i] == [] for i in range(n))
+    assert det.loads == _Lane.MAX_REBUILDS == st["detector_rebuilds"] and st["failed_batches"] == n
+
+
+def test_the_failed_engine_is_closed_before_the_new_one_is_built():
+    from telescope_cam_detection_amd._capi import RTD_E_HIP, RtdError
+    order = []
+
+    class Eng:
+        def close(self):
+            order.append("close")
+
+    class Model:
+        engine = Eng()
+
+    class Det(Wedged):
+        def load_model(self, max_retries=3):
+            order.append(("load", self.model))
+            self.model = Model()
+            return super().load_model(max_retries)
+
+    det = Det(lambda: RtdError(RTD_E_HIP, "fault"))
+    det.model = Model()
+    res = {}
+    with BatchCoordinator(det, max_batch_size=1, max_batch_wait_ms=1.0) as c:
+        _one_by_one(c, 4, res)
+    assert order == ["close", ("load", None)] and res[3][0]["class_id"] == 3
 
 
 class FakeAsyncDetector(FakeDetector):
