@@ -120,10 +120,13 @@ int rtd_infer_raw(rtd_handle h, int32_t n, const uint8_t* const* frames_bgr_hwc,
 
 /* Pipelined form of detect_batch (src/rtdetr_detector.py:307-403 called by the batcher, src/shared_inference_coordinator.py:250),
  * also used by the multi-camera shard and the benchmark: rtd_infer_async enqueues upload + preprocess + network + post-process on the
- * handle's stream and returns; rtd_collect blocks for THAT batch and returns rtd_infer's rows.  A handle holds ONE batch in flight
- * (a second rtd_infer_async first waits for the previous batch).  Host frames (frames_on_device = 0) are copied into a pinned staging
- * buffer of the handle before the call returns (the caller's buffers are free again) and reach HBM by one asynchronous DMA; device
- * frames must stay alive until rtd_collect / rtd_sync.  Everything is plain HIP inside the library: no torch stream, event or
+ * handle's stream and returns; rtd_collect blocks for the LAST submitted batch and returns rtd_infer's rows for it.  A handle has ONE
+ * result block: submit, then collect.  A second rtd_infer_async before rtd_collect is legal - batches run in submission order on the
+ * handle's stream (the benchmark's back-to-back loop) - but it overwrites the block, so the earlier batch's rows can no longer be
+ * collected; with host frames (frames_on_device = 0) it first waits for the previous batch, because the handle's pinned staging
+ * buffer holds one batch.  Host frames are copied into that buffer before the call returns (the caller's buffers are free again)
+ * and reach HBM by one asynchronous DMA; device frames must stay alive until rtd_collect / rtd_sync.  A failed rtd_infer_async
+ * drains the handle's stream before it returns: nothing of the failed batch is still reading the staging buffers.  Everything is plain HIP inside the library: no torch stream, event or
  * allocator takes part.  The result block also stays on the device: [n][Q][6] fp32 rows (label, score, x1, y1, x2, y2) - the
  * fixed-size block each rank contributes to the all-gather - see rtd_result_block. */
 int rtd_infer_async(rtd_handle h, int32_t n, const uint8_t* const* frames_bgr_hwc, const int32_t* hw, int32_t frames_on_device);

@@ -6,12 +6,16 @@ Three reference modules import nothing but the standard library and therefore lo
   /root/reference/src/bbox_utils.py:12-120                  ensure_valid_bbox, validate_bbox_coords, is_valid_bbox
   /root/reference/src/coco_constants.py:7-40                COCO_CLASSES, WILDLIFE_CLASSES, CLASS_ID_TO_CATEGORY, MAMMAL_CLASS_IDS
   /root/reference/src/shared_inference_coordinator.py:27-338  SharedInferenceCoordinator
+  /root/reference/src/memory_manager.py:158-248             MemoryManager.reduce_memory_usage / handle_oom_error (imports torch, which
+                                                            is present; without a GPU it runs in its "CPU mode" and the recommendations
+                                                            do not depend on the device)
 
 They are loaded from where they lie (never copied), driven with seeded inputs / the scripted scenarios of
-`tests/host_scenarios.py`, and only DATA is written: `tests/golden/host_bbox.json`, `host_coco.json`, `host_coordinator.json`.
+`tests/host_scenarios.py`, and only DATA is written: `tests/golden/host_bbox.json`, `host_coco.json`, `host_coordinator.json`,
+`host_engine_sequence.json`.
 `/root/reference` does not exist on the GPU box; the tests read the JSON files only.
 
-    python oracle/make_host_golden.py            # rewrite the three files
+    python oracle/make_host_golden.py            # rewrite the four files
     python oracle/make_host_golden.py --check    # regenerate in memory and compare with the committed files
 """
 import importlib.util
@@ -108,11 +112,27 @@ def make_coordinator(sic):
     return out
 
 
+def make_engine_sequence(mm):
+    """What the unchanged caller's memory manager tells `InferenceEngine._apply_degradation` (src/inference_engine_yolox.py:706-748) to do:
+    the recommendations of four OOM events in a row (:609-611 -> src/memory_manager.py:207-248) and of the three pressure levels
+    (:600-604 -> src/memory_manager.py:158-205).  tests/test_engine_sequence.py replays them on the real detector."""
+    m = mm.MemoryManager(device="cuda:0")
+    ooms = []
+    for _ in range(4):
+        rec = m.handle_oom_error()
+        ooms.append({"recommendations": rec, "oom_events": m.oom_events, "degradation_level": m.degradation_level})
+    m.record_recovery()
+    m2 = mm.MemoryManager(device="cuda:0")
+    levels = {lvl.name: m2.reduce_memory_usage(lvl) for lvl in (mm.MemoryPressure.HIGH, mm.MemoryPressure.CRITICAL, mm.MemoryPressure.EXTREME)}
+    return {"source": "src/memory_manager.py", "handle_oom_error": ooms, "recoveries_after_one_record": m.recoveries, "reduce_memory_usage": levels}
+
+
 def generate():
     return {
         "host_bbox.json": make_bbox(ref_module("bbox_utils")),
         "host_coco.json": make_coco(ref_module("coco_constants")),
         "host_coordinator.json": make_coordinator(ref_module("shared_inference_coordinator")),
+        "host_engine_sequence.json": make_engine_sequence(ref_module("memory_manager")),
     }
 
 

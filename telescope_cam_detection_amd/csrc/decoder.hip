@@ -973,7 +973,7 @@ void launch_gather_ln(const float* x, int64_t ldx, int rows_per_image, const int
 
 void launch_dec_layer(const DecArgs& a, hipStream_t s) {
   RTD_CHECK(a.D == 256 && a.D / a.heads == 32 && a.ffn <= 1024 && a.C <= 512, 1, "fused decoder: d_model 256, head dim 32, ffn <= 1024");
-  RTD_CHECK(a.n_levels == 3 && a.n_points == 4 && a.heads % NW == 0, 1, "fused decoder: 3 levels x 4 points, heads a multiple of the wave count");
+  RTD_CHECK(a.n_levels == 3 && a.n_points == 4 && a.heads == NW, 1, "fused decoder: 3 levels x 4 points, one head per wave");
   const int tiles = (a.Q + DR - 1) / DR;
   if (a.split == 2) rtd_launch(dec_layer_kernel<2>, dim3(a.B * tiles), dim3(NT), 0, s, a);
   else if (a.split) rtd_launch(dec_layer_kernel<1>, dim3(a.B * tiles), dim3(NT), 0, s, a);

@@ -1630,7 +1630,14 @@ int rtd_infer_raw(rtd_handle h, int32_t n, const uint8_t* const* frames, const i
 int rtd_infer_async(rtd_handle h, int32_t n, const uint8_t* const* frames, const int32_t* hw, int32_t frames_on_device) {
   return guarded(h, [&] {
     RTD_CHECK(frames && hw, RTD_E_INVALID, "null argument");
-    forward(h, n, frames, hw, frames_on_device != 0, /*via_pinned=*/frames_on_device == 0);
+    try {
+      forward(h, n, frames, hw, frames_on_device != 0, /*via_pinned=*/frames_on_device == 0);
+    } catch (...) {
+      // whatever was enqueued before the failure (the pinned -> HBM DMA) must not outlive the call: the next submit writes the staging buffer
+      if (h->stream) (void)hipStreamSynchronize(h->stream);
+      h->in_flight = false;
+      throw;
+    }
     h->in_flight = true;
     h->st_submits++;
   });

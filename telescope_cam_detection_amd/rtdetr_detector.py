@@ -132,7 +132,11 @@ class RTDETRDetector:
                 engine = _capi.Engine(arch, blob, device=dev, precision=_capi.precision_code(self.precision), max_batch=self.max_batch,
                                       input_size=tuple(self.input_size), use_graph=self.use_graph,
                                       profile=_capi.PROFILE_THROUGHPUT if str(self.profile).lower() == "throughput" else _capi.PROFILE_LATENCY)
-                self._prepare(engine)
+                try:
+                    self._prepare(engine)
+                except BaseException:
+                    engine.close()                            # a retry must not find this attempt's weights, arenas and graphs still resident
+                    raise
             except (RuntimeError, OSError) as e:              # the reference retries this set (:190-198); IOError is OSError
                 if k + 1 == tries:
                     logger.error("RT-DETR (MI355X): giving up on %s after %d attempt(s): %s", self.model_path, tries, e, exc_info=True)

@@ -276,5 +276,11 @@ def test_the_library_never_captures_a_stream_and_the_package_never_wraps_its_str
         assert "hipStreamBeginCapture" not in code and "hipStreamEndCapture" not in code, f
         if f.endswith(".hip"):
             assert "hipLaunchKernelGGL" not in code and "<<<" not in code, f
+        if os.path.basename(f) in ("ops.hip", "conv_igemm.hip", "decoder.hip"):
+            # the files that hold the plan ops' launchers contain no other stream call - a hipMem*Async / hipEventRecord inside a
+            # launcher would run once on the live stream while the graph is BUILT and be missing from every replay (build_exec only counts
+            # rtd_launch calls).  Memsets / copies live in engine.hip, outside the plan ops.
+            for call in ("hipMemsetAsync", "hipMemcpyAsync", "hipMemcpy2DAsync", "hipEventRecord", "hipStreamWaitEvent", "hipLaunchHostFunc"):
+                assert call not in code, (f, call)
     common = open(os.path.join(root, "telescope_cam_detection_amd", "csrc", "common.h")).read()
     assert common.count("hipLaunchKernelGGL(") == 1 and "hipGraphAddKernelNode" in common

@@ -7,22 +7,31 @@ from oracle import rtdetr_oracle as orc
 from tests.util import load_case, match_detections, sample, weights_for
 
 FAST = ["t_tiny_160", "t_tiny_160x224", "t_tinyb_192x128", "t_tinyc_160x224", "c1_r18_640_bs1", "c1_r18_640_scene", "c1_r18_640_resize"]
-SLOW = ["c2_r50_640_scene_bs2", "c4_r18_1920_bs1"]
+SLOW = ["c2_r50_640_scene_bs2", "c4_r18_1920_bs1", "c3_r101_1280_bs1"]
+# the first frames of a larger fixture (frames are independent; the sampled trunk tensors span the whole batch and are skipped)
+PARTIAL = [("c2_r50_640_bs8", 2)]
 
 
-@pytest.mark.parametrize("name", FAST + SLOW)
-def test_oracle_matches_golden(name):
+@pytest.mark.parametrize("name,first", [(n, None) for n in FAST + SLOW] + PARTIAL)
+def test_oracle_matches_golden(name, first):
     torch.set_num_threads(8)
     arch, wseed, input_size, frames, g = load_case(name)
+    if first is not None:
+        frames = frames[:first]
+        g = {k: (g[k][:first] if k in ("enc_cls_max", "topk", "logits", "pred_boxes", "labels", "boxes", "scores") else g[k]) for k in g.files}
     w = weights_for(arch, wseed)
     xs, sizes = zip(*[orc.preprocess(f, input_size) for f in frames])
     x = torch.cat(xs, 0)
-    np.testing.assert_allclose(sample(x), g["input_sample"], atol=0, rtol=0)   # PIL preprocess is exact
     col = {}
     labels, boxes, scores = orc.model_forward(arch, w, x, list(sizes), collect=col)
-    for i in range(3):
-        np.testing.assert_allclose(sample(col[f"backbone{i}"]), g[f"s_backbone{i}"], atol=2e-4, rtol=1e-4)
-        np.testing.assert_allclose(sample(col[f"enc{i}"]), g[f"s_enc{i}"], atol=2e-4, rtol=1e-4)
+    if first is None:
+        np.testing.assert_allclose(sample(x), g["input_sample"], atol=0, rtol=0)   # PIL preprocess is exact
+        for i in range(3):
+            # absolute bound scaled to the tensor (R101 at 1280 px carries activations of several hundred after 100 fp32 layers:
+            # 5e-6 of the largest value = 40 ulp there); the small nets keep the 2e-4 floor
+            for key in (f"backbone{i}", f"enc{i}"):
+                want = g["s_" + key]
+                np.testing.assert_allclose(sample(col[key]), want, atol=max(2e-4, 5e-6 * float(np.abs(want).max())), rtol=1e-4)
     np.testing.assert_allclose(col["enc_cls_max"].numpy(), g["enc_cls_max"], atol=1e-4)
     # same set of selected memory tokens; per-token heads equal
     mine, gold = np.sort(col["topk"].numpy(), 1), np.sort(g["topk"], 1)
