@@ -5,6 +5,11 @@ accumulation stays fp32 - the arithmetic of the GPU's pair engines without their
 error of the final rows against the un-rounded fp32 oracle, to choose the storage format for large inputs:
 
     python tools/pair_sim.py c3_r101_1280_bs1 bf16 f16
+
+Formats: bf16 / f16 (hi + lo of that type), f16ftz, and `f16q3[:region]` = fp16 pairs everywhere EXCEPT the stored activations
+of the HBM-bound head of the backbone, which are kept as hi fp16 + an 8-bit lo (3 bytes per channel: lo quantised to 1/256 of
+hi's ulp, i.e. 19 significant bits).  region = "s0" (stem.1 ... stage-0 output), "s1" (... stage-1 output, the default),
+"s2", "all" (every backbone activation).  VERDICT r4 item 3: priced here before any kernel is touched.
 """
 import os
 import sys
@@ -34,8 +39,55 @@ def pair(x, dt):
     return hi + lo
 
 
-def run(arch, w, xs, sizes, dt):
+def q3(x):
+    """hi fp16 + 8-bit lo: lo = x - hi lies within half an ulp of hi; it is stored as round(lo / ulp * 256) in [-128, 127]."""
+    hi = x.to(torch.float16).float()
+    lo = x - hi
+    e = torch.floor(torch.log2(hi.abs().clamp_min(2.0 ** -14)))           # exponent of hi (subnormal hi: the fixed 2^-24 grid)
+    ulp = torch.exp2(e - 10)
+    q = torch.clamp(torch.round(lo / ulp * 256.0), -128, 127)
+    lo_q = (q * ulp / 256.0).to(torch.float16).float()                     # what the kernel hands the matrix core: an fp16 value
+    return hi + lo_q
+
+
+def backbone_q3(region):
+    """orc.backbone with every tensor the engine STORES inside `region` rounded to the 3-byte form (block outputs feed the next
+    conv AND the residual add, so they are rounded where they are produced)."""
+    from telescope_cam_detection_amd.weights import backbone_blocks, block_has_shortcut
+    last_stage = {"s0": 0, "s1": 1, "s2": 2, "all": 3}[region]
+
+    def backbone(arch, w, x):
+        x = orc.conv_bn(w, "backbone.stem.0", x, stride=2, act="relu")     # stem.0's output stays a pair (the uint8 stem writes it once)
+        x = q3(orc.conv_bn(w, "backbone.stem.1", x, act="relu"))
+        x = orc.conv_bn(w, "backbone.stem.2", x, act="relu")
+        x = q3(F.max_pool2d(x, 3, 2, 1))
+        feats = {}
+        for pfx, cin, cout, stride, first in backbone_blocks(arch):
+            st = int(pfx.split(".")[1][1:])
+            r = q3 if st <= last_stage else (lambda t: t)
+            res = x
+            if arch.layer_type == "bottleneck":
+                y = r(orc.conv_bn(w, pfx + ".c1", x, act="relu"))
+                y = r(orc.conv_bn(w, pfx + ".c2", y, stride=stride, act="relu"))
+                y = orc.conv_bn(w, pfx + ".c3", y)
+            else:
+                y = r(orc.conv_bn(w, pfx + ".c1", x, stride=stride, act="relu"))
+                y = orc.conv_bn(w, pfx + ".c2", y)
+            if block_has_shortcut(arch, cin, cout, stride, first):
+                if stride == 2:
+                    res = F.avg_pool2d(res, 2, 2, 0, ceil_mode=True)
+                res = orc.conv_bn(w, pfx + ".sc", res)
+            x = r(F.relu(y + res))
+            feats[pfx] = x
+        return [feats[f"backbone.s{si}.b{arch.depths[si] - 1}"] for si in (1, 2, 3)]
+    return backbone
+
+
+def run(arch, w, xs, sizes, dt, region=None):
     c2, li = F.conv2d, F.linear
+    bb = orc.backbone
+    if region:
+        orc.backbone = backbone_q3(region)
     if dt is not None:
         F.conv2d = lambda x, w_, b=None, **kw: c2(pair(x, dt), pair(w_, dt), b, **kw)
         F.linear = lambda x, w_, b=None: li(pair(x, dt), pair(w_, dt), b)
@@ -44,6 +96,7 @@ def run(arch, w, xs, sizes, dt):
             return orc.model_forward(arch, w, xs, sizes)
     finally:
         F.conv2d, F.linear = c2, li
+        orc.backbone = bb
 
 
 def main():
@@ -60,8 +113,11 @@ def main():
     for f in fmts:
         global FTZ
         FTZ = f == "f16ftz"
-        dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f16ftz": torch.float16}[f]
-        l, b, s = run(arch, w, xs, list(sizes), dt)
+        region = None
+        if f.startswith("f16q3"):
+            region = f.split(":")[1] if ":" in f else "s1"
+        dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f16ftz": torch.float16}["f16" if region else f]
+        l, b, s = run(arch, w, xs, list(sizes), dt, region)
         for i in range(len(frames)):
             m, n, ws, wb, un = match_detections(rl[i], rb[i], rs[i], l[i], b[i], s[i], 1e-3, 1e9, return_unmatched=True)
             # box error of every matched row (label + score matched), sorted
