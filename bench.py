@@ -126,6 +126,35 @@ def launch_selftest(args, rank, world) -> int:
     return 0
 
 
+
+def bench_crop_step(batch: int, size: int, seed: int = 5000, n_crops: int = 16):
+    """bench.py --workload two_stage (BASELINE config 5): after each detect step, the Stage-2 crop batch of `n_crops` mixed-size boxes
+    (sides drawn from rng.integers(64, 512)) spread over the step's frames -> [16,3,336,336] classifier input, enqueued
+    (asynchronously, rtd_crop_resize_batch) on a torch-owned stream that the engine's own event orders BEHIND this step's forward
+    (rtd_signal_stream) - in the real pipeline the crops come from Stage-1 boxes; the next forward does not wait for
+    the crops (it overwrites nothing they read), so Stage 2 of step k overlaps Stage 1 of step k + 1 as it would in a pipeline.  The classifier forward is excluded (its network is out of scope) and the boxes are synthetic: Stage 1 on noise
+    frames with random weights finds nothing above threshold.  Returns (callable, description)."""
+    import numpy as np
+    import torch
+
+    rng = np.random.default_rng(seed)
+    from telescope_cam_detection_amd.stage2 import CropBatcher
+    batcher = CropBatcher()
+    rects = [[] for _ in range(batch)]
+    for i in range(n_crops):
+        cw, ch = int(rng.integers(64, min(512, size))), int(rng.integers(64, min(512, size)))
+        x, y = int(rng.integers(0, size - cw + 1)), int(rng.integers(0, size - ch + 1))
+        rects[i % batch].append((x, y, x + cw, y + ch))
+
+    def run(engine, frames, stream):
+        engine.signal_stream(stream.cuda_stream)          # Stage 2 after Stage 1 (ADVICE r4)
+        with torch.cuda.stream(stream):
+            batcher.preprocess_batch(frames, rects)
+
+    info = {"crops_per_step": n_crops, "crop_sides": "rng.integers(64, 512)", "classifier_input": [n_crops, 3, batcher.input_size, batcher.input_size],
+            "timed": "detect + crop/resize/normalise batch (one asynchronous launch on a torch-owned stream ordered after the forward); classifier forward EXCLUDED (EVA02 out of scope)"}
+    return run, info
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -217,7 +246,6 @@ def main():
 
     crops_fn, crop_info = None, None
     if args.workload == "two_stage":
-        from telescope_cam_detection_amd.stage2 import bench_crop_step
         crops_fn, crop_info = bench_crop_step(B, H, seed=5000 + rank)
 
     S = max(1, args.streams)

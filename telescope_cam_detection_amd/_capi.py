@@ -93,12 +93,17 @@ DET_DTYPE = np.dtype([("class_id", "<i4"), ("score", "<f4"), ("x1", "<f4"), ("y1
 
 _lib: Optional[C.CDLL] = None
 
-# every symbol include/rtdetr_mi355.h declares
+# every symbol include/rtdetr_mi355.h declares: the product C ABI (what a reference-side binding uses)
 EXPORTS = [
     "rtd_version", "rtd_create", "rtd_load_weights", "rtd_infer", "rtd_infer_raw", "rtd_infer_async", "rtd_collect", "rtd_prepare",
-    "rtd_result_block", "rtd_sync", "rtd_stream", "rtd_wait_stream", "rtd_signal_stream", "rtd_get_stats", "rtd_destroy", "rtd_last_error", "rtd_debug_tensor",
-    "rtd_debug_force_topk", "rtd_profile", "rtd_arena_bytes", "rtd_debug_option", "rtd_op_conv", "rtd_op_conv_dual", "rtd_op_conv_next", "rtd_op_layernorm",
-    "rtd_op_attention", "rtd_op_msdeform", "rtd_op_topk", "rtd_op_resize", "rtd_crop_resize_batch", "rtd_bench_conv", "rtd_bench_conv_pair", "rtd_bench_mfma_rate",
+    "rtd_result_block", "rtd_sync", "rtd_stream", "rtd_wait_stream", "rtd_signal_stream", "rtd_get_stats", "rtd_arena_bytes", "rtd_destroy",
+    "rtd_last_error", "rtd_crop_resize_batch",
+]
+# every symbol include/rtdetr_mi355_test.h declares: kernel-level test / bench / debug entry points (csrc/testapi.hip)
+TEST_EXPORTS = [
+    "rtd_debug_tensor", "rtd_debug_force_topk", "rtd_profile", "rtd_debug_option", "rtd_op_conv", "rtd_op_conv_dual", "rtd_op_conv_next",
+    "rtd_op_layernorm", "rtd_op_attention", "rtd_op_msdeform", "rtd_op_topk", "rtd_op_resize", "rtd_bench_conv", "rtd_bench_conv_pair",
+    "rtd_bench_mfma_rate",
 ]
 
 

@@ -15,8 +15,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmi355rtdetr.so")
-SOURCES = ["conv_igemm.hip", "ops.hip", "decoder.hip", "engine.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(PKG), "include", "rtdetr_mi355.h")]
+SOURCES = ["conv_igemm.hip", "ops.hip", "decoder.hip", "engine.hip", "testapi.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "engine_internal.h"), os.path.join(os.path.dirname(PKG), "include", "rtdetr_mi355.h"),
+           os.path.join(os.path.dirname(PKG), "include", "rtdetr_mi355_test.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
@@ -43,9 +44,17 @@ def build(force: bool = False, verbose: bool = True) -> str:
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
 
+    # which headers a source includes: an object is rebuilt only when its source or one of THOSE headers is newer (conv_igemm.hip alone
+    # takes minutes; engine / testapi / decoder / ops seconds)
+    common = os.path.join(CSRC, "common.h")
+    deps_of = {src: (HEADERS if src in ("engine.hip", "testapi.hip") else [common]) for src in SOURCES}   # only the host side sees the ABI headers
+
     def compile_one(src):
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in [path] + deps_of[src]):
+            return obj
+        cmd = [hipcc, *FLAGS, "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
@@ -53,7 +62,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(r.stderr[-2000:], file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=5) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     tmp = LIB_PATH + ".tmp"
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs], capture_output=True, text=True)
@@ -64,7 +73,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     nm = shutil.which("nm")
     if nm:
         u = subprocess.run([nm, "-C", "--undefined-only", tmp], capture_output=True, text=True).stdout
-        bad = [l.strip() for l in u.splitlines() if "rtd::" in l or "__device_stub__" in l]
+        bad = [l.strip() for l in u.splitlines() if "rtd::" in l or "rtd_eng::" in l or "__device_stub__" in l]
         if bad:
             os.remove(tmp)
             raise RuntimeError("libmi355rtdetr.so would have unresolved kernel symbols:\n" + "\n".join(bad[:10]))

@@ -132,17 +132,10 @@ struct ConvOpts {
                               // everywhere, 7 = 256-pixel tile, 8 = A-stationary kernel, 9 = streaming kernels on any grid, 10 = 128 x 64 tile
   int glds_min_blocks = 4;    // bf16: smallest grid of 128 x 128 tiles the LDS-DMA kernels take (fp32: 512, fixed)
   int glds_min_n = 128;       // bf16: smallest Cout the LDS-DMA kernels take (64 measured slower on the stage-0 reduce convs: 45 vs 42 us)
-  int wsa_min_ntn = 8;        // A-stationary kernel from this many channel tiles on (0 = never)
   int ws2_min_blocks = 257;   // grids that do not fit one block per CU run the 2-stage kernel at 2 blocks per CU
   int ws64_max_blocks = 160;  // 128 x 128-tile grids below this take the 128 x 64 tile (0 = never)
-  int ws256_min_blocks = 0;   // 256-pixel tiles from this many blocks on (0 = only under ConvArgs::prefer256)
   int reg_epilogue = 1;       // residual-free bf16 tiles finish in registers
   int conv_reg = 3;           // direct 3x3 kernels for the narrow layers (bit 1: the 64-channel pair kernel)
-  int conv_stream = 1;        // streaming 1x1 kernels for the thin wide-grid layers (bf16)
-  int stream_min_tiles = 2048;
-  int stream2 = 1;            // ... for the reducing K = 256 layers
-  int stream2_max_n = 2048;
-  int stream_slab = 1;        // 0 = accumulator-shaped global accesses
   int prefetch = 1;           // 0 = launches ignore ConvArgs::pf
   int glds_drop = 0;          // timing-only probes (results wrong): 1 = x descriptor has 0 records, 2 = w, 4 = no DMA at all, 32 = block stamps
   // ---- pair (F16X2) operands

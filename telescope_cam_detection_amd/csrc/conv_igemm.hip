@@ -1486,382 +1486,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_wsq_kernel(const ConvG g) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// v4b: the wave-specialised kernel on a 256 pixel x 128 channel tile, 3 stages.  Each MFMA wave owns 128 x 64 outputs
-// (4 x 2 MFMA tiles): per 16-deep k slice it reads 4 + 2 fragments for 8 MFMAs (0.75 KiB of LDS per MFMA instead of 1 KiB),
-// and a K-step stages 48 KiB for twice the MACs (24 KiB per 128 x 128 x 64 unit instead of 32).  The 128 x 128 kernel's K-step
-// time tracks its LDS traffic (64 KiB of fragment reads + 32 KiB of DMA writes per unit, ~1000 cycles against 512 of MFMA;
-// whole-K-step fragment prefetch (DEEP) changed nothing, tools/ingest_probe.hip shows the L2 path has 2x headroom) - this tile
-// moves 72 KiB per unit.  Used where the grid still fills the chip with 256-pixel tiles.
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(512, 2) void conv_igemm_ws256_kernel(const ConvG g) {
-  const ConvK& a = g.k;
-  constexpr int BM = 256, BN = 128;
-  constexpr int ES = (int)sizeof(T);
-  constexpr int BK = 128 / ES;
-  constexpr int STAGES = 3;
-  constexpr int STAGE = (BM + BN) * 128;
-  constexpr int SLD = BN + 4;
-  constexpr int SMEM = (STAGES * STAGE > BM * SLD * 4) ? STAGES * STAGE : BM * SLD * 4;
-  typedef typename Mma<T>::Frag Frag;
-  __shared__ __attribute__((aligned(16))) char smem[SMEM + 256];   // + the prefetch dummy
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = wv >= 4;
-  const int w4 = wv & 3;
-  const int wm = w4 & 1, wn = w4 >> 1;
-  int wg;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int nt = wg % a.ntn, mt = wg / a.ntn;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int nk = a.Kpad / BK;
-  // diagnostic (glds_drop bit 5): shader-clock stamps of the first 48 K-steps of blocks 0..63 into the split-K slab:
-  // [block][ks][0..2] loader wave 4: tile landed, barrier passed, next tile issued; [3..4] MFMA wave 0: barrier passed, MFMAs issued
-  long long* stamps = ((g.probe & 32) && g.slab && blockIdx.x < 64 && lane == 0) ? (long long*)g.slab + (size_t)blockIdx.x * 48 * 8 : nullptr;
-  const long long t_base = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
-  // phase stamps in slot ks = 47: [0] K loop done (MFMA wave 0) [1] staging done [2] epilogue stores issued [3] stores complete
-  // [5] 100 MHz wall clock at kernel entry [6] wall clock at the end (x10 ns)
-  if (stamps && wv == 0) stamps[47 * 8 + 5] = (long long)__builtin_amdgcn_s_memrealtime();
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // residual rows of this thread's 8 epilogue iterations, requested beside the first tiles (see conv_igemm_ws_kernel)
-  const int c8 = tid & 15;
-  const int c = n0 + c8 * 8;
-  bf16x8 rpre[8];
-  if (a.res_mode != RES_NONE && !a.res_f32 && c < a.N) {
-    int m = m0 + (tid >> 4);
-    const int b = m / a.OHW;
-    int p = m - b * a.OHW;
-    long long roff = (long long)b * a.r_bstride + (long long)p * a.ldr + c;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {                                // rows 32 apart: carry (image, pixel) instead of dividing again
-      if (m < a.M) rpre[it] = *(const bf16x8*)((const bf16*)a.res + roff);
-      m += 32; p += 32; roff += 32 * a.ldr;
-      while (p >= a.OHW) { p -= a.OHW; roff += a.r_bstride - (long long)a.OHW * a.ldr; }
-    }
-  }
-  if (!loader) prefetch_share(a, blockIdx.x, gridDim.x, tid, 256, smem + SMEM);
-
-  if (loader) {
-    const int lrow = w4 * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((w4 * 4 + (lane >> 4)) & 7);
-    int a_off[8], a_iy0[8], a_ix0[8], b_off[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + i * 32 + lrow;
-      if (m < a.M) {
-        const int b = m / a.OHW;
-        const int r = m - b * a.OHW;
-        const int oy = r / a.OW;
-        const int ox = r - oy * a.OW;
-        a_iy0[i] = oy * a.stride - a.pad;
-        a_ix0[i] = ox * a.stride - a.pad;
-        a_off[i] = (int)(((long long)b * a.x_bstride + ((long long)a_iy0[i] * a.W + a_ix0[i]) * a.ldx) * ES) + chunk * 16;
-      } else {
-        a_iy0[i] = -(1 << 28);
-        a_ix0[i] = -(1 << 28);
-        a_off[i] = 0;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b_off[i] = (n0 + i * 32 + lrow) * a.Kpad * ES + chunk * 16;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
-    int k0 = 0, kh = 0, kw = 0, c0 = 0;
-    auto issue = [&](int buf) {
-      char* sa = smem + buf * STAGE + w4 * 1024;
-      const int delta = ((kh * a.W + kw) * (int)a.ldx + c0) * ES;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-        const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        const unsigned vo = ok ? (unsigned)(a_off[i] + delta) : 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sa + i * 4096), 16, vo, 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(sa + BM * 128 + i * 4096), 16, (unsigned)(b_off[i] + k0 * ES), 0, 0, 0);
-      k0 += BK;
-      c0 += BK;
-      if (c0 >= a.Cin) {
-        c0 = 0;
-        if (++kw == a.KW) { kw = 0; ++kh; }
-      }
-    };
-    for (int t = 0; t < STAGES - 1 && t < nk; ++t) issue(t);
-    for (int ks = 0; ks < nk; ++ks) {
-      if (nk - 1 - ks >= 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // tile ks landed; tile ks+1 (12 DMAs) may stay in flight
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (stamps && wv == 4 && ks < 48) stamps[ks * 8 + 0] = (long long)__builtin_amdgcn_s_memtime() - t_base;
-      __builtin_amdgcn_s_barrier();
-      if (stamps && wv == 4 && ks < 48) stamps[ks * 8 + 1] = (long long)__builtin_amdgcn_s_memtime() - t_base;
-      if (ks + STAGES - 1 < nk) issue((ks + STAGES - 1) % STAGES);
-      if (stamps && wv == 4 && ks < 48) stamps[ks * 8 + 2] = (long long)__builtin_amdgcn_s_memtime() - t_base;
-    }
-  } else {
-    int foff[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 128 + (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
-    for (int ks = 0; ks < nk; ++ks) {
-      if (stamps && wv == 0 && ks > 0 && ks <= 48) stamps[(ks - 1) * 8 + 4] = (long long)__builtin_amdgcn_s_memtime() - t_base;
-      __builtin_amdgcn_s_barrier();
-      if (stamps && wv == 0 && ks < 48) stamps[ks * 8 + 3] = (long long)__builtin_amdgcn_s_memtime() - t_base;
-      const char* sa = smem + (ks % STAGES) * STAGE + wm * 128 * 128;
-      const char* sb = smem + (ks % STAGES) * STAGE + (BM + wn * 64) * 128;
-      Frag xf[2][4], wf[2][2];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xf[0][j] = *(const Frag*)(sa + j * 4096 + foff[0]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) wf[0][i] = *(const Frag*)(sb + i * 4096 + foff[0]);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        if (kk < 3) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) xf[(kk + 1) & 1][j] = *(const Frag*)(sa + j * 4096 + foff[kk + 1]);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) wf[(kk + 1) & 1][i] = *(const Frag*)(sb + i * 4096 + foff[kk + 1]);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) Mma<T>::run(wf[kk & 1][i], xf[kk & 1][j], acc[i][j]);
-      }
-    }
-  }
-  if (stamps && wv == 0) stamps[47 * 8 + 0] = (long long)__builtin_amdgcn_s_memtime() - t_base;
-  __syncthreads();                                 // every MFMA operand read is done: smem becomes the fp32 staging tile
-
-  float* st = (float*)smem;
-  if (!loader) {
-    const int h = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int pl = wm * 128 + j * 32 + (lane & 31);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-          *(f32x4*)(&st[pl * SLD + wn * 64 + i * 32 + 8 * q + 4 * h]) = v;
-        }
-    }
-  }
-  __syncthreads();
-  if (stamps && wv == 0) stamps[47 * 8 + 1] = (long long)__builtin_amdgcn_s_memtime() - t_base;
-  dispatch_act(a.act, [&](auto actc) { ws_copy_out<8, decltype(actc)::value>(a, st, SLD, tid, m0, n0, rpre); });
-  if (stamps && wv == 0) {
-    stamps[47 * 8 + 2] = (long long)__builtin_amdgcn_s_memtime() - t_base;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    stamps[47 * 8 + 3] = (long long)__builtin_amdgcn_s_memtime() - t_base;
-    stamps[47 * 8 + 6] = (long long)__builtin_amdgcn_s_memrealtime();
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// v4c: A-STATIONARY wave-specialised kernel for 1x1 convs / token GEMMs with a short K (<= 256) and many channel tiles
-// (the decoder's value projections: 67200 tokens x 256 -> 1536 = 12 channel tiles, 123 us as 6300 independent 4-step tiles).
-// A block loads its 128-pixel A tile ONCE (K/64 chunks, <= 64 KiB), then walks `npb` consecutive channel tiles: the loader waves
-// stream the filter tiles through a 3-stage ring without stopping at tile boundaries, the MFMA waves finish each channel tile
-// in registers (bias + activation -> bf16 -> a separate LDS slab -> 16-byte stores) while the ring refills behind them.
-// One s_barrier per K-step plus one per channel tile (slab written -> slab copied), executed by both roles.
-// Residual-free bf16 outputs only (the launch falls back to the independent-tile kernels otherwise).
-// ------------------------------------------------------------------------------------------------
-template <typename T, int NK>
-__global__ __launch_bounds__(512, 2) void conv_igemm_wsa_kernel(const ConvG g, int npb) {
-  // NK = K / (128 bytes): the A tile lives in the MFMA waves' REGISTERS (2 x 4 NK fragments = 32 NK VGPRs), which leaves the
-  // LDS to a 6-stage filter ring (5 tiles = 80 KiB in flight: with 2 in flight the K-step was 1060 cycles, DMA-latency bound)
-  const ConvK& a = g.k;
-  constexpr int BM = 128, BN = 128;
-  constexpr int ES = (int)sizeof(T);
-  constexpr int BK = 128 / ES;
-  constexpr int STAGES = 6, AHEAD = 5;
-  constexpr int ACHUNK = BM * 128;                 // one 128-byte-of-K chunk of the A tile (staged through the ring once)
-  constexpr int BSTAGE = BN * 128;
-  constexpr int SLB = BN + 8;                      // bf16 slab row
-  constexpr int SLAB = BM * SLB * 2;
-  static_assert(NK * ACHUNK <= STAGES * BSTAGE, "the A tile is staged through the ring region");
-  typedef typename Mma<T>::Frag Frag;
-  constexpr int MAXNPB = 8;                        // channel tiles per block (launch: npb <= 8)
-  __shared__ __attribute__((aligned(16))) char smem[STAGES * BSTAGE + SLAB + MAXNPB * BN * 4 + 256];
-  char* const sB = smem;
-  bf16* const sb = (bf16*)(smem + STAGES * BSTAGE);
-  float* const sbias = (float*)(smem + STAGES * BSTAGE + SLAB);   // this block's bias slice (registers are full of A fragments)
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = wv >= 4;
-  const int w4 = wv & 3;
-  const int wm = w4 & 1, wn = w4 >> 1;
-  int wg;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int ngroups = (a.ntn + npb - 1) / npb;
-  const int grp = wg % ngroups, mt = wg / ngroups;
-  const int m0 = mt * BM;
-  const int nt0 = grp * npb;
-  const int nts = min(npb, a.ntn - nt0);           // channel tiles of this block
-  const int S = nts * NK;                          // filter tiles to stream
-
-  // diagnostic (glds_drop bit 5): [block][tile][0..3] = shader clocks at: K steps done, slab written (barrier passed), copy-out issued;
-  // [block][15][0] = A tile + first filter tile landed (loader wave 4)
-  long long* stamps = ((g.probe & 32) && g.slab && blockIdx.x < 64 && lane == 0) ? (long long*)g.slab + (size_t)blockIdx.x * 16 * 4 : nullptr;
-  const long long t_base = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
-  if (!loader) prefetch_share(a, blockIdx.x, gridDim.x, tid, 256, smem + STAGES * BSTAGE + SLAB + MAXNPB * BN * 4);
-
-  if (loader) {
-    const int lrow = w4 * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((w4 * 4 + (lane >> 4)) & 7);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, g.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, g.w_bytes, 0x00020000);
-    // A tile (1x1 / stride 1 / pad 0: pixel m reads row m of x) into the ring region, chunk c at c * 16 KiB
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + i * 32 + lrow;
-      unsigned vo = 0x80000000u;
-      if (m < a.M) {
-        const int b = m / a.OHW;
-        const int p = m - b * a.OHW;
-        vo = (unsigned)(((long long)b * a.x_bstride + (long long)p * a.ldx) * ES) + chunk * 16;
-      }
-#pragma unroll
-      for (int c = 0; c < NK; ++c)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(sB + c * ACHUNK + w4 * 1024 + i * 4096), 16, m < a.M ? vo + c * 128 : vo, 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                                // A tile visible
-    __builtin_amdgcn_s_barrier();                                                // ... and in the MFMA waves' registers: the ring is free
-    auto issue_b = [&](int s) {
-      const int nt = nt0 + s / NK, ks = s - (s / NK) * NK;
-      char* dst = sB + (s % STAGES) * BSTAGE + w4 * 1024;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + i * 4096), 16,
-                                                 (unsigned)(((nt * BN + i * 32 + lrow) * a.Kpad + ks * BK) * ES + chunk * 16), 0, 0, 0);
-    };
-    for (int s = 0; s < AHEAD && s < S; ++s) issue_b(s);
-    for (int s = 0; s < S; ++s) {
-      switch (min(AHEAD - 1, S - 1 - s)) {                                       // filter tiles issued after tile s that may stay in flight
-        case 4: wait_vmcnt<16>(); break;
-        case 3: wait_vmcnt<12>(); break;
-        case 2: wait_vmcnt<8>(); break;
-        case 1: wait_vmcnt<4>(); break;
-        default: wait_vmcnt<0>(); break;
-      }
-      if (stamps && wv == 4 && s == 0) stamps[15 * 4] = (long long)__builtin_amdgcn_s_memtime() - t_base;
-      __builtin_amdgcn_s_barrier();
-      if (s + AHEAD < S) issue_b(s + AHEAD);
-      if ((s + 1) % NK == 0) __builtin_amdgcn_s_barrier();                       // channel-tile boundary: the MFMA waves' slab barrier
-    }
-  } else {
-    int foff[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) foff[kk] = (lane & 31) * 128 + (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
-    const int h = lane >> 5;
-    // the block's A fragments, once
-    Frag xa[2][NK * 4];
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int c = 0; c < NK; ++c)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) xa[j][c * 4 + kk] = *(const Frag*)(sB + c * ACHUNK + wm * 64 * 128 + j * 4096 + foff[kk]);
-    if (tid * 4 < nts * BN) *(f32x4*)(sbias + tid * 4) = *(const f32x4*)(a.bias + nt0 * BN + tid * 4);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < nts; ++t) {
-      const int n0 = (nt0 + t) * BN;
-      f32x16 acc[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < NK; ++ks) {
-        const int s = t * NK + ks;
-        __builtin_amdgcn_s_barrier();
-        const char* sbt = sB + (s % STAGES) * BSTAGE + wn * 64 * 128;
-        Frag wf[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) wf[0][i] = *(const Frag*)(sbt + i * 4096 + foff[0]);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          if (kk < 3) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) wf[(kk + 1) & 1][i] = *(const Frag*)(sbt + i * 4096 + foff[kk + 1]);
-          }
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) Mma<T>::run(wf[kk & 1][i], xa[j][ks * 4 + kk], acc[i][j]);
-        }
-      }
-      // ---- this channel tile is complete: finish it in registers, slab, copy-out (the ring refills meanwhile) ----
-      if (stamps && wv == 0 && t < 12) stamps[t * 4 + 0] = (long long)__builtin_amdgcn_s_memtime() - t_base;
-      dispatch_act(a.act, [&](auto actc) {
-        constexpr int ACT = decltype(actc)::value;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 bv = *(const f32x4*)(sbias + t * BN + wn * 64 + i * 32 + 8 * q + 4 * h);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const int pl = wm * 64 + j * 32 + (lane & 31);
-              bf16x4 o;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (bf16)act_c<ACT>(acc[i][j][4 * q + e] + bv[e]);
-              *(bf16x4*)(sb + pl * SLB + wn * 64 + i * 32 + 8 * q + 4 * h) = o;
-            }
-          }
-      });
-      __builtin_amdgcn_s_barrier();                                              // slab complete (all four MFMA waves wrote it)
-      if (stamps && wv == 0 && t < 12) stamps[t * 4 + 1] = (long long)__builtin_amdgcn_s_memtime() - t_base;
-      {
-        // copy-out by the 256 MFMA-role threads: 16 channel chunks x 16 rows per pass, 8 passes.  (Handing the copy to the loader
-        // waves, a few passes per K-step with exact-count buffer stores, was measured SLOWER: their stores and DMA issues share
-        // one vmcnt queue and the K-step went from 700 to 1140 cycles.)
-        const int c8 = tid & 15;
-        const int c = n0 + c8 * 8;
-        if (c < a.N) {
-          int m = m0 + (tid >> 4);
-          const int b = m / a.OHW;
-          int p = m - b * a.OHW;
-          long long yoff = (long long)b * a.y_bstride + (long long)p * a.ldy + c;
-          const bf16* srow = sb + (tid >> 4) * SLB + c8 * 8;
-#pragma unroll
-          for (int it = 0; it < 8; ++it) {
-            if (m < a.M) *(bf16x8*)((bf16*)a.y + yoff) = *(const bf16x8*)srow;
-            m += 16; p += 16; yoff += 16 * a.ldy; srow += 16 * SLB;
-            while (p >= a.OHW) { p -= a.OHW; yoff += a.y_bstride - (long long)a.OHW * a.ldy; }
-          }
-        }
-      }
-      if (stamps && wv == 0 && t < 12) stamps[t * 4 + 2] = (long long)__builtin_amdgcn_s_memtime() - t_base;
-    }
-  }
-}
 
 int conv_kpad(int K) { return (K + 63) / 64 * 64; }
 int conv_npad(int N) { return (N + 127) / 128 * 128; }
@@ -1871,10 +1495,10 @@ ConvOpts& conv_opts_template() { return g_conv_opts; }
 bool conv_set_option(const char* name, int value) {
   ConvOpts& o = g_conv_opts;
   const struct { const char* n; int* p; } table[] = {
-      {"conv_mode", &o.conv_mode}, {"glds_min_blocks", &o.glds_min_blocks}, {"glds_min_n", &o.glds_min_n}, {"wsa_min_ntn", &o.wsa_min_ntn},
-      {"ws2_min_blocks", &o.ws2_min_blocks}, {"ws64_max_blocks", &o.ws64_max_blocks}, {"ws256_min_blocks", &o.ws256_min_blocks},
-      {"reg_epilogue", &o.reg_epilogue}, {"conv_reg", &o.conv_reg}, {"conv_stream", &o.conv_stream}, {"stream_min_tiles", &o.stream_min_tiles},
-      {"stream2", &o.stream2}, {"stream2_max_n", &o.stream2_max_n}, {"stream_slab", &o.stream_slab}, {"prefetch", &o.prefetch},
+      {"conv_mode", &o.conv_mode}, {"glds_min_blocks", &o.glds_min_blocks}, {"glds_min_n", &o.glds_min_n}, 
+      {"ws2_min_blocks", &o.ws2_min_blocks}, {"ws64_max_blocks", &o.ws64_max_blocks}, 
+      {"reg_epilogue", &o.reg_epilogue}, {"conv_reg", &o.conv_reg}, 
+      {"prefetch", &o.prefetch},
       {"glds_drop", &o.glds_drop}, {"split_ws2_min_blocks", &o.split_ws2_min_blocks}, {"split_ws64_max_blocks", &o.split_ws64_max_blocks},
       {"split_flex", &o.split_flex}, {"split_flex_min_nk", &o.split_flex_min_nk}, {"split_flex_small_max", &o.split_flex_small_max},
       {"split_sx", &o.split_sx}, {"split_k2", &o.split_k2}, {"split_wsq", &o.split_wsq}, {"split_wsq_min_blocks", &o.split_wsq_min_blocks},
@@ -1918,30 +1542,6 @@ static bool dispatch_glds(const ConvOpts& o, const ConvK& k, bool ok, bool prefe
     else rtd_launch((conv_igemm_ws_kernel<T, 2>), dim3((unsigned)(mt * ntn)), dim3(512), 0, s, g);
     return true;
   }
-  if (sizeof(T) == 2 && o.wsa_min_ntn > 0 && (o.conv_mode == 0 || o.conv_mode == 8) && k.KH == 1 && k.KW == 1 && k.stride == 1 && k.pad == 0 &&
-      k.Kpad <= 256 && k.res_mode == RES_NONE && !k.y_f32 && y_bytes > 0 && ntn >= (o.conv_mode == 8 ? 1 : o.wsa_min_ntn)) {
-    // channel tiles per block: keep >= ~1000 blocks when the grid allows (two rounds of one block per CU ... four), never more than 8
-    int npb = (int)std::min<long long>(8, std::max<long long>(1, (mt * ntn) / 1024));
-    npb = std::max(npb, std::min<int>((int)ntn, 3));
-    npb = std::min<int>(npb, (int)ntn);
-    const long long groups = (ntn + npb - 1) / npb;
-    const dim3 grid((unsigned)(mt * groups));
-    g.y_bytes = y_bytes;
-    switch (k.Kpad / (128 / (int)sizeof(T))) {
-      case 1: rtd_launch((conv_igemm_wsa_kernel<T, 1>), grid, dim3(512), 0, s, g, npb); return true;
-      case 2: rtd_launch((conv_igemm_wsa_kernel<T, 2>), grid, dim3(512), 0, s, g, npb); return true;
-      case 4: rtd_launch((conv_igemm_wsa_kernel<T, 4>), grid, dim3(512), 0, s, g, npb); return true;
-      default: break;                             // K = 192: the independent-tile kernels
-    }
-  }
-  {
-    const long long mt256 = (k.M + 255) / 256;
-    const int min256 = prefer256 ? 100 : o.ws256_min_blocks;
-    if (o.conv_mode == 7 || (o.conv_mode == 0 && min256 > 0 && mt256 * ntn >= min256)) {
-      rtd_launch((conv_igemm_ws256_kernel<T>), dim3((unsigned)(mt256 * ntn)), dim3(512), 0, s, g);
-      return true;
-    }
-  }
   // loader / MFMA wave roles win at every grid size (tools/profile_layers.py): grids beyond one block per CU run 2 blocks per CU with
   // 2 stages, smaller grids 1 block per CU with 4 stages (3 tiles of DMA in flight); conv_mode 3 / 4 force either
   const bool four = o.conv_mode == 3 || (o.conv_mode != 4 && mt * ntn < o.ws2_min_blocks);
@@ -1950,201 +1550,6 @@ static bool dispatch_glds(const ConvOpts& o, const ConvK& k, bool ok, bool prefe
   return true;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Direct 3x3 / stride 1 / pad 1 convolution for the narrow, very wide-grid layers (Cin, Cout in {32, 64}: stem.1, stem.2 and
-// the stage-0 c2 convs at 320^2 / 160^2 pixels).  The implicit-GEMM kernels stage every input pixel 9 times (once per tap)
-// and are neither MFMA- nor HBM-bound there (200-350 TF/s, 1.1-1.9 TB/s).  Here
-//   * a block owns an 8 x 32 pixel output tile; its (8+2) x (32+2) pixel input patch is staged ONCE by LDS-DMA (zero padding
-//     = out-of-range buffer offset), 64- or 128-byte pixel rows with a source-side XOR swizzle so that the 32 consecutive
-//     pixels of an MFMA operand read conflict-free;
-//   * each wave keeps the WHOLE filter of its 32 TN output channels in registers (9 taps x CIN/16 fragments x TN: 72 or 144
-//     VGPRs), loaded once per persistent block; the only LDS traffic of the MFMA loop is one 16-byte pixel fragment per TN MFMAs;
-//   * blocks are persistent (block-cyclic over tiles) and two of them share a CU: one block's patch DMA runs under the
-//     other's MFMAs;
-//   * bias + activation in registers, bf16 rows through a wave-private LDS slab, 16-byte stores along NHWC's channels.
-// Cin = 64 filters do not fit one wave's registers for 64 output channels: gridDim.y splits the channels into 32-wide groups.
-// ------------------------------------------------------------------------------------------------
-// RES: a bf16 residual (basic-block nets: the block's second 3x3 conv) is added before / after the activation.  Its rows are
-// requested row-shaped (16 bytes per lane, like the stores) before the MFMAs of the row, cross the wave's store slab and are read
-// back in accumulator shape: the add happens in fp32 registers, one rounding.  Always issued (out-of-range offset = zeros), so the
-// tile loop's counted wait stays exact.
-template <int CIN, int TN, int GROUPS, bool RES = false>
-__global__ __launch_bounds__(256 * GROUPS, 2) void conv3x3_reg_kernel(const ConvK a, unsigned x_bytes, unsigned y_bytes, int tiles_x, int tiles_y, int ntiles, unsigned r_bytes = 0) {
-  // GROUPS = 32 TN-channel groups handled inside the block by different wave quartets (Cin = 64: the 64 output channels need
-  // two register-resident filters; both quartets read the same staged patch)
-  constexpr int NW = 4 * GROUPS, NT_ = 64 * NW;
-  constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2, NPIX = PW * PH;
-  constexpr int ROWB = CIN * 2;                   // bytes per patch pixel
-  constexpr int CPP = CIN / 8;                    // 16-byte chunks per pixel
-  constexpr int PPI = 1024 / ROWB;                // pixels per LDS-DMA wave instruction
-  constexpr int NINSTR = (NPIX + PPI - 1) / PPI;
-  constexpr int PBUF = NINSTR * 1024;             // one patch buffer
-  constexpr int KC = CIN / 16;                    // 16-deep k slices per tap
-  constexpr int ROWO = 64 * TN + 16;              // staging row: 32 TN bf16 channels + 16 bytes (bank skew)
-  constexpr int WROW = 9 * CIN * 2 + 16;          // filter row in LDS (one-time fragment fill): +16 bytes = conflict-free ds_read_b128
-  static_assert(32 * TN * GROUPS * WROW <= 2 * PBUF, "the filter is staged through the two patch buffers");
-  __shared__ __attribute__((aligned(16))) char patch[2 * PBUF];     // double buffered: tile i+1 lands while tile i is computed
-  __shared__ __attribute__((aligned(16))) char stage[NW][32 * ROWO];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wv >> 2, wq = wv & 3;
-  const int nbase = grp * 32 * TN;
-  const int h = lane >> 5;
-
-  bf16x8 wf[9][KC][TN];
-  {
-    // filter rows -> LDS with coalesced 16-byte loads (a fragment load straight from global touches 64 different 1 KiB-apart
-    // rows per instruction: 8x over-fetch, 1.2 MB of L2 traffic per block), then every wave fills its fragment registers
-    const bf16* wg = (const bf16*)a.w;
-    constexpr int CPR = 9 * CIN / 8;              // 16-byte chunks per filter row
-    for (int e = tid; e < 32 * TN * GROUPS * CPR; e += NT_) {
-      const int row = e / CPR, ch = e - row * CPR;
-      *(bf16x8*)(patch + row * WROW + ch * 16) = *(const bf16x8*)(wg + (size_t)row * a.Kpad + ch * 8);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          wf[tap][kc][tn] = *(const bf16x8*)(patch + (nbase + 32 * tn + (lane & 31)) * WROW + (tap * CIN + kc * 16 + 8 * h) * 2);
-    __syncthreads();                                               // the fragments are in registers: the buffers become patches
-  }
-
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res : a.x), 0, RES ? r_bytes : 0u, 0x00020000);
-  auto swz = [](int pi) { return CPP == 8 ? ((pi >> 1) & 7) : ((pi >> 2) & 3); };
-  auto issue_patch = [&](int tile, int buf) {
-    const int tx = tile % tiles_x;
-    const int t2 = tile / tiles_x;
-    const int ty = t2 % tiles_y;
-    const int b = t2 / tiles_y;
-    const int x0 = tx * TW, y0 = ty * TH;
-    for (int j = wv; j < NINSTR; j += NW) {
-      const int pi = j * PPI + lane / CPP;
-      const int py = pi / PW, px = pi - py * PW;
-      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-      const bool ok = pi < NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      const int src_chunk = (lane % CPP) ^ swz(pi);
-      const unsigned vo = ok ? (unsigned)(((long long)b * a.x_bstride + ((long long)iy * a.W + ix) * a.ldx) * 2 + src_chunk * 16) : 0x80000000u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(patch + buf * PBUF + j * 1024), 16, vo, 0, 0, 0);
-    }
-  };
-
-  int tile = blockIdx.x;
-  if (tile < ntiles) issue_patch(tile, 0);
-  for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
-    const int buf = it & 1;
-    // this wave's share of the tile landed.  The 4 TN stores of the previous tile were issued AFTER this tile's DMA and may
-    // stay in flight (every row issues exactly 2 TN buffer stores - rows / pixels outside the image store to an out-of-range
-    // offset, which the hardware drops - so the count is exact); waiting for their acknowledgement cost ~3 us per tile
-    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (TN * (RES ? 2 : 1) == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // RES: 2 TN residual loads + 2 TN stores per row
-    else if (TN * (RES ? 2 : 1) == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    __syncthreads();                                               // ... everybody's; the other buffer's readers are done
-    if (tile + (int)gridDim.x < ntiles) issue_patch(tile + gridDim.x, buf ^ 1);
-    const int tx = tile % tiles_x;
-    const int t2 = tile / tiles_x;
-    const int ty = t2 % tiles_y;
-    const int b = t2 / tiles_y;
-    const int x0 = tx * TW, y0 = ty * TH;
-    const char* pbuf = patch + buf * PBUF;
-
-#pragma unroll 1
-    for (int rr_ = 0; rr_ < 2; ++rr_) {
-      const int r = wq * 2 + rr_;
-      u32x4_ resv[2 * TN];
-      if (RES) {
-        const int oy_ = y0 + r;
-        const long long rrow = (long long)b * a.r_bstride + ((long long)oy_ * a.W + x0) * a.ldr + nbase;
-#pragma unroll
-        for (int i2 = 0; i2 < 2 * TN; ++i2) {
-          const int idx = i2 * 64 + lane;
-          const int p = idx / (4 * TN), ch = idx - p * (4 * TN);
-          const bool ok = oy_ < a.H && x0 + p < a.W;
-          resv[i2] = __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? (unsigned)((rrow + (long long)p * a.ldr + ch * 8) * 2) : 0x80000000u, 0, 0);
-        }
-      }
-      f32x16 acc[TN];
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[tn][e] = 0.f;
-      // pixel fragments of tap t+1 are read while the MFMAs of tap t issue (pinned: left alone, hipcc reads each fragment
-      // right before its MFMA - the register file is full of filter - and every MFMA waits out an LDS round trip)
-      bf16x8 xf[2][KC];
-      auto read_tap = [&](bf16x8 (&dst)[KC], int tap) {
-        const int kh = tap / 3, kw = tap - kh * 3;
-        const int pi = (r + kh) * PW + kw + (lane & 31);
-        const int sw = swz(pi);
-        const char* prow = pbuf + pi * ROWB;
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) dst[kc] = *(const bf16x8*)(prow + (((2 * kc + h) ^ sw) << 4));
-      };
-      read_tap(xf[0], 0);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        if (tap + 1 < 9) read_tap(xf[(tap + 1) & 1], tap + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][kc][tn], xf[tap & 1][kc], acc[tn], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // ---- epilogue of this 32-pixel row: lane = pixel (lane & 31), channels 32 tn + 8 q + 4 h + (0..3) ----
-      const int oy = y0 + r;
-      char* sw_ = stage[wv];
-      if (RES) {                                                    // residual rows -> slab (row shape); read back per accumulator below
-#pragma unroll
-        for (int i2 = 0; i2 < 2 * TN; ++i2) {
-          const int idx = i2 * 64 + lane;
-          const int p = idx / (4 * TN), ch = idx - p * (4 * TN);
-          *(u32x4_*)(sw_ + p * ROWO + ch * 16) = resv[i2];
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      dispatch_act(a.act, [&](auto actc) {
-        constexpr int ACT = decltype(actc)::value;
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 bv = *(const f32x4*)(a.bias + nbase + 32 * tn + 8 * q + 4 * h);   // L1-resident; registers are for the filter
-            bf16x4 o;
-            bf16x4 rv4;
-            if (RES) rv4 = *(const bf16x4*)(sw_ + (lane & 31) * ROWO + (32 * tn + 8 * q + 4 * h) * 2);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float v = acc[tn][4 * q + e] + bv[e];
-              if (RES && a.res_mode == RES_PRE) v += (float)rv4[e];
-              v = act_c<ACT>(v);
-              if (RES && a.res_mode == RES_POST) v += (float)rv4[e];
-              o[e] = (bf16)v;
-            }
-            *(bf16x4*)(sw_ + (lane & 31) * ROWO + (32 * tn + 8 * q + 4 * h) * 2) = o;      // same 8 bytes this lane just read
-          }
-      });
-      __builtin_amdgcn_wave_barrier();
-      {
-        const long long yrow = (long long)b * a.y_bstride + ((long long)oy * a.W + x0) * a.ldy + nbase;
-#pragma unroll
-        for (int i2 = 0; i2 < 2 * TN; ++i2) {
-          const int idx = i2 * 64 + lane;
-          const int p = idx / (4 * TN), ch = idx - p * (4 * TN);
-          const bool ok = oy < a.H && x0 + p < a.W;
-          const unsigned vo = ok ? (unsigned)((yrow + (long long)p * a.ldy + ch * 8) * 2) : 0x80000000u;
-          __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_*)(sw_ + p * ROWO + ch * 16), ry, vo, 0, 0);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();                              // the slab is rewritten by the next row
-    }
-  }
-}
 
 // F16X2 form of the direct 3x3 kernel for 32 input channels (stem.1 32 -> 32, stem.2 32 -> 64 at 320^2): a pixel's 128 bytes are
 // [32 hi | 32 lo], so the patch, its LDS-DMA and its swizzle are the sp16 kernel's CIN = 64 case; each wave keeps the hi AND the lo filter
@@ -2559,463 +1964,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_reg_split64_kernel(const ConvK
   }
 }
 
-// returns true when the launch was taken by the direct kernel
-static bool dispatch_reg(const ConvOpts& o, const ConvK& k, const ConvArgs& a, long long x_bytes, hipStream_t s) {
-  if (!o.conv_reg || o.conv_mode != 0) return false;
-  const Tensor& x = a.x;
-  const Tensor& y = a.y;
-  if (x.dt != BF16 || y.dt != BF16 || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1) return false;
-  const bool with_res = a.res_mode != RES_NONE;
-  long long r_bytes = 0;
-  if (with_res) {                                               // basic-block nets: 64 -> 64 with a bf16 residual
-    if (!(x.c == 64 && y.c == 64) || a.res.dt != BF16 || a.res.ld % 8 || ((uintptr_t)a.res.p & 15)) return false;
-    r_bytes = ((long long)(a.res.n - 1) * a.res.bstride + ((long long)a.res.h * a.res.w - 1) * a.res.ld + a.res.c) * 2;
-    if (r_bytes >= (1ll << 31)) return false;
-  }
-  if (!((x.c == 32 && (y.c == 32 || y.c == 64)) || (x.c == 64 && y.c == 64)) || x.ld % 8 || y.ld % 8 || ((uintptr_t)y.p & 15) || x_bytes >= (1ll << 31)) return false;
-  const long long y_bytes = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * 2;
-  if (y_bytes >= (1ll << 31)) return false;
-  const int tiles_x = (x.w + 31) / 32, tiles_y = (x.h + 7) / 8;
-  const long long ntiles = (long long)x.n * tiles_x * tiles_y;
-  if (ntiles < 256 || ntiles >= (1ll << 30)) return false;        // small maps: the implicit-GEMM tiles fill the chip better
-  // persistent blocks, two per CU (LDS: 2 patch buffers + the store slabs)
-  const unsigned gx = (unsigned)std::min<long long>(ntiles, x.c == 64 ? 256 : 512);
-  if (x.c == 32 && y.c == 32) rtd_launch((conv3x3_reg_kernel<32, 1, 1>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, 0u);
-  else if (x.c == 32) rtd_launch((conv3x3_reg_kernel<32, 2, 1>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, 0u);
-  else if (y.c == 64 && with_res) rtd_launch((conv3x3_reg_kernel<64, 1, 2, true>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, (unsigned)r_bytes);
-  else if (y.c == 64) rtd_launch((conv3x3_reg_kernel<64, 1, 2>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)y_bytes, tiles_x, tiles_y, (int)ntiles, 0u);
-  else return false;
-  return true;
-}
 
-// ------------------------------------------------------------------------------------------------
-// Streaming 1x1 convolution for the thin, very wide-grid layers of the first backbone stages (K = 64 / 128 input channels,
-// 200k / 50k pixels: stage-0/1 c3 + shortcut).  These move 120-240 MB per launch with 7-13 GFLOP: the tiled kernels run them at
-// ~3 TB/s because every 128-pixel block pays a prologue, a staging round trip and a slab epilogue for ONE K-step, while a
-// plain streaming kernel with the same byte mix reaches 6.5-7 TB/s and one with MFMA-fragment-shaped accesses 5 TB/s
-// (tools/stream_probe.hip).  Here there is no LDS tile, no barrier and no role split:
-//   * a WAVE owns 64 output channels and keeps their whole filter in registers (2 x K/16 fragments); it walks 32-pixel tiles
-//     block-cyclically (persistent grid);
-//   * the pixel fragments are read straight from global memory in MFMA B-operand shape (lane = pixel, 16 bytes of K each);
-//     the CG = N/64 waves of a block read the same pixels, the copies hit in the CU's L1;
-//   * the filter rows are PERMUTED when the fragments are loaded (MFMA row 8q+4h+e <- channel 32h+16i+4q+e) so that a lane's
-//     32 accumulators are 32 CONSECUTIVE channels of its pixel: residual and output move as 4 x 16 bytes per lane with no
-//     transpose, and the two lane halves complete one 128-byte line per pixel;
-//   * bias (LDS, broadcast reads) + residual + activation in fp32 registers, one rounding to bf16, `buffer_store` (an
-//     out-of-range offset drops the store: ragged last tile).
-// Arithmetic per output is the tiled kernels' (K in order into a zero accumulator, + bias, + residual, activation).
-// ------------------------------------------------------------------------------------------------
-// SLAB: residual and output cross a wave-private LDS slab (32 rows x 128 bytes + 16 of bank skew, no block barrier) so that
-// their global accesses are row-shaped - 8 lanes x 16 bytes cover one pixel's 128-byte run, 8 lines per instruction instead of
-// 32 (tools/stream_probe.hip: 44 us against 53-61 us for the stage-0 c3 byte mix)
-// NEXT (the block's NW waves = the N / 64 channel groups of ONE 32-pixel tile; N = 256 or 512): the following N -> N / 4 reduce conv
-// runs on the tile while the slabs still hold y: wave w computes output channels 16 w .. 16 w + 15 of the 32 pixels with N / 16
-// v_mfma_f32_16x16x32_f16 (its 16 x N filter slice stays in registers), reading every wave's slab between two block barriers.
-template <int NKK, int THREADS, bool DUAL = false, bool SLAB = true, bool NEXT = false>   // DUAL: the second half of K comes from ConvK::x2 (same channel count as x)
-__global__ __launch_bounds__(THREADS, NKK <= 4 ? 3 : 2) void conv1x1_stream_kernel(const ConvK a, unsigned x_bytes, unsigned r_bytes, unsigned y_bytes, unsigned x2_bytes, int CG, int ntiles, unsigned yn_bytes = 0) {
-  static_assert(!NEXT || SLAB, "the fused reduce conv reads the waves' slabs");
-  constexpr int NS = NEXT ? THREADS / 32 : 1;                   // 32-deep k steps of the fused conv: N / 32 with N = 64 NW
-  constexpr int NW = THREADS / 64;
-  __shared__ __attribute__((aligned(16))) float sbias[512];
-  __shared__ __attribute__((aligned(16))) char pf_dummy[256];
-  constexpr int SROW = 144;
-  __shared__ __attribute__((aligned(16))) char slabs[SLAB ? NW : 1][SLAB ? 32 * SROW : 16];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, pl = lane & 31;
-  const int cg = wv % CG, ps = wv / CG, PG = NW / CG;
-  const int cb = cg * 64;
-  for (int i = tid; i < a.N; i += THREADS) sbias[i] = a.bias[i];
-
-  bf16x8 wf[2][NKK];
-  {
-    const bf16* wg = (const bf16*)a.w;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = cb + 32 * ((pl >> 2) & 1) + 16 * i + 4 * (pl >> 3) + (pl & 3);
-#pragma unroll
-      for (int kk = 0; kk < NKK; ++kk) wf[i][kk] = *(const bf16x8*)(wg + (size_t)row * a.Kpad + kk * 16 + 8 * h);
-    }
-  }
-  __syncthreads();
-  prefetch_share(a, blockIdx.x, gridDim.x, tid, THREADS, pf_dummy);
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.x), 0, a.res ? r_bytes : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? a.x2 : a.x), 0, DUAL ? x2_bytes : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
-  const float* bl = sbias + cb + 32 * h;
-  char* sl = slabs[SLAB ? wv : 0];
-  char* sl_acc = sl + pl * SROW + h * 64;                      // this lane's 64 bytes in accumulator shape (pixel pl, channels 32h..)
-  char* sl_row = sl + (lane >> 3) * SROW + (lane & 7) * 16;    // ... in row shape (pixel lane/8 + 8j, 16-byte chunk lane%8)
-  // NEXT: this wave's 16 x 256 slice of the following filter as v_mfma_f32_16x16x32_f16 A operands (row lane & 15, k 32 s + 8 (lane >> 4) ..)
-  bf16x8 w1f[NS];
-  f32x4 b1v = {0.f, 0.f, 0.f, 0.f};
-  const __amdgpu_buffer_rsrc_t ryn = __builtin_amdgcn_make_buffer_rsrc((void*)(NEXT ? a.next_y : a.y), 0, NEXT ? yn_bytes : 0u, 0x00020000);
-  if (NEXT) {
-    const bf16* w1 = (const bf16*)a.next_w + (size_t)(16 * wv + (lane & 15)) * a.next_kpad + 8 * (lane >> 4);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) w1f[s] = *(const bf16x8*)(w1 + 32 * s);
-    b1v = *(const f32x4*)(a.next_bias + 16 * wv + 4 * (lane >> 4));
-  }
-
-  dispatch_act(a.act, [&](auto actc) {
-    constexpr int ACT = decltype(actc)::value;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-      const int m = (t * PG + ps) * 32 + pl;
-      const bool ok = m < a.M;
-      const int b = m / a.OHW;
-      const int p = m - b * a.OHW;
-      const unsigned xo = ok ? (unsigned)(((long long)b * a.x_bstride + (long long)p * a.ldx) * 2 + 16 * h) : 0x80000000u;
-      u32x4_ xr[NKK];
-      if (DUAL) {
-        const unsigned xo2 = ok ? (unsigned)(((long long)b * a.x2_bstride + (long long)p * a.ldx2) * 2 + 16 * h) : 0x80000000u;
-#pragma unroll
-        for (int kk = 0; kk < NKK / 2; ++kk) xr[kk] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xo + 32 * kk : xo, 0, 0);
-#pragma unroll
-        for (int kk = 0; kk < NKK / 2; ++kk) xr[NKK / 2 + kk] = __builtin_amdgcn_raw_buffer_load_b128(rx2, ok ? xo2 + 32 * kk : xo2, 0, 0);
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) xr[kk] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xo + 32 * kk : xo, 0, 0);
-      }
-      u32x4_ rv[4];
-      unsigned yrow[4];                                          // SLAB: byte offsets of this lane's 4 row-shaped output chunks
-      if (SLAB) {
-        int m2 = (t * PG + ps) * 32 + (lane >> 3);
-        const int b2 = m2 / a.OHW;
-        int p2 = m2 - b2 * a.OHW;
-        long long yo2 = (long long)b2 * a.y_bstride + (long long)p2 * a.ldy + cb + (lane & 7) * 8;
-        long long ro2 = (long long)b2 * a.r_bstride + (long long)p2 * a.ldr + cb + (lane & 7) * 8;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                            // rows 8 apart: carry (image, pixel)
-          const bool ok2 = m2 < a.M;
-          yrow[j] = ok2 ? (unsigned)(yo2 * 2) : 0x80000000u;
-          if (a.res_mode != RES_NONE) rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rr, ok2 ? (unsigned)(ro2 * 2) : 0x80000000u, 0, 0);
-          m2 += 8; p2 += 8; yo2 += 8 * a.ldy; ro2 += 8 * a.ldr;
-          while (p2 >= a.OHW) { p2 -= a.OHW; yo2 += a.y_bstride - (long long)a.OHW * a.ldy; ro2 += a.r_bstride - (long long)a.OHW * a.ldr; }
-        }
-      } else if (a.res_mode != RES_NONE) {
-        const unsigned ro = ok ? (unsigned)(((long long)b * a.r_bstride + (long long)p * a.ldr + cb + 32 * h) * 2) : 0x80000000u;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rv[q] = __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? ro + 16 * q : ro, 0, 0);
-      }
-      f32x16 acc[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < NKK; ++kk)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][kk], __builtin_bit_cast(bf16x8, xr[kk]), acc[i], 0, 0, 0);
-      const unsigned yo = ok ? (unsigned)(((long long)b * a.y_bstride + (long long)p * a.ldy + cb + 32 * h) * 2) : 0x80000000u;
-      if (SLAB && a.res_mode != RES_NONE) {                      // residual: row shape -> slab -> accumulator shape
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *(u32x4_*)(sl_row + j * 8 * SROW) = rv[j];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rv[q] = *(const u32x4_*)(sl_acc + 16 * q);
-        __builtin_amdgcn_wave_barrier();
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 b0 = *(const f32x4*)(bl + 8 * q), b1 = *(const f32x4*)(bl + 8 * q + 4);
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc[q >> 1][8 * (q & 1) + e] + (e < 4 ? b0[e & 3] : b1[e & 3]);
-        float r[8];
-        if (a.res_mode != RES_NONE) {
-          const bf16x8 rb = __builtin_bit_cast(bf16x8, rv[q]);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) r[e] = (float)rb[e];
-        }
-        if (a.res_mode == RES_PRE) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += r[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = act_c<ACT>(v[e]);
-        if (a.res_mode == RES_POST) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += r[e];
-        }
-        const bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-        if (SLAB) *(u32x4_*)(sl_acc + 16 * q) = __builtin_bit_cast(u32x4_, o);
-        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, o), ry, ok ? yo + 16 * q : yo, 0, 0);
-      }
-      if (SLAB) {                                                // output: accumulator shape -> slab -> row-shaped stores
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_*)(sl_row + j * 8 * SROW), ry, yrow[j], 0, 0);
-        __builtin_amdgcn_wave_barrier();
-      }
-      if (NEXT) {
-        __syncthreads();                                         // the four slabs hold the tile's 256 output channels (bf16, activated)
-        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};   // pixels 0-15 / 16-31 (column lane & 15), channels 16 wv + 4 (lane >> 4) + e
-        const int r16 = lane & 15, kq = lane >> 4;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {                            // k = 32 s ..: slab s / 2 (64 channels each), 64-byte half s % 2
-          const char* sb = slabs[s >> 1] + (s & 1) * 64 + kq * 16 + r16 * SROW;
-          const bf16x8 p0 = *(const bf16x8*)sb, p1 = *(const bf16x8*)(sb + 16 * SROW);
-          c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[s], p0, c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[s], p1, c1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int mn = t * 32 + 16 * j + r16;
-          const int bn = mn / a.OHW;
-          const int pn = mn - bn * a.OHW;
-          const f32x4 c = j ? c1 : c0;
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = c[e] + b1v[e];
-            if (a.next_act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
-          }
-          const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-          typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
-          const unsigned off = mn < a.M ? (unsigned)(((long long)bn * a.next_y_bstride + (long long)pn * a.next_ldy + 16 * wv + 4 * kq) * 2) : 0x80000000u;
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, o), ryn, off, 0, 0);
-        }
-        __syncthreads();                                         // every wave has read the slabs: the next tile may overwrite them
-      }
-    }
-  });
-}
-
-// The same streaming scheme for the REDUCING 1x1 layers (K = 256 -> 64 / 128 channels: stage-0 c1, stage-1 block-0 c1), whose
-// bytes are mostly input: here the filter (32-64 KB) lives in LDS, rows stored in the lanes' read order (row L = 64 cg + 32 i + pl
-// holds channel 64 cg + 32 h(pl) + 16 i + 4 q(pl) + e(pl), see above: consecutive lanes read consecutive skewed rows, no bank
-// conflict), a wave owns ALL channels of its 32 pixels (loop over 64-channel groups: the input is read once), and the input
-// crosses the wave-private slab too: row-shaped 16-byte loads (8 lanes = one 128-byte line), then B-operand fragments from LDS.
-template <int NKK, int NCG, int THREADS>
-__global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 : 3) void conv1x1_stream2_kernel(const ConvK a, unsigned x_bytes, unsigned r_bytes, unsigned y_bytes, int ntiles) {
-  constexpr int NW = THREADS / 64, K = NKK * 16, WROW = K * 2 + 16, SROW = 144, N = NCG * 64, NCH = NKK / 4;
-  __shared__ __attribute__((aligned(16))) char wl[N * WROW];
-  __shared__ __attribute__((aligned(16))) float sbias[N];
-  __shared__ __attribute__((aligned(16))) char slabs[NW][32 * SROW];
-  __shared__ __attribute__((aligned(16))) char pf_dummy[256];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, pl = lane & 31;
-  const int cblk = blockIdx.y * N;                              // wider layers: gridDim.y blocks of N channels each (the input is re-read per block, from L2)
-  for (int i = tid; i < N; i += THREADS) sbias[i] = a.bias[cblk + i];
-  {
-    const bf16* wg = (const bf16*)a.w + (size_t)cblk * a.Kpad;
-    constexpr int CPR = K / 8;                    // 16-byte chunks per filter row
-    for (int e = tid; e < N * CPR; e += THREADS) {
-      const int L = e / CPR, ch = e - L * CPR;
-      const int l = L & 31, i = (L >> 5) & 1, cg = L >> 6;
-      const int row = cg * 64 + 32 * ((l >> 2) & 1) + 16 * i + 4 * (l >> 3) + (l & 3);
-      *(bf16x8*)(wl + L * WROW + ch * 16) = *(const bf16x8*)(wg + (size_t)row * a.Kpad + ch * 8);
-    }
-  }
-  __syncthreads();
-  prefetch_share(a, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, tid, THREADS, pf_dummy);
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.x), 0, a.res ? r_bytes : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
-  char* sl = slabs[wv];
-  char* sl_acc = sl + pl * SROW + h * 64;                      // accumulator shape: pixel pl, channels 32h.. of the group
-  char* sl_frag = sl + pl * SROW + h * 16;                     // B-operand shape: pixel pl, K bytes 32 kk + 16 h of the chunk
-  char* sl_row = sl + (lane >> 3) * SROW + (lane & 7) * 16;    // row shape: pixel lane/8 + 8j, 16-byte piece lane%8
-  const char* wrow = wl + pl * WROW + h * 16;
-
-  dispatch_act(a.act, [&](auto actc) {
-    constexpr int ACT = decltype(actc)::value;
-    for (int t = blockIdx.x * NW + wv; t < ntiles; t += gridDim.x * NW) {
-      unsigned xrow[4], yrow[4], rrow[4];
-      {
-        int m2 = t * 32 + (lane >> 3);
-        const int b2 = m2 / a.OHW;
-        int p2 = m2 - b2 * a.OHW;
-        long long xo2 = (long long)b2 * a.x_bstride + (long long)p2 * a.ldx + (lane & 7) * 8;
-        long long yo2 = (long long)b2 * a.y_bstride + (long long)p2 * a.ldy + cblk + (lane & 7) * 8;
-        long long ro2 = (long long)b2 * a.r_bstride + (long long)p2 * a.ldr + cblk + (lane & 7) * 8;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                            // rows 8 apart: carry (image, pixel)
-          const bool ok2 = m2 < a.M;
-          xrow[j] = ok2 ? (unsigned)(xo2 * 2) : 0x80000000u;
-          yrow[j] = ok2 ? (unsigned)(yo2 * 2) : 0x80000000u;
-          rrow[j] = ok2 ? (unsigned)(ro2 * 2) : 0x80000000u;
-          m2 += 8; p2 += 8; xo2 += 8 * a.ldx; yo2 += 8 * a.ldy; ro2 += 8 * a.ldr;
-          while (p2 >= a.OHW) {
-            p2 -= a.OHW;
-            xo2 += a.x_bstride - (long long)a.OHW * a.ldx; yo2 += a.y_bstride - (long long)a.OHW * a.ldy; ro2 += a.r_bstride - (long long)a.OHW * a.ldr;
-          }
-        }
-      }
-      u32x4_ xraw[NCH][4];
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xraw[c][j] = __builtin_amdgcn_raw_buffer_load_b128(rx, xrow[j] + (xrow[j] >> 31 ? 0u : (unsigned)(c * 128)), 0, 0);
-      u32x4_ rv[4];
-      if (a.res_mode != RES_NONE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rr, rrow[j], 0, 0);
-      }
-      bf16x8 xf[NKK];
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {                            // input: row shape -> slab -> fragments, one 128-byte column chunk at a time
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *(u32x4_*)(sl_row + j * 8 * SROW) = xraw[c][j];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) xf[c * 4 + kk] = *(const bf16x8*)(sl_frag + kk * 32);
-        __builtin_amdgcn_wave_barrier();
-      }
-#pragma unroll 1
-      for (int cg = 0; cg < NCG; ++cg) {
-        f32x16 acc[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-        const char* wc = wrow + cg * 64 * WROW;
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(wc + i * 32 * WROW + kk * 32), xf[kk], acc[i], 0, 0, 0);
-        u32x4_ rq[4];
-        if (a.res_mode != RES_NONE) {                            // residual: row shape -> slab -> accumulator shape
-#pragma unroll
-          for (int j = 0; j < 4; ++j) *(u32x4_*)(sl_row + j * 8 * SROW) = rv[j];
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int q = 0; q < 4; ++q) rq[q] = *(const u32x4_*)(sl_acc + 16 * q);
-          __builtin_amdgcn_wave_barrier();
-          if (cg + 1 < NCG) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rr, rrow[j] + (rrow[j] >> 31 ? 0u : (unsigned)((cg + 1) * 128)), 0, 0);
-          }
-        }
-        const float* bl = sbias + cg * 64 + 32 * h;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 b0 = *(const f32x4*)(bl + 8 * q), b1 = *(const f32x4*)(bl + 8 * q + 4);
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = acc[q >> 1][8 * (q & 1) + e] + (e < 4 ? b0[e & 3] : b1[e & 3]);
-          float r[8];
-          if (a.res_mode != RES_NONE) {
-            const bf16x8 rb = __builtin_bit_cast(bf16x8, rq[q]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) r[e] = (float)rb[e];
-          }
-          if (a.res_mode == RES_PRE) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += r[e];
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = act_c<ACT>(v[e]);
-          if (a.res_mode == RES_POST) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += r[e];
-          }
-          const bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-          *(u32x4_*)(sl_acc + 16 * q) = __builtin_bit_cast(u32x4_, o);
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_*)(sl_row + j * 8 * SROW), ry, yrow[j] + (yrow[j] >> 31 ? 0u : (unsigned)(cg * 128)), 0, 0);
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-  });
-}
-
-// returns true when the launch was taken by the streaming kernel
-static bool dispatch_stream(const ConvOpts& o, const ConvK& k, const ConvArgs& a, long long x_bytes, long long x2_bytes, hipStream_t s) {
-  const bool next = a.next_y.p != nullptr;                      // a fused following conv exists in this kernel only: no A/B switch applies
-  if (!next && (!o.conv_stream || (o.conv_mode != 0 && o.conv_mode != 9))) return false;
-  const Tensor& x = a.x;
-  const Tensor& y = a.y;
-  const bool dual = a.x2.p != nullptr;
-  if (a.x_up2 || x.dt != BF16 || y.dt != BF16 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0) return false;
-  if (a.res_mode != RES_NONE && a.res.dt != BF16) return false;
-  if (dual && !(x.c == 64 && a.x2.c == 64)) return false;
-  if (!dual && x.c == 256 && a.Kpad == 256 && (y.c == 64 || y.c % 128 == 0) && y.c <= o.stream2_max_n && o.stream2) {
-    // reducing layers: filter in LDS, a wave owns all channels of its pixels
-    if (x.ld % 8 || y.ld % 8 || ((uintptr_t)y.p & 15)) return false;
-    if (a.res_mode != RES_NONE && (a.res.ld % 8 || ((uintptr_t)a.res.p & 15))) return false;
-    const long long y_bytes = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * 2;
-    long long r_bytes = 0;
-    if (a.res_mode != RES_NONE) r_bytes = ((long long)(a.res.n - 1) * a.res.bstride + ((long long)a.res.h * a.res.w - 1) * a.res.ld + a.res.c) * 2;
-    if (x_bytes >= (1ll << 31) || y_bytes >= (1ll << 31) || r_bytes >= (1ll << 31)) return false;
-    const long long ntiles = ((long long)k.M + 31) / 32;
-    const int ny = y.c <= 128 ? 1 : y.c / 128;                  // expanding layers (stage-2 c3: 256 -> 1024): 128 channels per block
-    if ((ntiles * ny < o.stream_min_tiles && o.conv_mode != 9) || ntiles >= (1ll << 30)) return false;
-    if (ny > 1) {
-      // one 8-wave block per CU; whole rounds of wave tiles, so that no wave of a block has one tile more than another
-      const long long rounds = (ntiles * ny + 2047) / 2048;
-      const unsigned gx = (unsigned)std::max<long long>(1, (ntiles + 8 * rounds - 1) / (8 * rounds));
-      rtd_launch((conv1x1_stream2_kernel<16, 2, 512>), dim3(gx, ny), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes, (int)ntiles);
-      return true;
-    }
-    if (y.c == 64) {        // 52 KB of LDS per 4-wave block: 3 blocks per CU
-      const unsigned gx = (unsigned)std::min<long long>((ntiles + 3) / 4, 768);
-      rtd_launch((conv1x1_stream2_kernel<16, 1, 256>), dim3(gx), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes, (int)ntiles);
-    } else {                // 105 KB per 8-wave block: one block per CU
-      const unsigned gx = (unsigned)std::min<long long>((ntiles + 7) / 8, 256);
-      rtd_launch((conv1x1_stream2_kernel<16, 2, 512>), dim3(gx), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes, (int)ntiles);
-    }
-    return true;
-  }
-  const int K = x.c + (dual ? a.x2.c : 0);
-  if (next && !((y.c == 256 || y.c == 512) && a.next_y.c == y.c / 4 && a.next_y.dt == BF16 && a.next_kpad == y.c && a.next_y.ld % 4 == 0 &&
-                ((uintptr_t)a.next_y.p & 7) == 0 && a.next_w && a.next_bias && (a.next_act == ACT_RELU || a.next_act == ACT_NONE) &&
-                ((y.c == 256 && (K == 64 || dual)) || (y.c == 512 && K == 128 && !dual)))) return false;
-  if (!(K == 64 || K == 128) || a.Kpad != K || y.c % 64 || y.c > 512 || x.ld % 8 || y.ld % 8 || ((uintptr_t)y.p & 15)) return false;
-  if (a.res_mode != RES_NONE && (a.res.ld % 8 || ((uintptr_t)a.res.p & 15))) return false;
-  const long long y_bytes = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * 2;
-  long long r_bytes = 0;
-  if (a.res_mode != RES_NONE) r_bytes = ((long long)(a.res.n - 1) * a.res.bstride + ((long long)a.res.h * a.res.w - 1) * a.res.ld + a.res.c) * 2;
-  if (x_bytes >= (1ll << 31) || y_bytes >= (1ll << 31) || r_bytes >= (1ll << 31) || x2_bytes >= (1ll << 31)) return false;
-  const int CG = y.c / 64;
-  if (CG != 1 && CG != 2 && CG != 4 && CG != 8) return false;
-  const int NW = CG == 8 ? 8 : 4;
-  const int PG = NW / CG;
-  const long long ntiles = ((long long)k.M + 32 * PG - 1) / (32 * PG);
-  if ((ntiles * NW < o.stream_min_tiles && o.conv_mode != 9 && !next) || ntiles >= (1ll << 30)) return false;
-  if (next) {
-    const long long yn_bytes = ((long long)(a.next_y.n - 1) * a.next_y.bstride + ((long long)a.next_y.h * a.next_y.w - 1) * a.next_y.ld + a.next_y.c) * 2;
-    if (yn_bytes >= (1ll << 31)) return false;
-    const unsigned gxn = (unsigned)std::min<long long>(ntiles, NW == 8 ? 256 : (dual ? 512 : 768));   // 4-wave blocks: 2 (K = 128) or 3 (K = 64) waves per SIMD
-    if (NW == 8) rtd_launch((conv1x1_stream_kernel<8, 512, false, true, true>), dim3(gxn), dim3(512), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes,
-                                    (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles, (unsigned)yn_bytes);
-    else if (dual) rtd_launch((conv1x1_stream_kernel<8, 256, true, true, true>), dim3(gxn), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes,
-                                 (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles, (unsigned)yn_bytes);
-    else rtd_launch((conv1x1_stream_kernel<4, 256, false, true, true>), dim3(gxn), dim3(256), 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes,
-                            (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles, (unsigned)yn_bytes);
-    return true;
-  }
-  // persistent blocks, as many as the register budget keeps resident (K = 64: 3 waves per SIMD, K = 128: 2)
-  // (the slab variant of K = 64 needs 128 VGPRs: 4 waves per SIMD)
-  const unsigned gx = (unsigned)std::min<long long>(ntiles, K == 64 ? (NW == 8 ? 256 : (o.stream_slab ? 1024 : 768)) : (NW == 8 ? 256 : 512));
-#define RTD_STREAM(NKK, THREADS, DUAL)                                                                                                \
-  do {                                                                                                                                \
-    if (o.stream_slab)                                                                                                                \
-      rtd_launch((conv1x1_stream_kernel<NKK, THREADS, DUAL, true>), dim3(gx), dim3(THREADS), 0, s, k, (unsigned)x_bytes,      \
-                         (unsigned)r_bytes, (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles, 0u);                              \
-    else                                                                                                                              \
-      rtd_launch((conv1x1_stream_kernel<NKK, THREADS, DUAL, false>), dim3(gx), dim3(THREADS), 0, s, k, (unsigned)x_bytes,     \
-                         (unsigned)r_bytes, (unsigned)y_bytes, (unsigned)x2_bytes, CG, (int)ntiles, 0u);                              \
-  } while (0)
-  if (K == 64) {
-    if (NW == 8) RTD_STREAM(4, 512, false);
-    else RTD_STREAM(4, 256, false);
-  } else if (dual) {
-    if (NW == 8) RTD_STREAM(8, 512, true);
-    else RTD_STREAM(8, 256, true);
-  } else {
-    if (NW == 8) RTD_STREAM(8, 512, false);
-    else RTD_STREAM(8, 256, false);
-  }
-#undef RTD_STREAM
-  return true;
-}
 
 // register-staged fallback: every shape (small channel counts, grids below the LDS-DMA kernels' thresholds)
 template <typename T>
@@ -3096,19 +2045,11 @@ bool conv_avg_supported(const ConvArgs& a) {
   return x.c == 128 && !a.next_y.p;
 }
 bool conv_next_supported(const ConvArgs& a) {
-  const ConvOpts& o = opts_of(a);
   const Tensor& x = a.x;
   const Tensor& y = a.y;
-  const bool dual = a.x2.p != nullptr;
   if (x.dt == F16X2)
     return sx_shape_ok(a) && y.c == 256 && (a.next_y.c == 64 || a.next_y.c == 128) && a.next_y.dt == F16X2 && a.next_y.ld % SPLIT_GROUP == 0 && y.ld % SPLIT_GROUP == 0;
-  if (!o.conv_stream || !o.stream_slab || x.dt != BF16 || y.dt != BF16 || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.x_up2) return false;
-  if (a.res_mode != RES_NONE && (a.res.dt != BF16 || a.res.ld % 8)) return false;
-  if (dual && !(x.c == 64 && a.x2.c == 64 && y.c == 256)) return false;
-  if (!dual && !((x.c == 64 && y.c == 256) || (x.c == 128 && y.c == 512))) return false;
-  if (x.ld % 8 || y.ld % 8 || a.next_y.c != y.c / 4 || a.next_y.dt != BF16 || a.next_y.ld % 4) return false;
-  const long long ntiles = ((long long)y.n * y.h * y.w + 31) / 32;
-  return ntiles * (y.c / 64) >= o.stream_min_tiles;
+  return false;                                                 // bf16 / fp32 operands: no kernel with a fused following conv (round 5: the bf16 streaming kernels were removed)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3860,10 +2801,8 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     const long long es = (long long)dtype_size(x.dt);
     const long long x_bytes = ((long long)(x.n - 1) * x.bstride + ((long long)x.h * x.w - 1) * x.ld + x.c) * es;
     const long long w_bytes = (long long)a.Npad * a.Kpad * es;
-    done = !dual && !a.next_y.p && dispatch_reg(o, k, a, x_bytes, s);
-    if (!done) done = dispatch_stream(o, k, a, x_bytes, x2_bytes, s);
-    RTD_CHECK(done || !a.next_y.p, 1, "conv: the fused following conv needs the streaming kernel (see conv_next_supported)");
-    if (!done) {
+    RTD_CHECK(!a.next_y.p, 1, "conv: a fused following conv exists on F16X2 operands only (see conv_next_supported)");
+    {
       const long long yb = ((long long)(y.n - 1) * y.bstride + ((long long)y.h * y.w - 1) * y.ld + y.c) * (long long)dtype_size(y.dt);
       const unsigned y_bytes = yb < (1ll << 31) ? (unsigned)yb : 0u;
       if (x.dt == BF16) done = dispatch_glds<bf16>(o, k, tile_ok, a.prefer256 != 0, x_bytes, w_bytes, y_bytes, (unsigned)x2_bytes, a.ws, s);

@@ -9,8 +9,8 @@ several frames) become ONE `[N, 3, S, S]` classifier batch with one HIP launch (
 every detection -> ONE crop launch -> ONE classifier forward per taxonomic category -> the same per-detection result rules
 (`SpeciesClassifier.classify`'s formatting, src/species_classifier.py:383-413, the time-of-day re-ranking and the rejected
 taxonomic levels of :393-445), detections returned in their input order.  The classifier network itself (timm EVA02-L/14@336,
-fetched by name, src/species_classifier.py:252-262) is out of scope; `StandInSpeciesClassifier` - declared as a stand-in - gives
-the glue something with the reference classifier's attributes to drive in tests and in `bench.py --workload two_stage`.
+fetched by name, src/species_classifier.py:252-262) is out of scope; the tests drive the glue with a declared stand-in that has the
+reference classifier's attributes (tests/standins.py), `bench.py --workload two_stage` times the crop batch alone.
 """
 from __future__ import annotations
 
@@ -269,83 +269,3 @@ class BatchedStage2:
         if isinstance(frame, np.ndarray):
             frame = torch.from_numpy(np.ascontiguousarray(frame)).cuda()
         return self.process_batch([frame.contiguous()], [detections])[0]
-
-
-class StandInSpeciesClassifier:
-    """STAND-IN for the reference's `SpeciesClassifier` (timm EVA02-L/14@336 + iNat21 taxonomy, both unavailable offline): a small
-    seeded conv net over the same [N,3,S,S] input with the attributes `BatchedStage2` / `format_predictions` read.  It exists so that
-    the batched glue can be tested end to end and timed; it says nothing about the real classifier's accuracy or cost."""
-
-    def __init__(self, num_classes: int = 40, input_size: int = 336, device: str = "cuda:0", seed: int = 0, use_hierarchical: bool = True,
-                 confidence_threshold: float = 0.3):
-        import torch
-        import torch.nn as nn
-
-        g = torch.Generator().manual_seed(seed)
-        net = nn.Sequential(nn.Conv2d(3, 16, 7, 4, 3), nn.ReLU(), nn.Conv2d(16, 32, 3, 2, 1), nn.ReLU(), nn.AdaptiveAvgPool2d(4), nn.Flatten(),
-                            nn.Linear(512, num_classes))
-        with torch.no_grad():
-            for prm in net.parameters():
-                prm.copy_(torch.randn(prm.shape, generator=g) * (2.5 if prm.dim() == 2 else 0.15))
-        self.model = net.to(device).eval()
-        self.input_size = input_size
-        self.use_hierarchical = use_hierarchical
-        self.confidence_threshold = confidence_threshold
-        self.enable_geographic_filter = False
-        self.allowed_species = None
-        self.hierarchy_thresholds = {"species": 0.6, "genus": 0.4, "family": 0.3, "order": 0.2, "class": 0.1}
-        self.taxonomy = {str(i): {"common_name": f"species_{i}", "genus": f"genus_{i // 2}", "family": f"family_{i // 4}",
-                                  "order": f"order_{i // 8}", "class": "Aves" if i % 2 else "Mammalia"} for i in range(num_classes)}
-
-    def get_hierarchical_label(self, class_id: int, confidence: float):
-        """same contract as src/species_classifier.py:168-233: the most specific rank the confidence supports, or (None, None)"""
-        entry = self.taxonomy.get(str(class_id), {})
-        if not self.use_hierarchical:
-            return entry.get("common_name", f"species_{class_id}"), "species"
-        for level, key in (("species", "common_name"), ("genus", "genus"), ("family", "family"), ("order", "order"), ("class", "class")):
-            if confidence >= self.hierarchy_thresholds[level]:
-                label = entry.get(key)
-                return (label, level) if label else (None, None)
-        return None, None
-
-
-class StandInPipeline:
-    """The attributes of `TwoStageDetectionPipeline` (src/two_stage_pipeline_yolox.py:63-91) that `BatchedStage2` reads, with
-    stand-in classifiers for the reference's categories - for tests and bench.py only."""
-
-    def __init__(self, device: str = "cuda:0", categories=("bird", "mammal"), min_crop_size: int = 64, crop_padding_percent: int = 20):
-        from .coco_constants import CLASS_ID_TO_CATEGORY
-
-        self.enable_species_classification = True
-        self.class_id_to_category = CLASS_ID_TO_CATEGORY
-        self.species_classifiers = {c: StandInSpeciesClassifier(device=device, seed=10 + i) for i, c in enumerate(categories)}
-        self.min_crop_size = min_crop_size
-        self.crop_padding_percent = crop_padding_percent
-        self.rejected_taxonomic_levels = ["order", "class"]
-        self.time_of_day_top_k = 5
-        self.time_of_day_penalty = 0.3
-        self.enhancer = None
-
-
-def bench_crop_step(batch: int, size: int, seed: int = 5000, n_crops: int = 16):
-    """bench.py --workload two_stage (BASELINE config 5): after each detect step, the Stage-2 crop batch of `n_crops` mixed-size boxes
-    (sides drawn from rng.integers(64, 512)) spread over the step's frames -> [16,3,336,336] classifier input, enqueued on
-    the engine's stream.  The classifier forward is excluded (its network is out of scope) and the boxes are synthetic: Stage 1 on noise
-    frames with random weights finds nothing above threshold.  Returns (callable, description)."""
-    import torch
-
-    rng = np.random.default_rng(seed)
-    batcher = CropBatcher()
-    rects = [[] for _ in range(batch)]
-    for i in range(n_crops):
-        cw, ch = int(rng.integers(64, min(512, size))), int(rng.integers(64, min(512, size)))
-        x, y = int(rng.integers(0, size - cw + 1)), int(rng.integers(0, size - ch + 1))
-        rects[i % batch].append((x, y, x + cw, y + ch))
-
-    def run(engine, frames, stream):
-        with torch.cuda.stream(stream):
-            batcher.preprocess_batch(frames, rects)
-
-    info = {"crops_per_step": n_crops, "crop_sides": "rng.integers(64, 512)", "classifier_input": [n_crops, 3, batcher.input_size, batcher.input_size],
-            "timed": "detect + crop/resize/normalise batch (one launch); classifier forward EXCLUDED (EVA02 out of scope)"}
-    return run, info

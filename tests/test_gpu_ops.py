@@ -105,7 +105,7 @@ def test_conv_dual(L, dt, case):
     wcat = torch.cat([w1.permute(0, 2, 3, 1).reshape(Cout, -1), w2.reshape(Cout, C2)], dim=1).contiguous().cuda()
     xd, x2d, bd = nhwc(x, tdt), nhwc(x2, tdt), b.cuda()
     from telescope_cam_detection_amd import _capi
-    for out_f32, mode in (((1, 0), (1, 10)) if dt == "f32" else ((0, 0), (1, 0), (0, 3), (0, 9), (0, 10))):
+    for out_f32, mode in (((1, 0), (1, 10)) if dt == "f32" else ((0, 0), (1, 0), (0, 3), (0, 10))):
         if dt == "f32" and B * H * W * ((Cout + 127) // 128) < 512 * 128:
             # fp32 launches need >= 512 tiles for the LDS-DMA kernels: the library must refuse the shape, not fall back
             yd = torch.zeros(B, H, W, Cout, dtype=torch.float32, device="cuda")
@@ -160,9 +160,9 @@ def test_dual_input_conv_random_shapes(L, seed):
 
 
 @pytest.mark.parametrize("seed", list(range(16)))
-def test_streaming_1x1_kernels_random_shapes(L, seed):
-    """conv_mode 9 (streaming kernels on any grid): random small maps - images smaller than a 32-pixel tile, tiles that straddle
-    several images, ragged last tiles - for every channel configuration the three streaming kernels take."""
+def test_bf16_1x1_convs_random_small_shapes(L, seed):
+    """bf16 1x1 convs on random small maps - images smaller than a tile, tiles that straddle several images, ragged last tiles - with every
+    activation / residual form (round 5: the bf16 streaming kernels are gone; these shapes now run on the bf16 engine's one tile path)."""
     rng = np.random.default_rng(4200 + seed)
     Cin = int(rng.choice([64, 128, 256]))
     Cout = int(rng.choice([64, 128, 256, 512]) if Cin != 256 else rng.choice([64, 128, 256, 384, 640]))
@@ -183,7 +183,7 @@ def test_streaming_1x1_kernels_random_shapes(L, seed):
     if res_mode == 2:
         y = y + q(res)
     from telescope_cam_detection_amd import _capi
-    _capi.debug_option("conv_mode", 9)
+    _capi.debug_option("conv_mode", 0)
     try:
         xd, wd, bd = nhwc(x, tdt), w.permute(0, 2, 3, 1).contiguous().cuda(), b.cuda()
         rd = nhwc(res, tdt) if res is not None else None
@@ -247,13 +247,10 @@ def test_conv(L, dt, case):
     rd = nhwc(res, tdt) if res is not None else None
     from telescope_cam_detection_amd import _capi
     # conv_mode 0 = auto (LDS-DMA kernel where eligible), 1 = the register-staged fallback kernel only,
-    # 3 / 4 = wave-specialised LDS-DMA kernel (4 / 2 stages), 7 = wave-specialised 256-pixel tile,
-    # 8 = A-stationary kernel wherever it is eligible (1x1, K <= 256, no residual),
-    # 9 = streaming 1x1 kernel wherever it is eligible (K = 64 / 128, Cout % 64 == 0), whatever the grid size
+    # 3 / 4 = wave-specialised LDS-DMA kernel (4 / 2 stages),
     # 10 = the 128 x 64 tile of the wave-specialised kernel (auto below 160 tiles) on every shape the LDS-DMA kernels take
-    for out_f32, mode in (((1, 0), (1, 1), (1, 3), (1, 7), (1, 10)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 3), (0, 4), (0, 7), (1, 7), (0, 8), (0, 9), (0, 109), (0, 10), (1, 10))):
-        _capi.debug_option("stream_slab", 0 if mode >= 100 else 1)      # 109 = mode 9 with accumulator-shaped global accesses
-        mode %= 100
+    # (round 5: the 256-pixel, A-stationary, streaming and direct-3x3 bf16 generations were removed; bf16 / fp32 keep this one path)
+    for out_f32, mode in (((1, 0), (1, 1), (1, 3), (1, 10)) if dt == "f32" else ((0, 0), (1, 0), (0, 1), (0, 3), (0, 4), (0, 10), (1, 10))):
         _capi.debug_option("conv_mode", mode)
         yd = torch.full((B, OH, OW, Cout), float("nan"), dtype=torch.float32 if out_f32 else tdt, device="cuda")
         ck(L, L.rtd_op_conv(code, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None,
@@ -269,7 +266,6 @@ def test_conv(L, dt, case):
             tol = dict(atol=2e-2, rtol=1e-2)       # + one bf16 rounding of the output
         torch.testing.assert_close(got, y, **tol, msg=lambda m: f"conv_mode {mode} out_f32 {out_f32} {case}: {m}")
     _capi.debug_option("conv_mode", 0)
-    _capi.debug_option("stream_slab", 1)
 
 
 SPLIT_CONV_CASES = [

@@ -4,7 +4,8 @@ import pytest
 import torch
 
 from oracle import stage2_oracle as s2o
-from telescope_cam_detection_amd.stage2 import BatchedStage2, CropBatcher, StandInPipeline, crop_rect, normalised_bbox
+from telescope_cam_detection_amd.stage2 import BatchedStage2, CropBatcher, crop_rect, normalised_bbox
+from tests.standins import StandInPipeline
 from telescope_cam_detection_amd.synth import scene_frame
 
 

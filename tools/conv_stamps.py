@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
 """In-kernel s_memtime stamps of one conv layer (rtd_bench_conv with rtd_debug_option("glds_drop", 32)).
 
-    RTD_CONV_STAMPS=1 python tools/conv_stamps.py s1c2 ws256    # per-K-step stamps of the 256-pixel tile kernel (blocks 0, 1, 17)
-    RTD_CONV_STAMPS=2 python tools/conv_stamps.py s0c3          # block-level phases of the default 128-pixel ws kernels
-    RTD_CONV_STAMPS=3 python tools/conv_stamps.py vpall wsa     # per channel tile of the A-stationary kernel
+    RTD_CONV_STAMPS=2 python tools/conv_stamps.py s0c3          # block-level phases of the 128-pixel ws kernels (bf16 operands)
+(round 5: the 256-pixel and A-stationary bf16 kernels and their stamp modes were removed with those kernels)
 """
 import ctypes as C
 import os
@@ -23,13 +22,9 @@ SHAPES = {  # HW, Cin, Cout, k, stride, pad, residual
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "s1c2"
     L = _capi.lib()
-    if "ws256" in sys.argv[2:]:
-        _capi.debug_option("conv_mode", 7)
     _capi.debug_option("glds_drop", 32)
     hw, cin, cout, k, st, pad, res = SHAPES[which]
     out = (C.c_float * 2)()
-    if "wsa" in sys.argv[2:]:
-        _capi.debug_option("conv_mode", 8)
     if hw < 0:      # token GEMM: 1 x (-hw) "image"
         rc = L.rtd_bench_conv(0, 8, 1, -hw, cin, cout, k, st, pad, res, 3, 0, out)
     else:
