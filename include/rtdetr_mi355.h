@@ -145,8 +145,32 @@ typedef struct rtd_stats {
   int32_t stream_capture_status; /* hipStreamIsCapturing of the handle's stream now: 0 none (the only value this library produces) */
   int32_t in_flight;             /* 1: a submitted batch has not been collected */
   int64_t plans, graphs, graph_nodes, graph_launches, eager_passes, submits, collects, failed_calls;
+  int64_t saturated_values;      /* F16X2 activations found AT the format's saturation value (+-65504) by the last rtd_self_check, -1 = never run */
+  float max_abs_filter;          /* largest |folded filter value| of the loaded blob (> 65504 is refused by rtd_load_weights on the pair engine) */
+  int32_t reserved;
 } rtd_stats;
 int rtd_get_stats(rtd_handle h, rtd_stats* out);
+
+/* Real-weights guard (part of "the model is ready after load_model", src/rtdetr_detector.py:132-173).  Every parity claim of this library
+ * was measured on seeded synthetic weights; the pair engine's fp16 halves SATURATE at +-65504 - silently, finitely.  Two things keep a
+ * trained checkpoint honest:
+ *  (1) rtd_load_weights returns RTD_E_WEIGHTS for a tensor that holds NaN / Inf and - RTD_PREC_F16X3 - for a folded filter value
+ *      beyond 65504 (rtd_last_error names the tensor);
+ *  (2) rtd_self_check runs ONE built-in frame of the handle's input size through the library's exact fp32 engine and through an engine of
+ *      the handle's precision, both built from the handle's own weights, counts the activations that sit at the saturation value and
+ *      matches the detection rows (same label, |dscore| <= score_tol = 1e-3, max |dbox| <= box_tol_px = 1e-2, the reference tolerance).
+ *      The caller decides: RTDETRDetector.load_model(verify=True) logs the report and refuses a checkpoint whose rows do not match.
+ *      Costs two temporary bs-1 engines (a second or two at load time); the handle itself is not touched. */
+typedef struct rtd_check_report {
+  int32_t struct_size;             /* in: = sizeof(rtd_check_report) */
+  int32_t rows, rows_matched;      /* rows of the fp32 engine's answer / of them matched by the handle's precision within the tolerance */
+  float worst_score_err, worst_box_err_px;   /* over the matched rows */
+  float score_tol, box_tol_px;
+  float max_abs_filter;
+  int64_t saturated_values;        /* F16X2 activations at +-65504 after that forward (0 for the other precisions) */
+  char max_abs_filter_name[64];
+} rtd_check_report;
+int rtd_self_check(rtd_handle h, rtd_check_report* out);
 
 /* mutable attribute `model.to(device)` / teardown (src/inference_engine_yolox.py:743-744) */
 void rtd_destroy(rtd_handle h);

@@ -81,7 +81,14 @@ class RtdDet(C.Structure):
 class RtdStats(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("last_error_code", C.c_int32), ("stream_capture_status", C.c_int32), ("in_flight", C.c_int32),
                 ("plans", C.c_int64), ("graphs", C.c_int64), ("graph_nodes", C.c_int64), ("graph_launches", C.c_int64),
-                ("eager_passes", C.c_int64), ("submits", C.c_int64), ("collects", C.c_int64), ("failed_calls", C.c_int64)]
+                ("eager_passes", C.c_int64), ("submits", C.c_int64), ("collects", C.c_int64), ("failed_calls", C.c_int64),
+                ("saturated_values", C.c_int64), ("max_abs_filter", C.c_float), ("reserved", C.c_int32)]
+
+
+class RtdCheckReport(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("rows", C.c_int32), ("rows_matched", C.c_int32), ("worst_score_err", C.c_float),
+                ("worst_box_err_px", C.c_float), ("score_tol", C.c_float), ("box_tol_px", C.c_float), ("max_abs_filter", C.c_float),
+                ("saturated_values", C.c_int64), ("max_abs_filter_name", C.c_char * 64)]
 
 
 class RtdLayerTime(C.Structure):
@@ -97,7 +104,7 @@ _lib: Optional[C.CDLL] = None
 EXPORTS = [
     "rtd_version", "rtd_create", "rtd_load_weights", "rtd_infer", "rtd_infer_raw", "rtd_infer_async", "rtd_collect", "rtd_prepare",
     "rtd_result_block", "rtd_sync", "rtd_stream", "rtd_wait_stream", "rtd_signal_stream", "rtd_get_stats", "rtd_arena_bytes", "rtd_destroy",
-    "rtd_last_error", "rtd_crop_resize_batch",
+    "rtd_last_error", "rtd_crop_resize_batch", "rtd_self_check",
 ]
 # every symbol include/rtdetr_mi355_test.h declares: kernel-level test / bench / debug entry points (csrc/testapi.hip)
 TEST_EXPORTS = [
@@ -146,6 +153,8 @@ def lib() -> C.CDLL:
     L.rtd_wait_stream.argtypes = [vp, vp]
     L.rtd_signal_stream.argtypes = [vp, vp]
     L.rtd_get_stats.argtypes = [vp, C.POINTER(RtdStats)]
+    L.rtd_self_check.argtypes = [vp, C.POINTER(RtdCheckReport)]
+    L.rtd_self_check.restype = C.c_int
     L.rtd_result_block.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.rtd_sync.argtypes = [vp]
     L.rtd_stream.argtypes = [vp]
@@ -191,7 +200,7 @@ def _stats_of(handle) -> dict:
     st = RtdStats()
     if not handle or lib().rtd_get_stats(handle, C.byref(st)) != RTD_OK:
         return {}
-    return {k: int(getattr(st, k)) for k, _ in RtdStats._fields_ if k != "struct_size"}
+    return {k: (float(getattr(st, k)) if k == "max_abs_filter" else int(getattr(st, k))) for k, _ in RtdStats._fields_ if k not in ("struct_size", "reserved")}
 
 
 def _raise(code: int, handle) -> None:
@@ -355,6 +364,17 @@ class Engine:
 
     def stats(self) -> dict:
         return _stats_of(self._h)
+
+    def self_check(self) -> dict:
+        """rtd_self_check: this engine's arithmetic against the library's exact fp32 engine on one built-in frame, with THESE weights."""
+        rep = RtdCheckReport()
+        rep.struct_size = C.sizeof(RtdCheckReport)
+        rc = lib().rtd_self_check(self._h, C.byref(rep))
+        if rc != RTD_OK:
+            _raise(rc, self._h)
+        return {"rows": rep.rows, "rows_matched": rep.rows_matched, "worst_score_err": rep.worst_score_err, "worst_box_err_px": rep.worst_box_err_px,
+                "score_tol": rep.score_tol, "box_tol_px": rep.box_tol_px, "saturated_values": rep.saturated_values,
+                "max_abs_filter": rep.max_abs_filter, "max_abs_filter_name": rep.max_abs_filter_name.decode(errors="replace")}
 
     def result_block(self):
         p = C.c_void_p()

@@ -347,6 +347,7 @@ void launch_to_f32(const void* src, int dt, float* dst, int64_t n, hipStream_t s
 // dense [rows][C] fp32 <-> F16X2 rows (C % 32 == 0); `ld*` in channels
 void launch_f32_to_split(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int C, hipStream_t s);
 void launch_split_to_f32(const void* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int C, hipStream_t s);
+void launch_count_saturated(const void* split_buf, int64_t n16, unsigned long long* count_dev, hipStream_t s);
 
 #if defined(__HIPCC__)
 // ---- F16X2 helpers: element offset (in bf16 units, from the tensor base) of the hi half of channel c of a pixel whose first

@@ -58,6 +58,33 @@ void parse_blob(rtd_engine* e) {
   }
 }
 
+// Real-weights guard, part 1: a checkpoint is refused at load time when a tensor holds a NaN / Inf, or - on the pair
+// engine, whose operands are fp16 hi/lo halves that SATURATE at +-65504 (common.h split2, f2h_rne below) - when a folded filter value does
+// not fit that range: the result would be finite, plausible and wrong.  (BN folding multiplies a filter row by gamma / sqrt(var + eps):
+// a collapsed running_var on a trained checkpoint is how such values arise.)
+void check_weight_range(rtd_engine* e) {
+  e->max_abs_filter = 0.f;
+  e->max_abs_filter_name.clear();
+  for (const auto& kv : e->host) {
+    const HostTensor& t = kv.second;
+    const int64_t n = t.numel();
+    float mx = 0.f;
+    bool finite = true;
+    for (int64_t i = 0; i < n; ++i) {
+      const float v = t.data[i];
+      if (!std::isfinite(v)) { finite = false; break; }
+      mx = std::max(mx, fabsf(v));
+    }
+    RTD_CHECK(finite, RTD_E_WEIGHTS, "weight blob: tensor " + kv.first + " holds a NaN or an infinity");
+    const bool is_filter = kv.first.size() > 2 && kv.first.compare(kv.first.size() - 2, 2, ".w") == 0;
+    if (is_filter && mx > e->max_abs_filter) { e->max_abs_filter = mx; e->max_abs_filter_name = kv.first; }
+  }
+  if (e->cfg.precision == RTD_PREC_F16X3)
+    RTD_CHECK(e->max_abs_filter <= 65504.f, RTD_E_WEIGHTS,
+              "weight blob: folded filter " + e->max_abs_filter_name + " reaches " + std::to_string(e->max_abs_filter) +
+                  ", beyond the fp16 pair format's range (65504): load this checkpoint with precision fp32");
+}
+
 const HostTensor& host_tensor(rtd_engine* e, const std::string& name) {
   auto it = e->host.find(name);
   RTD_CHECK(it != e->host.end(), RTD_E_WEIGHTS, "weight blob: missing tensor " + name);
@@ -340,7 +367,9 @@ struct Builder {
   Tensor act(int dt, int n, int h, int w, int c, const std::string& name = "") {
     Tensor t;
     t.dt = dt; t.n = n; t.h = h; t.w = w; t.c = c; t.ld = c; t.bstride = (int64_t)h * w * c;
-    t.p = alloc((size_t)n * h * w * c * dtype_size(dt));
+    const size_t nbytes = (size_t)n * h * w * c * dtype_size(dt);
+    t.p = alloc(nbytes);
+    if (!dry && dt == F16X2) plan->split_acts.emplace_back(t.p, nbytes);
     if (!name.empty()) plan->named[name] = t;
     return t;
   }
@@ -1363,6 +1392,7 @@ int rtd_load_weights(rtd_handle h, const void* blob, size_t nbytes) {
     if (!e->ev_xs) HIP_CHECK(hipEventCreateWithFlags(&e->ev_xs, hipEventDisableTiming));
     e->blob.assign((const char*)blob, (const char*)blob + nbytes);
     parse_blob(e);
+    check_weight_range(e);
     const rtd_config& c = e->cfg;
     // level geometry (strides 8/16/32)
     int hh = down2(down2(c.input_h)), ww = down2(down2(c.input_w));
@@ -1537,6 +1567,112 @@ int rtd_signal_stream(rtd_handle h, void* consumer_stream) {
   });
 }
 
+// Real-weights guard, part 2: the handle's arithmetic against the library's own exact fp32 engine, on ONE built-in frame, with THESE weights.
+// Two temporary bs-1 handles are built from the handle's blob: the fp32 engine (the reference arithmetic, ~2 ms per frame) and an engine of
+// the handle's precision whose activations all keep their own buffer (arena_reuse off), so that after the forward every F16X2 activation of
+// the network can be scanned for the saturation value.  Rows are matched like the parity tests match them (same label, |dscore| <= 1e-3,
+// max |dbox| <= 1e-2 px, greedy) - near-ties at the two top-k cuts can cost single rows on any engine, a checkpoint outside the format's
+// range costs most of them.
+static void check_frame(int H, int W, std::vector<uint8_t>& f) {
+  f.resize((size_t)H * W * 3);
+  uint32_t lcg = 12345u;
+  auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return lcg >> 8; };
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x)
+      for (int c = 0; c < 3; ++c) f[((size_t)y * W + x) * 3 + c] = (uint8_t)(70 + 40 * c + (x * (60 + 20 * c)) / W + (y * (50 - 10 * c)) / H);
+  for (int o = 0; o < 14; ++o) {
+    const int cx = (int)(rnd() % (unsigned)W), cy = (int)(rnd() % (unsigned)H);
+    const int sx = std::max(4, (int)(rnd() % (unsigned)std::max(1, W / 4))), sy = std::max(4, (int)(rnd() % (unsigned)std::max(1, H / 4)));
+    const uint8_t col[3] = {(uint8_t)(rnd() & 255), (uint8_t)(rnd() & 255), (uint8_t)(rnd() & 255)};
+    const bool ell = rnd() & 1;
+    for (int y = std::max(0, cy - sy); y < std::min(H, cy + sy); ++y)
+      for (int x = std::max(0, cx - sx); x < std::min(W, cx + sx); ++x) {
+        if (ell) {
+          const float dx = (float)(x - cx) / sx, dy = (float)(y - cy) / sy;
+          if (dx * dx + dy * dy >= 1.f) continue;
+        }
+        for (int c = 0; c < 3; ++c) f[((size_t)y * W + x) * 3 + c] = col[c];
+      }
+  }
+  for (auto& v : f) v = (uint8_t)std::min(255, std::max(0, (int)v + (int)(rnd() % 13u) - 6));
+}
+
+int rtd_self_check(rtd_handle h, rtd_check_report* out) {
+  return guarded(h, [&] {
+    RTD_CHECK(out && out->struct_size == (int32_t)sizeof(rtd_check_report), RTD_E_INVALID, "rtd_check_report.struct_size mismatch");
+    RTD_CHECK(h->loaded && !h->blob.empty(), RTD_E_STATE, "weights not loaded");
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    const int H = h->cfg.input_h, W = h->cfg.input_w, Q = h->cfg.num_queries;
+    std::vector<uint8_t> frame;
+    check_frame(H, W, frame);
+    const uint8_t* fp = frame.data();
+    const int32_t hw[2] = {H, W};
+    struct Rows { std::vector<int32_t> l; std::vector<float> b, s; };
+    int64_t saturated = 0;
+    auto run = [&](int precision, bool scan, Rows& r) {
+      rtd_config c = h->cfg;
+      c.precision = precision; c.max_batch = 1; c.use_graph = 0;
+      rtd_handle t = nullptr;
+      RTD_CHECK(rtd_create(&c, &t) == RTD_OK, RTD_E_HIP, "self check: rtd_create failed: " + std::string(rtd_last_error(nullptr)));
+      t->opts.arena_reuse = scan ? 0 : t->opts.arena_reuse;      // every activation keeps its own buffer until the scan
+      t->opts.side_stream = 0;
+      int rc = rtd_load_weights(t, h->blob.data(), h->blob.size());
+      r.l.resize(Q); r.b.resize((size_t)Q * 4); r.s.resize(Q);
+      if (rc == RTD_OK) rc = rtd_infer_raw(t, 1, &fp, hw, 0, r.l.data(), r.b.data(), r.s.data());
+      std::string msg = rc == RTD_OK ? "" : std::string(rtd_last_error(t));
+      if (rc == RTD_OK && scan) {
+        unsigned long long* cnt = nullptr;
+        hipError_t er = hipMalloc((void**)&cnt, 8);
+        if (er == hipSuccess) er = hipMemsetAsync(cnt, 0, 8, t->stream);
+        if (er == hipSuccess) {
+          for (const auto& a : t->plans[1]->split_acts) launch_count_saturated(a.first, (int64_t)(a.second / 2), cnt, t->stream);
+          unsigned long long v = 0;
+          er = hipMemcpyAsync(&v, cnt, 8, hipMemcpyDeviceToHost, t->stream);
+          if (er == hipSuccess) er = hipStreamSynchronize(t->stream);
+          saturated = (int64_t)v;
+        }
+        if (cnt) (void)hipFree(cnt);
+        if (er != hipSuccess) { rc = RTD_E_HIP; msg = hipGetErrorString(er); }
+      }
+      rtd_destroy(t);
+      RTD_CHECK(rc == RTD_OK, rc, "self check (" + std::string(precision == RTD_PREC_FP32 ? "fp32" : "subject") + " engine): " + msg);
+    };
+    Rows ref, got;
+    run(RTD_PREC_FP32, false, ref);
+    run(h->cfg.precision, h->cfg.precision == RTD_PREC_F16X3, got);
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    const float stol = 1e-3f, btol = 1e-2f;
+    std::vector<char> used(Q, 0);
+    int matched = 0;
+    float ws = 0.f, wb = 0.f;
+    for (int i = 0; i < Q; ++i) {
+      int best = -1;
+      float bd = 0.f;
+      for (int j = 0; j < Q; ++j) {
+        if (used[j] || got.l[j] != ref.l[i] || fabsf(got.s[j] - ref.s[i]) > stol) continue;
+        float d = 0.f;
+        for (int k = 0; k < 4; ++k) d = std::max(d, fabsf(got.b[(size_t)j * 4 + k] - ref.b[(size_t)i * 4 + k]));
+        if (best < 0 || d < bd) { best = j; bd = d; }
+      }
+      if (best >= 0 && bd <= btol) {
+        used[best] = 1; ++matched;
+        ws = std::max(ws, fabsf(got.s[best] - ref.s[i])); wb = std::max(wb, bd);
+      }
+    }
+    bool finite = true;
+    for (int i = 0; i < Q; ++i) finite = finite && std::isfinite(got.s[i]) && std::isfinite(got.b[(size_t)i * 4]);
+    memset(out, 0, sizeof *out);
+    out->struct_size = (int32_t)sizeof(rtd_check_report);
+    out->rows = Q; out->rows_matched = finite ? matched : 0;
+    out->worst_score_err = ws; out->worst_box_err_px = wb;
+    out->score_tol = stol; out->box_tol_px = btol;
+    out->saturated_values = saturated;
+    out->max_abs_filter = h->max_abs_filter;
+    strncpy(out->max_abs_filter_name, h->max_abs_filter_name.c_str(), sizeof(out->max_abs_filter_name) - 1);
+    h->st_saturated = saturated;
+  });
+}
+
 int rtd_get_stats(rtd_handle h, rtd_stats* out) {
   if (!h || !out) return RTD_E_INVALID;
   std::lock_guard<std::mutex> lk(h->mu);
@@ -1546,6 +1682,8 @@ int rtd_get_stats(rtd_handle h, rtd_stats* out) {
   out->eager_passes = h->st_eager; out->submits = h->st_submits; out->collects = h->st_collects; out->failed_calls = h->st_failed;
   out->last_error_code = h->st_last_code;
   out->in_flight = h->in_flight ? 1 : 0;
+  out->saturated_values = h->st_saturated;
+  out->max_abs_filter = h->max_abs_filter;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (h->stream && hipStreamIsCapturing(h->stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusInvalidated; }
   out->stream_capture_status = (int32_t)cs;

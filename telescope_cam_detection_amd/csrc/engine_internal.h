@@ -82,6 +82,7 @@ struct Plan {
   Tensor input;            // [n,H,W,8]
   const uint8_t** frame_table = nullptr;   // fused uint8 stem: device table of the n frame pointers of the current call
   bool stem_fused = false;
+  std::vector<std::pair<void*, size_t>> split_acts;   // every F16X2 activation the builder allocated (pointer, bytes): rtd_self_check's saturation scan
   float* block6 = nullptr; // [n,Q,6]
   float* scale_wh = nullptr;
   int32_t* tk_idx = nullptr;
@@ -119,6 +120,8 @@ struct rtd_engine {
   // counters (rtd_get_stats): what this handle did, so that a failure report describes itself
   int64_t st_plans = 0, st_graphs = 0, st_graph_nodes = 0, st_graph_launches = 0, st_eager = 0, st_submits = 0, st_collects = 0, st_failed = 0;
   int32_t st_last_code = 0;
+  // real-weights guard: the largest |folded filter value| of the blob (rtd_load_weights) and the saturated activations the last rtd_self_check saw
+  float max_abs_filter = 0.f; std::string max_abs_filter_name; int64_t st_saturated = -1;
   bool in_flight = false;                          // rtd_infer_async enqueued a batch that rtd_collect / rtd_sync has not waited for yet
   uint8_t* pin_stage = nullptr; size_t pin_stage_bytes = 0;    // rtd_infer_async on host frames: pinned staging (one batch in flight per handle)
   int P = BF16;  // storage / MFMA type of the conv trunk

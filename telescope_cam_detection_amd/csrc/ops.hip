@@ -4,6 +4,8 @@
 // NHWC channel dimension, fp32 arithmetic regardless of the storage type, no MFMA reshaping.
 #include <float.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace rtd {
@@ -76,6 +78,23 @@ void launch_split_to_f32(const void* src, int64_t lds_, float* dst, int64_t ldd,
   if (rows == 0) return;
   RTD_CHECK(C % SPLIT_GROUP == 0 && lds_ % SPLIT_GROUP == 0 && ldd % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, 1, "split -> f32: 32-channel groups, 16-byte rows");
   rtd_launch(k_split_to_f32, dim3(blocks_for(rows * (C / 8), 256)), dim3(256), 0, s, (const sp16*)src, lds_, dst, ldd, rows, C);
+  HIP_CHECK(hipGetLastError());
+}
+
+// Real-weights guard (rtd_self_check): how many hi halves of an F16X2 buffer sit at the format's saturation value +-65504 (0x7BFF: split2
+// clamps there instead of producing inf).  A legitimate activation of exactly 65504 is as good as impossible, so a non-zero count says the
+// checkpoint drives this engine outside its range.  `n16` 16-bit words, groups of [32 hi | 32 lo].
+__global__ void k_count_saturated(const unsigned short* __restrict__ p, int64_t n16, unsigned long long* __restrict__ count) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  unsigned c = 0;
+  for (; i < n16; i += step)
+    if ((i & 63) < 32 && (p[i] & 0x7FFFu) == 0x7BFFu) ++c;
+  if (c) atomicAdd(count, (unsigned long long)c);
+}
+void launch_count_saturated(const void* split_buf, int64_t n16, unsigned long long* count_dev, hipStream_t s) {
+  if (n16 <= 0) return;
+  rtd_launch(k_count_saturated, dim3(std::min<unsigned>(blocks_for(n16, 256), 4096u)), dim3(256), 0, s, (const unsigned short*)split_buf, n16, count_dev);
   HIP_CHECK(hipGetLastError());
 }
 

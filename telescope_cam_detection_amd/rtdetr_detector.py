@@ -112,11 +112,23 @@ class RTDETRDetector:
         self.postprocessor = None
         self.transforms = None
         self.arch: Optional[Arch] = None
+        self.last_check: Optional[dict] = None    # report of the load-time self check (load_model(verify=True))
 
     # ------------------------------------------------------------------ load
-    def load_model(self, max_retries: int = 3) -> bool:
+    # a checkpoint passes the load-time self check when at least this share of the fp32 engine's rows is matched within 1e-3 / 1e-2 px;
+    # near-ties at the two top-k cuts may cost single rows on any engine (tests/test_gpu_parity.py x3_check), a checkpoint outside the
+    # pair format's range costs most of them
+    VERIFY_MIN_MATCH = 0.97
+
+    def load_model(self, max_retries: int = 3, verify: bool = True) -> bool:
         """Build the device engine.  Contract of src/rtdetr_detector.py:60-204: never raises, True / False; transient failures
-        (I/O, runtime errors) are retried with a doubling pause (1 s, 2 s, 4 s ...), anything else fails at once."""
+        (I/O, runtime errors) are retried with a doubling pause (1 s, 2 s, 4 s ...), anything else fails at once.
+
+        `verify` (build-specific, default on; the default "f16x3" precision only): the real-weights guard.  The library already refuses
+        a blob with NaN / Inf or with a folded filter beyond the fp16 pair format's range (RTD_E_WEIGHTS); here one built-in frame runs
+        through the library's exact fp32 engine and through this engine's arithmetic with THESE weights (rtd_self_check) - the report is
+        logged, and a checkpoint whose rows do not agree within the reference tolerance is refused (False) instead of serving finite,
+        plausible, wrong boxes.  `self.last_check` keeps the report."""
         try:
             dev = _device_index(self.device)
         except ValueError as e:
@@ -133,6 +145,9 @@ class RTDETRDetector:
                                       input_size=tuple(self.input_size), use_graph=self.use_graph,
                                       profile=_capi.PROFILE_THROUGHPUT if str(self.profile).lower() == "throughput" else _capi.PROFILE_LATENCY)
                 try:
+                    if verify and str(self.precision).lower() == "f16x3" and not self._verified(engine):
+                        engine.close()
+                        return False
                     self._prepare(engine)
                 except BaseException:
                     engine.close()                            # a retry must not find this attempt's weights, arenas and graphs still resident
@@ -158,6 +173,24 @@ class RTDETRDetector:
                         self.conf_threshold)
             return True
         return False
+
+    def _verified(self, engine) -> bool:
+        rep = engine.self_check()
+        self.last_check = rep
+        share = rep["rows_matched"] / max(1, rep["rows"])
+        line = ("%d of %d rows of the fp32 engine matched within %.0e / %.0e px (worst %.1e / %.1e px), %d activations at the fp16 pair "
+                "format's saturation value, largest folded filter value %.3g (%s)")
+        args = (rep["rows_matched"], rep["rows"], rep["score_tol"], rep["box_tol_px"], rep["worst_score_err"], rep["worst_box_err_px"],
+                rep["saturated_values"], rep["max_abs_filter"], rep["max_abs_filter_name"])
+        if share < self.VERIFY_MIN_MATCH:
+            logger.error("RT-DETR (MI355X): %s FAILS the load-time self check: " + line + ".  The f16x3 engine is not valid for these weights; "
+                         "use precision='fp32'.", self.model_path, *args)
+            return False
+        if share < 1.0 or rep["saturated_values"] > 0:
+            logger.warning("RT-DETR (MI355X): load-time self check of %s: " + line, self.model_path, *args)
+        else:
+            logger.info("RT-DETR (MI355X): load-time self check of %s: " + line, self.model_path, *args)
+        return True
 
     def _prepare(self, engine) -> None:
         """Plan, arena and hipGraph of every declared batch size, now - the serving path then only replays.  A size whose arena does not

@@ -1,0 +1,120 @@
+"""Real-weights guard: every parity claim was measured on seeded synthetic weights, and the pair engine's fp16 halves
+saturate silently at +-65504.  A checkpoint that leaves the format's range must be EITHER handled correctly OR refused loudly - never served
+as finite, plausible, wrong boxes.  (/root/reference/src/rtdetr_detector.py:132-173: "model ready after load_model".)"""
+import logging
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SIZE = (160, 224)
+
+
+def _detector(tmp_path, w, name, precision="f16x3", arch_name="tinyc"):
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.rtdetr_detector import RTDETRDetector
+    from telescope_cam_detection_amd.weights import save_weights
+    path = str(tmp_path / f"{name}.pth")
+    save_weights(path, ARCHS[arch_name], w)
+    return RTDETRDetector(config_path=arch_name, model_path=path, device="cuda:0", conf_threshold=0.0, input_size=SIZE, wildlife_only=False,
+                          precision=precision, max_batch=2)
+
+
+def _weights(seed=3):
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.weights import synth_weights
+    return {k: v.clone() for k, v in synth_weights(ARCHS["tinyc"], seed).items()}
+
+
+def _agrees_with_oracle(det, w, min_share):
+    from oracle import rtdetr_oracle as orc
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.synth import scene_frame
+    from tests.util import match_detections
+    frame = scene_frame(77, 200, 260)
+    labels, boxes, scores = det.model.engine.infer_raw([frame])
+    x, wh = orc.preprocess(frame, SIZE)
+    ol, ob, osc = orc.model_forward(ARCHS["tinyc"], w, x, [wh])
+    m, n, ws, wb = match_detections(ol[0].numpy(), ob[0].numpy(), osc[0].numpy(), labels[0], boxes[0], scores[0], 1e-3, 1e-2)
+    return m >= min_share * n, (m, n, ws, wb)
+
+
+def test_ordinary_weights_pass_the_self_check_with_every_row(tmp_path):
+    w = _weights()
+    det = _detector(tmp_path, w, "ordinary")
+    assert det.load_model(max_retries=1) is True
+    rep = det.last_check
+    assert rep["rows"] == 50 and rep["rows_matched"] == rep["rows"] and rep["saturated_values"] == 0, rep
+    assert rep["worst_score_err"] <= 1e-3 and rep["worst_box_err_px"] <= 1e-2 and 0 < rep["max_abs_filter"] < 65504 and rep["max_abs_filter_name"].endswith(".w")
+    st = det.model.engine.stats()
+    assert st["saturated_values"] == -1 and abs(st["max_abs_filter"] - rep["max_abs_filter"]) < 1e-6      # the serving handle itself was not checked: temporaries were
+    again = det.model.engine.self_check()
+    assert again == rep and det.model.engine.stats()["saturated_values"] == 0
+    # the guard can be switched off (and does not run for the other precisions)
+    det2 = _detector(tmp_path, w, "ordinary2")
+    assert det2.load_model(max_retries=1, verify=False) is True and det2.last_check is None
+    det3 = _detector(tmp_path, w, "ordinary3", precision="fp32")
+    assert det3.load_model(max_retries=1) is True and det3.last_check is None
+
+
+def test_collapsed_running_var_is_correct_or_loud(tmp_path, caplog):
+    """The verdict's case: BN running_var 1e-6 on one stage-2 channel (the folded filter row grows ~300-fold).  Whatever the engine does with
+    it - the test accepts both outcomes - a loaded detector must agree with the oracle, and a refused one must have said why."""
+    w = _weights()
+    w["backbone.s2.b0.c1.bn.v"][5] = 1e-6
+    det = _detector(tmp_path, w, "collapsed_var")
+    with caplog.at_level(logging.ERROR):
+        ok = det.load_model(max_retries=1)
+    if ok:
+        good, detail = _agrees_with_oracle(det, w, 0.97)
+        assert good, detail
+        assert det.last_check["rows_matched"] >= 0.97 * det.last_check["rows"]
+    else:
+        assert "self check" in caplog.text or "beyond the fp16 pair format" in caplog.text
+        assert det.model is None and det.detect(np.zeros((64, 64, 3), np.uint8)) == []
+
+
+def test_saturating_checkpoint_is_refused_by_the_pair_engine_and_served_by_fp32(tmp_path, caplog):
+    """The same channel with a trained-looking gamma of 400 on top: its activations leave the fp16 range.  The f16x3 engine must refuse the
+    checkpoint at load time (self check: rows do not match, saturated activations counted); the fp32 engine serves it and agrees with the oracle."""
+    w = _weights()
+    w["backbone.s2.b0.c1.bn.v"][5] = 1e-6
+    w["backbone.s2.b0.c1.bn.g"][5] = 400.0
+    det = _detector(tmp_path, w, "saturating")
+    with caplog.at_level(logging.ERROR):
+        assert det.load_model(max_retries=1) is False
+    assert "FAILS the load-time self check" in caplog.text and det.model is None
+    rep = det.last_check
+    assert rep["saturated_values"] > 0 and rep["rows_matched"] < 0.97 * rep["rows"], rep
+    assert 65504 > rep["max_abs_filter"] > 1000 and "s2.b0.c1" in rep["max_abs_filter_name"]
+    ref = _detector(tmp_path, w, "saturating_fp32", precision="fp32")
+    assert ref.load_model(max_retries=1) is True
+    good, detail = _agrees_with_oracle(ref, w, 0.97)
+    assert good, detail
+
+
+def test_filter_beyond_the_fp16_range_and_non_finite_tensors_are_refused_at_load(tmp_path, caplog):
+    from telescope_cam_detection_amd import _capi
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.weights import fold_weights, pack_blob
+    w = _weights()
+    w["backbone.s1.b0.c2.bn.g"][2] = 3.0e6                                 # folded filter row ~ 1e5 .. 1e6
+    blob = pack_blob(fold_weights(ARCHS["tinyc"], w))
+    with pytest.raises(_capi.RtdError) as ei:
+        _capi.Engine(ARCHS["tinyc"], blob, device=0, precision=_capi.PREC_F16X3, max_batch=1, input_size=SIZE)
+    assert ei.value.code == _capi.RTD_E_WEIGHTS and "beyond the fp16 pair format" in str(ei.value) and "s1.b0.c2" in str(ei.value)
+    e32 = _capi.Engine(ARCHS["tinyc"], blob, device=0, precision=_capi.PREC_FP32, max_batch=1, input_size=SIZE)    # fp32 takes it
+    e32.close()
+    det = _detector(tmp_path, w, "huge_gamma")
+    with caplog.at_level(logging.ERROR):
+        assert det.load_model(max_retries=1) is False
+    assert "beyond the fp16 pair format" in caplog.text
+    w = _weights()
+    w["enc.lat.0.conv.w"].view(-1)[7] = float("inf")
+    blob = pack_blob(fold_weights(ARCHS["tinyc"], w))
+    for prec in (_capi.PREC_F16X3, _capi.PREC_FP32):
+        with pytest.raises(_capi.RtdError) as ei:
+            _capi.Engine(ARCHS["tinyc"], blob, device=0, precision=prec, max_batch=1, input_size=SIZE)
+        assert ei.value.code == _capi.RTD_E_WEIGHTS and "NaN or an infinity" in str(ei.value)
