@@ -157,7 +157,7 @@ int rtd_get_stats(rtd_handle h, rtd_stats* out);
  *  (1) rtd_load_weights returns RTD_E_WEIGHTS for a tensor that holds NaN / Inf and - RTD_PREC_F16X3 - for a folded filter value
  *      beyond 65504 (rtd_last_error names the tensor);
  *  (2) rtd_self_check runs ONE built-in frame of the handle's input size through the library's exact fp32 engine and through an engine of
- *      the handle's precision, both built from the handle's own weights, counts the activations that sit at the saturation value and
+ *      the handle's precision, both built from the blob the handle was loaded with, counts the activations that sit at the saturation value and
  *      matches the detection rows (same label, |dscore| <= score_tol = 1e-3, max |dbox| <= box_tol_px = 1e-2, the reference tolerance).
  *      The caller decides: RTDETRDetector.load_model(verify=True) logs the report and refuses a checkpoint whose rows do not match.
  *      Costs two temporary bs-1 engines (a second or two at load time); the handle itself is not touched. */
@@ -170,7 +170,7 @@ typedef struct rtd_check_report {
   int64_t saturated_values;        /* F16X2 activations at +-65504 after that forward (0 for the other precisions) */
   char max_abs_filter_name[64];
 } rtd_check_report;
-int rtd_self_check(rtd_handle h, rtd_check_report* out);
+int rtd_self_check(rtd_handle h, const void* blob, size_t nbytes, rtd_check_report* out);   /* blob: the one given to rtd_load_weights (the handle keeps no host copy) */
 
 /* mutable attribute `model.to(device)` / teardown (src/inference_engine_yolox.py:743-744) */
 void rtd_destroy(rtd_handle h);

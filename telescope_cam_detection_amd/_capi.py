@@ -153,7 +153,7 @@ def lib() -> C.CDLL:
     L.rtd_wait_stream.argtypes = [vp, vp]
     L.rtd_signal_stream.argtypes = [vp, vp]
     L.rtd_get_stats.argtypes = [vp, C.POINTER(RtdStats)]
-    L.rtd_self_check.argtypes = [vp, C.POINTER(RtdCheckReport)]
+    L.rtd_self_check.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(RtdCheckReport)]
     L.rtd_self_check.restype = C.c_int
     L.rtd_result_block.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.rtd_sync.argtypes = [vp]
@@ -365,11 +365,12 @@ class Engine:
     def stats(self) -> dict:
         return _stats_of(self._h)
 
-    def self_check(self) -> dict:
-        """rtd_self_check: this engine's arithmetic against the library's exact fp32 engine on one built-in frame, with THESE weights."""
+    def self_check(self, blob: bytes) -> dict:
+        """rtd_self_check: this engine's arithmetic against the library's exact fp32 engine on one built-in frame, with the weights of
+        `blob` (the container this engine was loaded from: the handle keeps no host copy)."""
         rep = RtdCheckReport()
         rep.struct_size = C.sizeof(RtdCheckReport)
-        rc = lib().rtd_self_check(self._h, C.byref(rep))
+        rc = lib().rtd_self_check(self._h, blob, len(blob), C.byref(rep))
         if rc != RTD_OK:
             _raise(rc, self._h)
         return {"rows": rep.rows, "rows_matched": rep.rows_matched, "worst_score_err": rep.worst_score_err, "worst_box_err_px": rep.worst_box_err_px,

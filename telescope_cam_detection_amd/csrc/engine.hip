@@ -1597,10 +1597,11 @@ static void check_frame(int H, int W, std::vector<uint8_t>& f) {
   for (auto& v : f) v = (uint8_t)std::min(255, std::max(0, (int)v + (int)(rnd() % 13u) - 6));
 }
 
-int rtd_self_check(rtd_handle h, rtd_check_report* out) {
+int rtd_self_check(rtd_handle h, const void* blob, size_t nbytes, rtd_check_report* out) {
   return guarded(h, [&] {
     RTD_CHECK(out && out->struct_size == (int32_t)sizeof(rtd_check_report), RTD_E_INVALID, "rtd_check_report.struct_size mismatch");
-    RTD_CHECK(h->loaded && !h->blob.empty(), RTD_E_STATE, "weights not loaded");
+    RTD_CHECK(h->loaded, RTD_E_STATE, "weights not loaded");
+    RTD_CHECK(blob && nbytes >= 12, RTD_E_WEIGHTS, "self check: the weight blob given to rtd_load_weights is needed again (the handle does not keep its host copy)");
     HIP_CHECK(hipSetDevice(h->cfg.device));
     const int H = h->cfg.input_h, W = h->cfg.input_w, Q = h->cfg.num_queries;
     std::vector<uint8_t> frame;
@@ -1616,7 +1617,7 @@ int rtd_self_check(rtd_handle h, rtd_check_report* out) {
       RTD_CHECK(rtd_create(&c, &t) == RTD_OK, RTD_E_HIP, "self check: rtd_create failed: " + std::string(rtd_last_error(nullptr)));
       t->opts.arena_reuse = scan ? 0 : t->opts.arena_reuse;      // every activation keeps its own buffer until the scan
       t->opts.side_stream = 0;
-      int rc = rtd_load_weights(t, h->blob.data(), h->blob.size());
+      int rc = rtd_load_weights(t, blob, nbytes);
       r.l.resize(Q); r.b.resize((size_t)Q * 4); r.s.resize(Q);
       if (rc == RTD_OK) rc = rtd_infer_raw(t, 1, &fp, hw, 0, r.l.data(), r.b.data(), r.s.data());
       std::string msg = rc == RTD_OK ? "" : std::string(rtd_last_error(t));

@@ -145,7 +145,7 @@ class RTDETRDetector:
                                       input_size=tuple(self.input_size), use_graph=self.use_graph,
                                       profile=_capi.PROFILE_THROUGHPUT if str(self.profile).lower() == "throughput" else _capi.PROFILE_LATENCY)
                 try:
-                    if verify and str(self.precision).lower() == "f16x3" and not self._verified(engine):
+                    if verify and str(self.precision).lower() == "f16x3" and not self._verified(engine, blob):
                         engine.close()
                         return False
                     self._prepare(engine)
@@ -174,8 +174,8 @@ class RTDETRDetector:
             return True
         return False
 
-    def _verified(self, engine) -> bool:
-        rep = engine.self_check()
+    def _verified(self, engine, blob) -> bool:
+        rep = engine.self_check(blob)
         self.last_check = rep
         share = rep["rows_matched"] / max(1, rep["rows"])
         line = ("%d of %d rows of the fp32 engine matched within %.0e / %.0e px (worst %.1e / %.1e px), %d activations at the fp16 pair "

@@ -49,12 +49,15 @@ def test_ordinary_weights_pass_the_self_check_with_every_row(tmp_path):
     assert rep["rows"] == 50 and rep["rows_matched"] == rep["rows"] and rep["saturated_values"] == 0, rep
     assert rep["worst_score_err"] <= 1e-3 and rep["worst_box_err_px"] <= 1e-2 and 0 < rep["max_abs_filter"] < 65504 and rep["max_abs_filter_name"].endswith(".w")
     st = det.model.engine.stats()
-    assert st["saturated_values"] == -1 and abs(st["max_abs_filter"] - rep["max_abs_filter"]) < 1e-6      # the serving handle itself was not checked: temporaries were
-    again = det.model.engine.self_check()
+    assert st["saturated_values"] == 0 and abs(st["max_abs_filter"] - rep["max_abs_filter"]) < 1e-6      # the handle remembers its last check
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.weights import fold_weights, pack_blob
+    again = det.model.engine.self_check(pack_blob(fold_weights(ARCHS["tinyc"], w)))
     assert again == rep and det.model.engine.stats()["saturated_values"] == 0
+    assert det.model.engine.stats()["failed_calls"] == 0 and det.model.engine.stats()["plans"] >= 1       # the check ran on temporaries: this handle's plans are its own
     # the guard can be switched off (and does not run for the other precisions)
     det2 = _detector(tmp_path, w, "ordinary2")
-    assert det2.load_model(max_retries=1, verify=False) is True and det2.last_check is None
+    assert det2.load_model(max_retries=1, verify=False) is True and det2.last_check is None and det2.model.engine.stats()["saturated_values"] == -1
     det3 = _detector(tmp_path, w, "ordinary3", precision="fp32")
     assert det3.load_model(max_retries=1) is True and det3.last_check is None
 
@@ -64,6 +67,7 @@ def test_collapsed_running_var_is_correct_or_loud(tmp_path, caplog):
     it - the test accepts both outcomes - a loaded detector must agree with the oracle, and a refused one must have said why."""
     w = _weights()
     w["backbone.s2.b0.c1.bn.v"][5] = 1e-6
+    w["backbone.s2.b0.c1.bn.m"][5] = -1.0                       # the channel's pre-activation is positive everywhere: it survives the ReLU
     det = _detector(tmp_path, w, "collapsed_var")
     with caplog.at_level(logging.ERROR):
         ok = det.load_model(max_retries=1)
@@ -81,7 +85,8 @@ def test_saturating_checkpoint_is_refused_by_the_pair_engine_and_served_by_fp32(
     checkpoint at load time (self check: rows do not match, saturated activations counted); the fp32 engine serves it and agrees with the oracle."""
     w = _weights()
     w["backbone.s2.b0.c1.bn.v"][5] = 1e-6
-    w["backbone.s2.b0.c1.bn.g"][5] = 400.0
+    w["backbone.s2.b0.c1.bn.m"][5] = -1.0
+    w["backbone.s2.b0.c1.bn.g"][5] = 400.0                      # x 301 from the collapsed variance: the channel's activations reach 1e5 (tools/guard_probe.py)
     det = _detector(tmp_path, w, "saturating")
     with caplog.at_level(logging.ERROR):
         assert det.load_model(max_retries=1) is False
