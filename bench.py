@@ -197,8 +197,9 @@ def main():
     arch = ARCHS[args.arch]
     B, H = args.batch, args.size
     Q = arch.num_queries
-    w = synth_weights(arch, 0)
-    blob = pack_blob(fold_weights(arch, w))
+    # the packed blob through the on-disk cache: the N ranks of a node fold the 43 M parameters once, not once each (weights.cached_blob)
+    from telescope_cam_detection_amd.weights import cached_blob
+    blob = cached_blob(arch, f"synthetic:{arch.name}:0", lambda: synth_weights(arch, 0))
 
     def fence(engs):
         for e in engs:

@@ -184,6 +184,10 @@ struct ConvArgs {
   // optional (streaming pair kernel, a stage's last expand conv): the 2 x 2 / stride-2 average of y, [B, OH / 2, OW / 2, N] F16X2, written by
   // the same launch (the next stage's vd-shortcut input); see conv_avg_supported()
   Tensor avg_y;
+  // optional (streaming pair kernel only; every other kernel ignores it and writes y): nothing reads y after this launch - its consumers
+  // are the fused following conv (next_y, from the tile in LDS) and the fused 2 x 2 average (avg_y): the stores of y are dropped
+  // (buffer descriptor of zero bytes).  A bottleneck net's stage-0 output at the stage-1 boundary: 210 MB per R50 bs-8 step.
+  int y_dead = 0;
   int prefer256 = 0;   // throughput profile (rtd_config.profile): take the 256-pixel tile from 100 blocks on (bf16 / fp32 operands)
   const ConvOpts* opts = nullptr;   // the handle's snapshot of the dispatch switches; nullptr = the process-wide template
   Tensor y;            // output [B,OH,OW,N] (view)

@@ -2397,7 +2397,9 @@ static bool dispatch_sx(const ConvK& k, const ConvArgs& a, long long x_bytes, lo
                                                      (unsigned)y_bytes, (unsigned)x2_bytes, (int)ntiles, (unsigned)yn_bytes, ny, ao)
   const int nx = next ? a.next_y.c : 0;
   if (avg) {
-    if (a.x.c == 64) rtd_launch((conv1x1_sx_kernel<2, 0, true, 128, false, true>), grid, blk, 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes,
+    // ConvArgs::y_dead: y's only readers are the two fused consumers of this very launch - a zero-byte descriptor drops its stores
+    const unsigned yb = (a.y_dead && next) ? 0u : (unsigned)y_bytes;
+    if (a.x.c == 64) rtd_launch((conv1x1_sx_kernel<2, 0, true, 128, false, true>), grid, blk, 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, yb,
                                         (unsigned)x2_bytes, (int)ntiles, (unsigned)yn_bytes, ny, ao);
     else rtd_launch((conv1x1_sx_kernel<4, 0, true, 0, false, true>), grid, blk, 0, s, k, (unsigned)x_bytes, (unsigned)r_bytes, (unsigned)y_bytes,
                             (unsigned)x2_bytes, (int)ntiles, (unsigned)yn_bytes, ny, ao);

@@ -411,12 +411,14 @@ struct Builder {
     a.opts = &e->conv_opts;
     a.prefer256 = e->cfg.profile == RTD_PROFILE_THROUGHPUT;
     if (avg_pending) { a.avg_y = avg_pending_y; if (dry) a.avg_y.p = nullptr; avg_pending = false; }
+    if (y_dead_pending) { a.y_dead = (a.avg_y.c && next_y) ? 1 : 0; y_dead_pending = false; }
     slab_need[lane] = std::max(slab_need[lane], conv_split_slab_bytes(a));
     const double M = (double)y.pixels();
     const double kreal = (double)k * k * (real_cin ? real_cin : x.c) + (x2 ? x2->c : 0);
     const double flops = 2.0 * M * y.c * kreal + (next_y ? 2.0 * M * y.c * next_y->c : 0.0);
     const double bytes = (double)x.pixels() * x.c * dtype_size(x.dt) + tbytes(y) + (double)y.c * K * dtype_size(x.dt) +
-                         (res ? tbytes(*res) : 0.0) + (x2 ? tbytes(*x2) : 0.0) + (next_y ? tbytes(*next_y) : 0.0) + (a.avg_y.c ? tbytes(a.avg_y) : 0.0);
+                         (res ? tbytes(*res) : 0.0) + (x2 ? tbytes(*x2) : 0.0) + (next_y ? tbytes(*next_y) : 0.0) + (a.avg_y.c ? tbytes(a.avg_y) : 0.0) -
+                         (a.y_dead ? tbytes(y) : 0.0);
     auto ap = std::make_shared<ConvArgs>(a);
     if (!dry) {
       // chain: the previous conv launch of the plan prefetches THIS filter while it runs (ConvArgs::pf)
@@ -429,6 +431,7 @@ struct Builder {
   // set by the plan builder right before the conv that should also write the 2 x 2 average of its output (ConvArgs::avg_y); consumed by conv()
   bool avg_pending = false;
   Tensor avg_pending_y;
+  bool y_dead_pending = false;   // the next conv's output has no reader outside that launch (see ConvArgs::y_dead)
   std::shared_ptr<ConvArgs> last_conv;
   // two-pass split-K workspace of this plan: sized for the plan's own batch (the slice count depends on per-image extents only, so every
   // batch size up to max_batch runs the same arithmetic), allocated once every conv is known.  ONE SLAB PER LANE: launches of a lane are
@@ -682,6 +685,10 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
             prepooled = B.act(P, n, oh / 2, ow / 2, cout);
             have_prepooled = true;
             B.avg_pending = true; B.avg_pending_y = prepooled;
+            // `out` is then read by nobody but this launch's own fused consumers when (a) the next stage's first reduce conv rides on it
+            // (nx: stage 1's block 0 reads its c1 input from the tile) and (b) the stage output is not an encoder feature (stage 0):
+            // block 0 of the next stage takes its residual from the shortcut conv over the fused average, never from `out`
+            if (e->opts.dead_out && nx && si == 0 && oname.empty()) B.y_dead_pending = true;
           }
         }
         if (fold_sc) B.conv(pfx + ".c3", t2, out, 1, 1, 0, ACT_RELU, nullptr, RES_NONE, 0, &sc_in, pfx + ".sc", 0, nx, nx_name, ACT_RELU);

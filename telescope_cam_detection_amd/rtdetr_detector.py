@@ -138,9 +138,7 @@ class RTDETRDetector:
         for k in range(tries):
             t0 = time.perf_counter()
             try:
-                state, arch_name = load_state(self.model_path)
-                arch = ARCHS[arch_name] if arch_name else arch_from_config_path(self.config_path)
-                blob = pack_blob(fold_weights(arch, state))
+                blob, arch = self._blob()
                 engine = _capi.Engine(arch, blob, device=dev, precision=_capi.precision_code(self.precision), max_batch=self.max_batch,
                                       input_size=tuple(self.input_size), use_graph=self.use_graph,
                                       profile=_capi.PROFILE_THROUGHPUT if str(self.profile).lower() == "throughput" else _capi.PROFILE_LATENCY)
@@ -173,6 +171,37 @@ class RTDETRDetector:
                         self.conf_threshold)
             return True
         return False
+
+    def _blob(self):
+        """(packed weight blob, Arch) for `model_path`: through the on-disk blob cache (weights.cached_blob) when the variant is known
+        without reading the file - `synthetic:<arch>:<seed>`, or a config_path that names it - so that the ranks of a node fold a
+        checkpoint once, not once each."""
+        from .weights import cached_blob
+        mp = str(self.model_path)
+        arch = None
+        if mp.startswith("synthetic:"):
+            arch = ARCHS[mp.split(":")[1]]
+        else:
+            try:
+                arch = arch_from_config_path(self.config_path)
+            except ValueError:
+                arch = None
+        if arch is None:
+            state, arch_name = load_state(self.model_path)
+            return pack_blob(fold_weights(ARCHS[arch_name], state)), ARCHS[arch_name]
+
+        other = {}
+
+        def make_state():
+            state, arch_name = load_state(self.model_path)
+            if arch_name and arch_name != arch.name:          # the file knows better than the config's name (the precedence this class always had)
+                other["state"], other["arch"] = state, ARCHS[arch_name]
+                raise LookupError(arch_name)
+            return state
+        try:
+            return cached_blob(arch, mp, make_state), arch
+        except LookupError:
+            return pack_blob(fold_weights(other["arch"], other["state"])), other["arch"]
 
     def _verified(self, engine, blob) -> bool:
         rep = engine.self_check(blob)

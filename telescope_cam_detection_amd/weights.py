@@ -358,3 +358,58 @@ def unpack_blob(blob: bytes) -> Dict[str, np.ndarray]:
 def save_weights(path: str, arch: Arch, w: Dict[str, torch.Tensor]) -> None:
     """Write a model file this build's `RTDETRDetector.load_model` accepts (un-fused tensors)."""
     torch.save({"arch": arch.name, "model": w}, path)
+
+
+# --------------------------------------------------------------------------------------
+# Packed-blob cache.  One process per GPU means eight ranks of a node load the same checkpoint at the same moment (main.py:1236-1291: one
+# engine per camera); each would read the file, fold BN / RepVGG and pack ~170 MB.  The packed blob is therefore kept on disk, keyed by
+# what it was made from - variant, source (seed, or file path + size + mtime) and the text of this module (the folding rules) - written
+# once with an atomic rename and read back by the other ranks.  RTD_BLOB_CACHE names the directory ("" or "0" switches the cache off).
+# --------------------------------------------------------------------------------------
+def _cache_dir():
+    import os
+    d = os.environ.get("RTD_BLOB_CACHE")
+    if d is None:
+        d = os.path.join(os.environ.get("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache")), "telescope_cam_detection_amd", "blobs")
+    return None if d in ("", "0") else d
+
+
+def blob_cache_key(arch: Arch, source: str) -> str:
+    import hashlib
+    import os
+    ident = source
+    if not source.startswith("synthetic:") and os.path.exists(source):
+        st = os.stat(source)
+        ident = f"{os.path.abspath(source)}|{st.st_size}|{st.st_mtime_ns}"
+    with open(os.path.abspath(__file__), "rb") as f:
+        rules = hashlib.sha256(f.read()).hexdigest()[:16]
+    return hashlib.sha256(f"{arch.name}|{ident}|{rules}|v{BLOB_VERSION}".encode()).hexdigest()[:32]
+
+
+def cached_blob(arch: Arch, source: str, make_state) -> bytes:
+    """The packed blob for (`arch`, `source`): from the cache when present and intact, else `pack_blob(fold_weights(arch, make_state()))`,
+    stored for the next process.  Any cache trouble (read-only home, a torn file) falls back to building it: the cache is an optimisation."""
+    import os
+    import tempfile
+    d = _cache_dir()
+    path = os.path.join(d, blob_cache_key(arch, source) + ".rtdw") if d else None
+    if path and os.path.exists(path):
+        try:
+            with open(path, "rb") as f:
+                blob = f.read()
+            if blob[:4] == BLOB_MAGIC and len(blob) >= 12:
+                unpack_blob(blob)      # validates the table against the file's length (raises on a torn file)
+                return blob
+        except Exception:
+            pass
+    blob = pack_blob(fold_weights(arch, make_state()))
+    if path:
+        try:
+            os.makedirs(d, exist_ok=True)
+            fd, tmp = tempfile.mkstemp(dir=d, suffix=".tmp")
+            with os.fdopen(fd, "wb") as f:
+                f.write(blob)
+            os.replace(tmp, path)                                    # atomic: a concurrent reader sees the old state or the whole file
+        except OSError:
+            pass
+    return blob

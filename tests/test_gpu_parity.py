@@ -693,6 +693,40 @@ def test_f16x3_fused_vd_shortcut_average_equals_the_avgpool_launch(aname, size, 
         np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("aname,size,bs", [("r50", (640, 640), 3), ("r101", (320, 512), 2)])
+def test_f16x3_unwritten_stage0_output_changes_nothing(aname, size, bs):
+    """ConvArgs::y_dead (round 5): at the stage-0 / stage-1 boundary of a bottleneck net the stage-0 output's only readers - stage 1's first
+    reduce conv and the vd-shortcut average - are fused into the launch that produces it, so its stores are dropped (210 MB per R50 bs-8 step).
+    Against the plan that writes it: one launch list, backbone maps and final rows bit for bit, graph replay included."""
+    from telescope_cam_detection_amd import _capi
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.synth import noise_frame, scene_frame
+    from telescope_cam_detection_amd.weights import fold_weights, pack_blob, synth_weights
+
+    arch = ARCHS[aname]
+    blob = pack_blob(fold_weights(arch, synth_weights(arch, 6)))
+    frames = [noise_frame(60 + i, size[0], size[1]) if i % 2 else scene_frame(60 + i, size[0], size[1]) for i in range(bs)]
+    out, maps, nbytes, nops = {}, {}, {}, {}
+    for dead in (0, 1):
+        _capi.debug_option("dead_out", dead)
+        eng = _capi.Engine(arch, blob, 0, _capi.PREC_F16X3, bs, size, True)
+        for _ in range(3):
+            out[dead] = eng.infer_raw(frames)
+        maps[dead] = [eng.debug_tensor(f"backbone{i}") for i in range(3)]
+        prof = eng.profile(bs, 1)
+        nops[dead] = len(prof)
+        nbytes[dead] = sum(p["bytes"] for p in prof if p["name"] == f"backbone.s0.b{arch.depths[0] - 1}.c3")
+        eng.close()
+    _capi.debug_option("reset", 0)
+    assert nops[0] == nops[1]
+    h4, w4 = size[0] // 4, size[1] // 4
+    assert nbytes[0] - nbytes[1] == bs * h4 * w4 * 256 * 4                  # exactly the stage-0 output, 4 bytes per channel
+    for a, b in zip(maps[0], maps[1]):
+        np.testing.assert_array_equal(a, b)
+    for x, y in zip(out[0], out[1]):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_non_square_input_with_partial_tiles_bf16_and_fp32():
     """416 x 736 (multiples of 32, but 208 x 368 and 104 x 184 are not multiples of the 8 x 32 / 128-pixel tiles): every conv
     kernel family meets ragged tiles.  fp32 engine vs oracle at the north-star tolerance, bf16 engine vs fp32 engine to bf16 noise."""

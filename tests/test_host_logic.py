@@ -288,3 +288,33 @@ def test_the_library_never_captures_a_stream_and_the_package_never_wraps_its_str
                 assert call not in code, (f, call)
     common = open(os.path.join(root, "telescope_cam_detection_amd", "csrc", "common.h")).read()
     assert common.count("hipLaunchKernelGGL(") == 1 and "hipGraphAddKernelNode" in common
+
+
+def test_packed_blob_cache_is_keyed_by_source_and_survives_a_torn_file(tmp_path, monkeypatch):
+    """the ranks of a node fold a checkpoint once.  Same (variant, source) -> the cached bytes, bit for bit; another
+    seed or a touched file -> another key; a torn cache file is rebuilt, not trusted; RTD_BLOB_CACHE=0 switches the cache off."""
+    from telescope_cam_detection_amd import weights as W
+    monkeypatch.setenv("RTD_BLOB_CACHE", str(tmp_path))
+    arch = ARCHS["tiny"]
+    calls = []
+
+    def make(seed):
+        def f():
+            calls.append(seed)
+            return W.synth_weights(arch, seed)
+        return f
+    a = W.cached_blob(arch, "synthetic:tiny:1", make(1))
+    b = W.cached_blob(arch, "synthetic:tiny:1", make(1))
+    assert a == b == W.pack_blob(W.fold_weights(arch, W.synth_weights(arch, 1))) and calls == [1]
+    c = W.cached_blob(arch, "synthetic:tiny:2", make(2))
+    assert c != a and calls == [1, 2] and len(list(tmp_path.glob("*.rtdw"))) == 2
+    path = tmp_path / (W.blob_cache_key(arch, "synthetic:tiny:1") + ".rtdw")
+    path.write_bytes(a[: len(a) // 2])                                  # a torn write
+    assert W.cached_blob(arch, "synthetic:tiny:1", make(1)) == a and calls == [1, 2, 1]
+    f = tmp_path / "ckpt.pth"
+    f.write_bytes(b"x")
+    k1 = W.blob_cache_key(arch, str(f))
+    f.write_bytes(b"xy")
+    assert W.blob_cache_key(arch, str(f)) != k1 != W.blob_cache_key(ARCHS["tinyb"], str(f))
+    monkeypatch.setenv("RTD_BLOB_CACHE", "0")
+    assert W.cached_blob(arch, "synthetic:tiny:1", make(1)) == a and calls[-1] == 1 and len(calls) == 4
