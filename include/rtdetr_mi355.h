@@ -109,6 +109,12 @@ int rtd_infer(rtd_handle h, int32_t n, const uint8_t* const* frames_bgr_hwc, con
 int rtd_infer_raw(rtd_handle h, int32_t n, const uint8_t* const* frames_bgr_hwc, const int32_t* hw,
                   int32_t frames_on_device, int32_t* labels, float* boxes, float* scores);
 
+/* RTDETRDetector.preprocess (src/rtdetr_detector.py:206-236) as a value: BGR -> RGB, PIL-exact antialiased stretch to input_h x input_w
+ * when the frame has another size, / 255 - written as [3][input_h][input_w] fp32 to out_chw_dev (DEVICE memory of the caller, e.g. a torch
+ * tensor).  Synchronous.  detect / detect_batch never call it (the network reads the uint8 frames directly); it exists so that a caller
+ * of the reference's preprocess() gets the tensor without a forward pass or a host round trip. */
+int rtd_preprocess(rtd_handle h, const uint8_t* frame_bgr_hwc, int32_t frame_h, int32_t frame_w, int32_t frame_on_device, float* out_chw_dev);
+
 /* Pipelined form of detect_batch (src/rtdetr_detector.py:307-403 called by the batcher, src/shared_inference_coordinator.py:250),
  * also used by the multi-camera shard and the benchmark: rtd_infer_async enqueues upload + preprocess + network + post-process on the
  * handle's stream and returns; rtd_collect blocks for the LAST submitted batch and returns rtd_infer's rows for it.  A handle has ONE

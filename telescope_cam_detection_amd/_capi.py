@@ -104,7 +104,7 @@ _lib: Optional[C.CDLL] = None
 EXPORTS = [
     "rtd_version", "rtd_create", "rtd_load_weights", "rtd_infer", "rtd_infer_raw", "rtd_infer_async", "rtd_collect", "rtd_prepare",
     "rtd_result_block", "rtd_sync", "rtd_stream", "rtd_wait_stream", "rtd_signal_stream", "rtd_get_stats", "rtd_arena_bytes", "rtd_destroy",
-    "rtd_last_error", "rtd_crop_resize_batch", "rtd_self_check",
+    "rtd_last_error", "rtd_crop_resize_batch", "rtd_self_check", "rtd_preprocess",
 ]
 # every symbol include/rtdetr_mi355_test.h declares: kernel-level test / bench / debug entry points (csrc/testapi.hip)
 TEST_EXPORTS = [
@@ -155,6 +155,8 @@ def lib() -> C.CDLL:
     L.rtd_get_stats.argtypes = [vp, C.POINTER(RtdStats)]
     L.rtd_self_check.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(RtdCheckReport)]
     L.rtd_self_check.restype = C.c_int
+    L.rtd_preprocess.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.rtd_preprocess.restype = C.c_int
     L.rtd_result_block.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.rtd_sync.argtypes = [vp]
     L.rtd_stream.argtypes = [vp]
@@ -364,6 +366,14 @@ class Engine:
 
     def stats(self) -> dict:
         return _stats_of(self._h)
+
+    def preprocess_into(self, frame, on_device: bool, out_ptr: int) -> None:
+        """rtd_preprocess: one HWC uint8 BGR frame (numpy array, or a contiguous device tensor when on_device) -> [3, H, W] fp32 at out_ptr (device)."""
+        h, w = int(frame.shape[0]), int(frame.shape[1])
+        src = frame.data_ptr() if on_device else frame.ctypes.data
+        rc = lib().rtd_preprocess(self._h, C.c_void_p(src), h, w, int(on_device), C.c_void_p(out_ptr))
+        if rc != RTD_OK:
+            _raise(rc, self._h)
 
     def self_check(self, blob: bytes) -> dict:
         """rtd_self_check: this engine's arithmetic against the library's exact fp32 engine on one built-in frame, with the weights of

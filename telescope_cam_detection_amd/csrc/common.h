@@ -267,6 +267,7 @@ struct ResizeCoef {
 };
 void launch_resize_pil(const uint8_t* src, int sh, int sw, uint8_t* tmp, const Tensor& y, int image, const ResizeCoef& coef,
                        hipStream_t s);
+void launch_u8_hwc_to_chw_f32(const uint8_t* src, int H, int W, float* out, hipStream_t s);
 void launch_resize_pil_u8(const uint8_t* src, int sh, int sw, uint8_t* tmp, uint8_t* dst, int dh, int dw, const ResizeCoef& c, hipStream_t s);
 // ---- fused decoder layer (decoder.hip) ----
 struct DecLin {

@@ -1520,6 +1520,47 @@ int rtd_collect(rtd_handle h, float conf, int32_t wildlife_only, rtd_det* out, i
   });
 }
 
+int rtd_preprocess(rtd_handle h, const uint8_t* frame, int32_t fh, int32_t fw, int32_t frame_on_device, float* out_chw_dev) {
+  return guarded(h, [&] {
+    rtd_engine* e = h;
+    RTD_CHECK(e->loaded, RTD_E_STATE, "weights not loaded");
+    RTD_CHECK(frame && out_chw_dev && fh > 0 && fw > 0 && fh <= 16384 && fw <= 16384, RTD_E_INVALID, "frame pointer / size");
+    HIP_CHECK(hipSetDevice(e->cfg.device));
+    check_streams_live(e);
+    const int H = e->cfg.input_h, W = e->cfg.input_w;
+    if (e->in_flight) { HIP_CHECK(hipStreamSynchronize(e->stream)); }           // a submitted batch may still read the staging buffers used below
+    const size_t bytes = (size_t)fh * fw * 3;
+    const uint8_t* src = frame;
+    if (!frame_on_device) {
+      if (bytes > e->frame_stage_bytes) {
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+        if (e->frame_stage) (void)hipFree(e->frame_stage);
+        e->frame_stage = nullptr; e->frame_stage_bytes = 0;
+        HIP_CHECK(hipMalloc((void**)&e->frame_stage, bytes));
+        e->frame_stage_bytes = bytes;
+      }
+      HIP_CHECK(hipMemcpyAsync(e->frame_stage, frame, bytes, hipMemcpyHostToDevice, e->stream));
+      src = e->frame_stage;
+    }
+    if (fh != H || fw != W) {                                                    // PIL-exact antialiased stretch, uint8 in and out (T.Resize on the PIL image)
+      const size_t tmp = (size_t)fh * W * 3;
+      if (tmp > e->resize_tmp_bytes) {
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+        if (e->resize_tmp) (void)hipFree(e->resize_tmp);
+        e->resize_tmp = nullptr; e->resize_tmp_bytes = 0;
+        HIP_CHECK(hipMalloc((void**)&e->resize_tmp, tmp));
+        e->resize_tmp_bytes = tmp;
+      }
+      if (!e->u8_stage) HIP_CHECK(hipMalloc((void**)&e->u8_stage, (size_t)e->cfg.max_batch * H * W * 3));
+      const ResizeCoef& rc = resize_tables(e, fh, fw);
+      launch_resize_pil_u8(src, fh, fw, e->resize_tmp, e->u8_stage, H, W, rc, e->stream);
+      src = e->u8_stage;
+    }
+    launch_u8_hwc_to_chw_f32(src, H, W, out_chw_dev, e->stream);
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+  });
+}
+
 int rtd_prepare(rtd_handle h, int32_t n) {
   return guarded(h, [&] {
     check_n(h, n);

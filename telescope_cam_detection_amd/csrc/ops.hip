@@ -1236,6 +1236,22 @@ void launch_resize_pil_u8(const uint8_t* src, int sh, int sw, uint8_t* tmp, uint
   HIP_CHECK(hipGetLastError());
 }
 
+// RTDETRDetector.preprocess (src/rtdetr_detector.py:206-236) as a value: uint8 HWC BGR at the network's size -> [3][H][W] fp32 RGB in [0, 1]
+// (ToTensor: v / 255.0f, the division the engines' own input paths perform).  One thread per pixel.
+__global__ void k_u8_hwc_to_chw_f32(const uint8_t* __restrict__ src, int H, int W, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t hw = (int64_t)H * W;
+  if (i >= hw) return;
+  const uint8_t* px = src + i * 3;
+  out[i] = (float)px[2] / 255.0f;
+  out[hw + i] = (float)px[1] / 255.0f;
+  out[2 * hw + i] = (float)px[0] / 255.0f;
+}
+void launch_u8_hwc_to_chw_f32(const uint8_t* src, int H, int W, float* out, hipStream_t s) {
+  rtd_launch(k_u8_hwc_to_chw_f32, dim3(blocks_for((int64_t)H * W, 256)), dim3(256), 0, s, src, H, W, out);
+  HIP_CHECK(hipGetLastError());
+}
+
 // ---- backbone.stem.0 from uint8 frames -------------------------------------------------------------------------------------
 // The generic path writes every frame as bf16 NHWC with 3 -> 8 channel padding (16 bytes per pixel: 52 MB at 640^2 bs 8) and the
 // stem conv reads it back with K = 72 of which 27 taps are real.  Here a block stages the (2*8+1) x (2*32+1) pixel uint8 patch of

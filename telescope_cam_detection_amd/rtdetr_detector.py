@@ -292,17 +292,22 @@ class RTDETRDetector:
 
     # ------------------------------------------------------------------ API of the reference class
     def preprocess(self, img: Union[np.ndarray, "torch.Tensor"]) -> tuple:
-        """(preprocessed [1,3,H,W] fp32 tensor on the device, [[w, h]] tensor) - src/rtdetr_detector.py:206-236.
-        Provided for interface parity; `detect` does not call it (the library fuses this step)."""
+        """(preprocessed [1,3,H,W] fp32 tensor on the device, [[w, h]] tensor) - src/rtdetr_detector.py:206-236: BGR -> RGB, the PIL-exact
+        antialiased stretch to the engine's input size, / 255.  Provided for interface parity; `detect` does not call it (the network's
+        first kernel reads the uint8 frame directly).  One small launch on the device (rtd_preprocess): no forward pass, no host round trip."""
         import torch
 
         a, on_dev = self._as_frame(img)
+        if not on_dev:
+            a = np.ascontiguousarray(a)
         eng = self.model.engine
         if on_dev:
             self._order_after_producer(eng)
-        eng.infer_raw([a], on_device=on_dev)
-        dev = f"cuda:{self._dev_index}"
-        x = torch.from_numpy(eng.debug_tensor("input")[:, :, :, :3]).permute(0, 3, 1, 2).contiguous().to(dev)
+        dev = torch.device("cuda", self._dev_index)
+        ih, iw = self._engine_input_size
+        x = torch.empty((1, 3, ih, iw), dtype=torch.float32, device=dev)
+        torch.cuda.current_stream(dev).synchronize()           # x's memory may be a recycled block that torch's stream is still using
+        eng.preprocess_into(a, on_dev, x.data_ptr())
         h, w = a.shape[:2]
         return x, torch.tensor([[w, h]], device=dev)
 

@@ -74,8 +74,8 @@ def test_fp32_engine_matches_oracle_and_golden(name):
         for rl, rb, rs in ((ol[b].numpy(), ob[b].numpy(), osc[b].numpy()), (g["labels"][b], g["boxes"][b], g["scores"][b])):
             m, n, ws, wb = match_detections(rl, rb, rs, labels[b], boxes[b], scores[b], 1e-3, 1e-2)
             print(f"{name}[{b}] matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
-            # a selection flip at the K-th/K+1-th near-tie (gap ~1e-5, see make_golden output) may move a few rows
-            assert m >= n - 3, (m, n, ws, wb)
+            # measured: every row on every case; ONE row is the allowance for a near-tie at a top-k cut (gap ~1e-5, see make_golden output)
+            assert m >= n - 1, (m, n, ws, wb)
         assert (np.diff(scores[b]) <= 0).all(), "scores must be descending"
     eng.close()
 
@@ -95,8 +95,8 @@ def test_fp32_engine_full_size_configs_against_hf_fixtures(name):
         m, n, ws, wb = match_detections(g["labels"][b], g["boxes"][b], g["scores"][b], labels[b], boxes[b], scores[b], 1e-3, 1e-2)
         print(f"{name}[{b}] matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px")
         miss += n - m
-        assert m >= n - 3, (m, n)          # measured 300/300 on every frame; a selection flip at the K-th / K+1-th near-tie (gap ~1e-5) may move a row
-    assert miss <= 3
+        assert m >= n - 1, (m, n)          # measured 300/300 on every frame; a selection flip at the K-th / K+1-th near-tie (gap ~1e-5) may move a row
+    assert miss <= 1
     eng.close()
 
 
@@ -121,7 +121,7 @@ def x3_check(name, arch, w, input_size, eng, frames, ref_topk, ref_scores_all, r
             off_cut = [i for i in un if float(rs[b][i]) - cut > cut_tol]
             print(f"{name}[{b}] f16x3 {tag_phase} vs {tag}: matched {m}/{n} worst dscore={ws:.2e} dbox={wb:.2e}px; "
                   f"unmatched at the top-{Q} cut: {len(un) - len(off_cut)}, elsewhere: {len(off_cut)}")
-            assert not off_cut and len(un) <= 6, (tag, b, m, n, [float(rs[b][i]) - cut for i in un])
+            assert not off_cut and len(un) <= 1, (tag, b, m, n, [float(rs[b][i]) - cut for i in un])   # measured (round 5, 88 frame checks): 0 everywhere; one near-tie at the cut is the whole allowance
 
     labels, boxes, scores = eng.infer_raw(frames)
     mx = eng.debug_tensor("enc_cls_max")[:, :, 0, 0]
@@ -149,7 +149,7 @@ def x3_check(name, arch, w, input_size, eng, frames, ref_topk, ref_scores_all, r
         else:
             rows("free-running", b, refs, labels, boxes, scores)
         assert (np.diff(scores[b]) <= 0).all(), "scores must be descending"
-    assert sum(flips) <= max(2, len(frames) // 2), flips           # measured: 0-1 per frame on the noise frames, none on the scenes
+    assert sum(flips) <= 1, flips           # measured (round 5): none on any case - the only differing selections are exact ties of masked anchors, which are not flips
     eng.force_topk(np.asarray(ref_topk))
     labels, boxes, scores = eng.infer_raw(frames)
     eng.force_topk(None)
@@ -820,6 +820,31 @@ def test_detector_keeps_working_after_the_callers_degrade_writes():
     assert det.detect_batch_collect(ticket) == before
     x, wh = det.preprocess(frames[1])
     assert x.is_cuda and tuple(x.shape) == (1, 3) + tuple(input_size) and wh.tolist() == [[frames[1].shape[1], frames[1].shape[0]]]
+
+
+def test_preprocess_returns_the_reference_tensor_bit_for_bit():
+    """`RTDETRDetector.preprocess` (src/rtdetr_detector.py:206-236: BGR -> RGB, ToPILImage -> Resize -> ToTensor, orig_size [[w, h]]) as one
+    small device launch (rtd_preprocess, round 5: no forward pass, no host round trip): equal to the oracle's PIL pipeline bit for bit for a
+    frame of the network's size, a 720p and a 1080p frame, from host memory and from a device tensor - on every engine precision."""
+    from oracle import rtdetr_oracle as orc
+    from telescope_cam_detection_amd.rtdetr_detector import RTDETRDetector
+    from telescope_cam_detection_amd.synth import noise_frame, scene_frame
+    size = (320, 416)
+    frames = [scene_frame(5, 320, 416), noise_frame(6, 720, 1280), scene_frame(7, 1080, 1920), noise_frame(8, 97, 131)]
+    for prec in ("f16x3", "bf16"):
+        det = RTDETRDetector(config_path="tinyc", model_path="synthetic:tinyc:1", device="cuda:0", input_size=size, precision=prec, max_batch=2)
+        assert det.load_model(max_retries=1) is True
+        for f in frames:
+            want, (w_, h_) = orc.preprocess(f, size)
+            for src in (f, torch.from_numpy(f).cuda(), torch.from_numpy(f)):
+                x, wh = det.preprocess(src)
+                assert x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (1, 3) + size
+                assert torch.equal(x.cpu(), want), (prec, f.shape)
+                assert wh.tolist() == [[w_, h_]] == [[f.shape[1], f.shape[0]]]
+        before = det.detect(frames[1])
+        det.preprocess(frames[2])                                   # shares the engine's staging buffers: the next detect is unaffected
+        assert det.detect(frames[1]) == before
+        det.model.engine.close()
 
 
 def test_out_of_memory_surfaces_as_torch_cuda_out_of_memory_error():
