@@ -153,10 +153,11 @@ def lib() -> C.CDLL:
     L.rtd_wait_stream.argtypes = [vp, vp]
     L.rtd_signal_stream.argtypes = [vp, vp]
     L.rtd_get_stats.argtypes = [vp, C.POINTER(RtdStats)]
-    L.rtd_self_check.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(RtdCheckReport)]
-    L.rtd_self_check.restype = C.c_int
-    L.rtd_preprocess.argtypes = [vp, vp, i32, i32, i32, vp]
-    L.rtd_preprocess.restype = C.c_int
+    if hasattr(L, "rtd_self_check") or not override:     # (an OLDER build under RTD_LIB_PATH, tools/ab_lib.sh, may predate these two)
+        L.rtd_self_check.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(RtdCheckReport)]
+        L.rtd_self_check.restype = C.c_int
+        L.rtd_preprocess.argtypes = [vp, vp, i32, i32, i32, vp]
+        L.rtd_preprocess.restype = C.c_int
     L.rtd_result_block.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.rtd_sync.argtypes = [vp]
     L.rtd_stream.argtypes = [vp]

@@ -42,7 +42,7 @@ __device__ __forceinline__ float dinv_sig(float x) {
 // request the whole filter in their first round and later rounds hit in L2.  The fp32 summation order of a row depends only on
 // its tile index, not on the batch size (batch invariance holds bit for bit).
 template <int ACT>
-__device__ __forceinline__ void row_gemm(const float* Xs, int ldx, const DecLin& L, float* Ys, int ldy, const float* Rs, int ldr, int wave, int lane, int rot) {
+__device__ void row_gemm(const float* Xs, int ldx, const DecLin& L, float* Ys, int ldy, const float* Rs, int ldr, int wave, int lane, int rot) {
   const int ntiles = (L.N + 15) >> 4;
   const int r16 = lane & 15, q = lane >> 4;
   const float* xrow = Xs + r16 * ldx + 4 * q;
@@ -135,7 +135,7 @@ __device__ __forceinline__ void split_rows(const float* Xs, int ldx, int K, sp16
 // 5x less MFMA time for the same filter bytes, products exact to ~2^-17.  A lane's fragments: A[row = lane & 15][32c + 8 (lane >> 4) .. +7],
 // W[n0 + (lane & 15)][same k].  Output: fp32 Ys and / or a hi/lo split (Yh, Yl) for a following GEMM.
 template <int ACT, bool WLO = true>   // WLO = false: the filter's lo half is neither loaded nor multiplied (hi-only filter, split activations)
-__device__ __forceinline__ void row_gemm_split(const sp16* Ah, const sp16* Al, int lda, const DecLin& L, float* Ys, int ldy, const float* Rs, int ldr,
+__device__ void row_gemm_split(const sp16* Ah, const sp16* Al, int lda, const DecLin& L, float* Ys, int ldy, const float* Rs, int ldr,
                                sp16* Yh, sp16* Yl, int ldyb, int wave, int lane, int rot, int probe = 0) {
   constexpr int PF = 2;   // K steps of filter fragments in flight per wave (round 2: 3 changed nothing; round 4: 4 needs 128 VGPRs of fragments - 256 + 704 B of scratch, 140 us per layer)
   const int ntiles = (L.N + 15) >> 4;
@@ -289,7 +289,7 @@ __device__ __forceinline__ void row_ln(float* Xs, int ldx, int D, const LNRegs& 
 // is pure HBM/MALL latency (random 64-byte rows of a ~200 MB tensor) and was 50 % of the kernel with one
 // 2-byte load per lane and 8 items per pass.
 template <typename TV>
-__device__ __forceinline__ void sample_rows(const DecArgs& a, const float* sO, int LDO, const float* sR, int LDR, float* sA, int LDH, int b,
+__device__ void sample_rows(const DecArgs& a, const float* sO, int LDO, const float* sR, int LDR, float* sA, int LDH, int b,
                             int nvalid, int tid) {
   constexpr int NL = 3, NP = 4, LP = NL * NP;
   constexpr int V = 16 / (int)sizeof(TV);                      // channels per 16-byte load: 8 (bf16) / 4 (fp32)
@@ -369,7 +369,7 @@ __device__ __forceinline__ void sample_rows(const DecArgs& a, const float* sO, i
 // and the accumulator tile of P^T is already the B-fragment of the next product  O^T += V^T P^T
 // (MI355X guide: "an accumulator tile as the next MFMA's operand").  K and V were written by the previous launch
 // in fragment order, so each operand fetch is one contiguous 1 KiB wave load.
-__device__ __forceinline__ void self_attention_rows(const DecArgs& a, const float* sQ, int ldq, float* sA, int LDH, int b, int tiles, int wave, int lane) {
+__device__ void self_attention_rows(const DecArgs& a, const float* sQ, int ldq, float* sA, int LDH, int b, int tiles, int wave, int lane) {
   const int head = wave;                                        // NW == heads
   const int r16 = lane & 15, q = lane >> 4;
   const float scale = rsqrtf(32.f);
@@ -441,7 +441,7 @@ __device__ __forceinline__ void self_attention_rows(const DecArgs& a, const floa
 //   O^T  += V_pair^T P_pair^T : the 32-deep contraction runs over the pair's keys in the order (tile e, key 4 kq + r) -> position
 //                               8 kq + 4 e + r, which is exactly how a lane's S accumulators of the two tiles are laid out (no shuffle);
 //                               V fragments [d][hi | lo][lane][8] per pair, written half by each tile's producer block.
-__device__ __forceinline__ void self_attention_rows_split(const DecArgs& a, const float* sQ, int ldq, float* sA, int LDH, int b, int tiles, int wave, int lane) {
+__device__ void self_attention_rows_split(const DecArgs& a, const float* sQ, int ldq, float* sA, int LDH, int b, int tiles, int wave, int lane) {
   const int head = wave;
   const int r16 = lane & 15, q = lane >> 4;
   const float scale = rsqrtf(32.f);
@@ -555,9 +555,11 @@ __device__ __forceinline__ void touch_weights(const DecLin& L, int part, int npa
 // SPLIT: the linear layers take hi/lo fp16 splits of their operands (row_gemm_split); every fp32 A operand of K <= 256 is split
 // into the sXh/sXl staging rows right before its GEMM, the two wide ones (FFN hidden 1024, qpos hidden 512) are written as
 // splits by the producing GEMM straight into the sF region (same bytes as the fp32 rows they replace).
-// (The phase functions above are __forceinline__: when the inliner's budget runs out - any experiment that grows this kernel - hipcc leaves one
-// of them as a CALL, the by-reference DecArgs must then live in memory, and the whole 704-byte argument struct is copied to scratch at kernel
-// entry.  Round 4 read that as register spilling ("256 registers + 704 B of scratch"); it is an inlining artefact.)
+// (The phase functions above are plain __device__ functions that hipcc inlines here.  When the inliner's budget runs out - any experiment that
+// grows this kernel - it leaves one of them as a CALL, the by-reference DecArgs must then live in memory, and the whole 704-byte argument
+// struct is copied to scratch at kernel entry: round 4 read that as register spilling ("256 registers + 704 B of scratch"); it is an
+// inlining artefact, and __forceinline__ on the phase functions removes it.  They are NOT force-inlined in this build: with the attribute
+// hipcc schedules the same code 2.5 % slower (0.770 vs 0.747 ms per step for the nine launches, same box, round 5).)
 template <int SPLIT>
 __global__ __launch_bounds__(NT, 1) void dec_layer_kernel(const DecArgs a) {
   // LDS (floats).  Row strides are (cols + 4): ds_read_b128 of 16 rows x 4 k-groups is conflict-free.

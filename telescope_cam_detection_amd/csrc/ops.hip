@@ -756,7 +756,118 @@ __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ keys, i
       kreg[j] = (j < npt && i < N) ? f2key(kb[i]) : 0u;         // slots beyond N are never counted (guarded by i < N)
     }
   }
-  auto key_at = [&](int j, int i) -> unsigned { return REG ? kreg[j] : f2key(kb[i]); };
+  // ---- fast path (round 5): bound the candidates before any pass over all the keys ----------------------------------------------
+  // The keys are thrown into 1024 BAGS by a multiplicative hash of their index; the K-th largest of the bag maxima, L, is a lower bound
+  // of the K-th largest key (the K best bags each hold a different key >= L), so the answer lies among the keys >= L - about 1.1 K of
+  // them (24 000 keys, K = 300: ~340) whatever structure the index carries (per-thread strides meet the post-processor's class-major
+  // layout: every 16th thread holds a class; contiguous groups meet the encoder's spatially clustered scores; a hash meets neither).
+  // L costs one LDS atomic-max per key on scattered addresses and a radix select over ONE value per thread (4 passes of 1024 LDS
+  // atomics instead of 24 576: a pass over all the keys of one image serialises 64-way on the handful of exponent buckets that scores
+  // share, ~12 us for the first pass alone); the candidates are compacted with one atomic per wave and key slot and ordered by
+  // counting, for every candidate, the candidates above it (the 64-bit (key, ~index) composites are distinct: ranks are exact, ties fall
+  // lowest-index-first as before).  More than 1024 candidates (heavy ties at the cut, e.g. masked anchors sharing one score) fall
+  // through to the general path below.
+  {
+    unsigned* bag = (unsigned*)sel;                                // the first 4 KB of sel (re-zeroed below)
+    bag[tid] = 0u;
+    __syncthreads();
+    auto bag_of = [](int i) -> unsigned { return ((unsigned)i * 2654435761u) >> 22; };
+    if (REG) {
+#pragma unroll
+      for (int j = 0; j < MAXPT; ++j) {
+        const int i = tid + j * 1024;
+        if (j < npt && i < N) atomicMax(&bag[bag_of(i)], kreg[j]);
+      }
+    } else {
+      for (int i = tid; i < N; i += 1024) atomicMax(&bag[bag_of(i)], f2key(kb[i]));
+    }
+    __syncthreads();
+    const unsigned tmax = bag[tid];
+    __syncthreads();
+    if (tid == 0) { s_prefix = 0; s_krem = (unsigned)K; s_cnt_gt = 0; }
+    sel[tid] = 0ull;
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      unsigned* mine = whist[tid >> 6];
+      for (int b = tid & 63; b < 256; b += 64) mine[b] = 0;
+      __builtin_amdgcn_wave_barrier();
+      const unsigned prefix = s_prefix;
+      const unsigned mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+      if ((tmax & mask) == prefix) atomicAdd(&mine[(tmax >> shift) & 255u], 1u);
+      __syncthreads();
+      if (tid < 256) {
+        unsigned t = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += whist[w][tid];
+        hist[tid] = t;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const int l = tid;
+        const unsigned c0 = hist[255 - 4 * l], c1 = hist[254 - 4 * l], c2 = hist[253 - 4 * l], c3 = hist[252 - 4 * l];
+        const unsigned tot = c0 + c1 + c2 + c3;
+        unsigned incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned t = __shfl_up(incl, o, 64);
+          if (l >= o) incl += t;
+        }
+        const unsigned excl = incl - tot;
+        const unsigned rem = s_krem;
+        if (excl < rem && rem <= incl) {
+          unsigned r = rem - excl, d;
+          if (r <= c0) d = 255 - 4 * l;
+          else if ((r -= c0) <= c1) d = 254 - 4 * l;
+          else if ((r -= c1) <= c2) d = 253 - 4 * l;
+          else { r -= c2; d = 252 - 4 * l; }
+          s_krem = r;
+          s_prefix = prefix | (d << shift);
+        }
+      }
+      __syncthreads();
+    }
+    const unsigned Lb = s_prefix;                                  // K-th largest thread maximum
+    const int lane_ = tid & 63;
+    auto offer = [&](unsigned k, int i, bool has) {                // wave-aggregated compaction of the keys >= Lb
+      const bool take = has && k >= Lb;
+      const unsigned long long bal = __ballot(take);
+      if (bal) {
+        unsigned base = 0;
+        if (lane_ == (int)__builtin_ctzll(bal)) base = atomicAdd(&s_cnt_gt, (unsigned)__popcll(bal));
+        base = __shfl(base, (int)__builtin_ctzll(bal), 64);
+        const unsigned pos = base + (unsigned)__popcll(bal & ((1ull << lane_) - 1ull));
+        if (take && pos < 1024) sel[pos] = ((unsigned long long)k << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+      }
+    };
+    if (REG) {
+#pragma unroll
+      for (int j = 0; j < MAXPT; ++j) {
+        const int i = tid + j * 1024;
+        if (j < npt) offer(kreg[j], i, i < N);                      // (j < npt is block-uniform: every lane of a wave takes part in the ballot)
+      }
+    } else {
+      for (int base_i = 0; base_i < N; base_i += 1024) {
+        const int i = base_i + tid;
+        offer(i < N ? f2key(kb[i]) : 0u, i, i < N);
+      }
+    }
+    __syncthreads();
+    const unsigned C = s_cnt_gt;
+    if (C <= 1024u) {                                               // block-uniform
+      if ((unsigned)tid < C) {
+        const unsigned long long my = sel[tid];
+        unsigned r = 0;
+        for (unsigned j = 0; j < C; ++j) r += sel[j] > my ? 1u : 0u;
+        if (r < (unsigned)K) {
+          idx_out[(int64_t)blockIdx.x * K + r] = (int32_t)(0xffffffffu - (unsigned)(my & 0xffffffffu));
+          if (val_out) val_out[(int64_t)blockIdx.x * K + r] = key2f((unsigned)(my >> 32));
+        }
+      }
+      return;
+    }
+    __syncthreads();                                                // every wave has read C before the general path resets the counters
+  }
   if (tid == 0) { s_prefix = 0; s_krem = (unsigned)K; s_cnt_gt = 0; s_cnt_eq = 0; }
   sel[tid] = 0ull;
   __syncthreads();

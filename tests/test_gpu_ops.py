@@ -589,6 +589,40 @@ def test_topk_exact(L, case):
         assert (idx[b][1:][same_val & (val[b][1:] != 0)] > idx[b][:-1][same_val & (val[b][1:] != 0)]).all(), "ties: lowest index first"
 
 
+@pytest.mark.parametrize("kind", ["distinct", "sigmoid", "all_equal", "two_values", "ties_at_cut", "short"])
+@pytest.mark.parametrize("N,K", [(8400, 300), (24000, 300), (33600, 300), (1500, 1024), (300, 300)])
+def test_topk_fast_and_general_paths(L, kind, N, K):
+    """k_topk (round 5) bounds the candidates by the K-th largest per-thread maximum and ranks them by counting; more than 1024 candidates
+    (heavy ties) take the general radix path.  Both must return torch.topk's values with the documented tie rule (lowest index first):
+    distinct keys and score-like keys (fast path), one or two distinct values (general path), a tie group that straddles the cut."""
+    B = 3
+    g = torch.Generator().manual_seed(N * 7 + K + len(kind))
+    if kind == "distinct":
+        keys = torch.randperm(B * N, generator=g).float().view(B, N) * 0.25 - 1000.0
+    elif kind == "sigmoid":
+        keys = torch.sigmoid(torch.randn(B, N, generator=g) * 2.0 - 3.0)
+    elif kind == "all_equal":
+        keys = torch.full((B, N), 0.3125)
+    elif kind == "two_values":
+        keys = torch.where(torch.rand(B, N, generator=g) < 0.5, torch.tensor(1.5), torch.tensor(-2.0))
+    elif kind == "ties_at_cut":
+        keys = torch.randn(B, N, generator=g)
+        kth = torch.sort(keys, 1, descending=True).values[:, min(K, N) - 1:min(K, N)]
+        keys = torch.where((keys - kth).abs() < 0.02, kth.expand_as(keys), keys)       # a group of exact ties around the K-th value
+    else:
+        keys = torch.randn(B, N, generator=g)
+        keys[:, N // 2:] = -float("inf")                                              # most threads hold only -inf
+    idx = torch.empty(B, K, dtype=torch.int32, device="cuda")
+    val = torch.empty(B, K, dtype=torch.float32, device="cuda")
+    kd = keys.cuda()
+    ck(L, L.rtd_op_topk(kd.data_ptr(), B, N, K, idx.data_ptr(), val.data_ptr()))
+    idx, val = idx.cpu().long(), val.cpu()
+    for b in range(B):
+        order = np.lexsort((np.arange(N), -keys[b].double().numpy()))[:K]               # (value desc, index asc)
+        assert np.array_equal(idx[b].numpy(), order), (kind, N, K, b)
+        assert torch.equal(val[b], keys[b][torch.as_tensor(order)])
+
+
 @pytest.mark.parametrize("size", [((720, 1280), (640, 640)), ((1080, 1920), (640, 640)), ((100, 90), (192, 128)),
                                   ((300, 260), (192, 128)), ((640, 640), (640, 640)), ((37, 53), (64, 96))])
 def test_resize_matches_pil_bit_exactly(L, size):
