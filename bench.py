@@ -435,6 +435,7 @@ def main():
             print(f"[bench] cpu baseline on {cores} threads ...", file=sys.stderr, flush=True)
             nb = min(B, 8)                                    # the benchmark batch itself (R50 640 bs 8: ~2 s per batch on 16 threads)
             host = [f.cpu().numpy() for f in frames[:nb]]
+            w = synth_weights(arch, 0)                       # the oracle takes the un-folded state (the engines were loaded from the cached blob)
             orc.detect_batch(arch, w, host, (H, H))          # warm-up
             reps = 3
             t1 = time.perf_counter()

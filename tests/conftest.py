@@ -17,7 +17,7 @@ def pytest_configure(config):
 # The GPU suite runs hot-path evidence FIRST: end-to-end parity against the oracle / HF fixtures, then the kernel
 # tests, then Stage 2, the batcher and the RCCL step.  Under `-x` a defect in host glue can then no longer hide the kernels' evidence.
 _FILE_ORDER = ["test_oracle_golden.py", "test_host_golden.py", "test_host_logic.py", "test_checkpoint.py", "test_gpu_parity.py", "test_gpu_ops.py", "test_weights_guard.py",
-               "test_stage2.py", "test_engine_sequence.py", "test_batching.py", "test_rccl_collate.py"]
+               "test_stage2.py", "test_engine_sequence.py", "test_batching.py", "test_rccl_collate.py", "test_bench_contract.py"]
 # inside test_gpu_parity.py: the default engine's full-size BASELINE configs and oracle cases lead
 _PARITY_FIRST = ["test_f16x3_engine_full_size_configs_against_hf_fixtures", "test_f16x3_engine_matches_oracle_and_golden",
                  "test_full_size_properties_f16x3_bs8", "test_f16x3_other_backbones_and_sizes_against_the_oracle", "test_detector_class_end_to_end",

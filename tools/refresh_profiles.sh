@@ -1,11 +1,11 @@
 #!/bin/bash
 # Regenerates every measurement committed under profiles/ on the GPU box (one gpurun call each; a part that times out stops the script):
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r04 r50'      (default config: R50 640^2 bs 8, f16x3)
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r04 r101'     (BASELINE configs[2]: R101 1280^2 bs 4)
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r04 lines'    (the other bench lines)
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r05 r50'      (default config: R50 640^2 bs 8, f16x3)
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r05 r101'     (BASELINE configs[2]: R101 1280^2 bs 4)
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r05 lines'    (the other bench lines)
 # then, back in the container, tools/summarize_profiles.py turns the CSVs into profiles/<round>_*.json (commands at the end of this file)
 set -u
-R=${1:-r04}
+R=${1:-r05}
 WHAT=${2:-r50}
 export TMPDIR=/tmp
 O=gpurun_out/$R
