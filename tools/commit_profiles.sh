@@ -3,7 +3,7 @@
 # container, kernel sources unchanged since the GPU runs: the summaries are stamped with the csrc hash bench.py checks).
 #   bash tools/commit_profiles.sh r03
 set -eu
-R=${1:-r03}
+R=${1:-r05}
 T=gpurun_out/$R; P=profiles/$R
 f() { ls $1 2>/dev/null | head -1; }
 if [ -n "$(f "$T/trace/*kernel_trace.csv")" ]; then
@@ -24,8 +24,8 @@ if [ -n "$(f "$T/trace_r101/*kernel_trace.csv")" ]; then
   tail -n 1 $T/bench_r101.json > ${P}_bench_r101_1280_bs4_f16x3.json
   unset RTD_PROFILE_CONFIG RTD_PROFILE_ARGS
 fi
-for n in r18:r18_bs8_f16x3 bf16:r50_bs8_bf16 fp32:r50_bs8_fp32 two_stage:two_stage_r50_bs8_f16x3 collate:collate_r50_bs8_f16x3; do
+for n in r18:r18_bs8_f16x3 bf16:r50_bs8_bf16 fp32:r50_bs8_fp32 two_stage:two_stage_r50_bs8_f16x3 collate:collate_r50_bs8_f16x3 c4:c4_r50_bs1_collate; do
   src=$T/bench_${n%%:*}.json
-  [ -s $src ] && tail -n 1 $src > ${P}_bench_${n##*:}.json
+  if [ -s $src ]; then tail -n 1 $src > ${P}_bench_${n##*:}.json; fi
 done
 ls -la profiles | grep $R

@@ -44,6 +44,8 @@ else
   run 300 $O/bench_fp32.json python bench.py --precision fp32 --no-cpu-baseline --steps 30 --warmup 5 --multi-streams 0
   run 300 $O/bench_two_stage.json python bench.py --workload two_stage --no-cpu-baseline --no-latency
   run 300 $O/bench_collate.json python bench.py --collate --no-cpu-baseline --no-latency --no-detect-host --multi-streams 0 --no-bf16-line
+  # BASELINE configs[3]'s per-rank shape (one camera per GPU: bs 1 + the collate all-gather) at N = 1: the line a SCALE run's N = 1 must agree with
+  run 300 $O/bench_c4.json python bench.py --batch 1 --collate --no-cpu-baseline --no-detect-host --multi-streams 0 --no-bf16-line
 fi
 find $O -name "*.csv" | head -40
 # back in the container (kernel sources unchanged since the run):
