@@ -316,7 +316,15 @@ def main():
             sha = csrc_sha()
             tag = f"{args.arch}_{H}_bs{B}_{args.precision}"
             sfx = "" if tag == "r50_640_bs8_f16x3" else f"_{args.arch}_{H}_bs{B}"
-            with open(os.path.join(ROOT, "profiles", f"r04_pmc_hbm_traffic{sfx}.json")) as fh:
+            import glob
+
+            def newest(stem):                                       # profiles/rNN_<stem><sfx>.json of the latest round that has one
+                found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{stem}{sfx}.json")))
+                if not found:
+                    raise OSError(f"no profiles/rNN_{stem}{sfx}.json")
+                return found[-1]
+            pmc_path = newest("pmc_hbm_traffic")
+            with open(pmc_path) as fh:
                 pmc = json.load(fh)
             if pmc.get("csrc_sha") == sha and pmc.get("config") == tag and dom == "conv_igemm":
                 allf = [v for k, v in pmc.items() if isinstance(v, dict) and "launches" in v]
@@ -324,18 +332,18 @@ def main():
                 tb = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in fams)
                 nl = sum(v["launches"] for v in fams)
                 out["roofline"]["traffic"] = round(tb / nl / 1e6, 2)
-                out["roofline"]["traffic_unit"] = f"MB HBM per launch (PMC, profiles/r04_pmc_hbm_traffic{sfx}.json @ csrc {sha})"
+                out["roofline"]["traffic_unit"] = f"MB HBM per launch (PMC, profiles/{os.path.basename(pmc_path)} @ csrc {sha})"
                 out["roofline"]["alg_mbytes_per_launch_unfused"] = round(d["bytes"] / d["launches"] / 1e6, 2)
                 step_bytes = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in allf)
                 out["hbm"] = {"gbytes_per_step_pmc": round(step_bytes / 1e9, 3), "gbytes_per_s": round(step_bytes / elapsed * args.steps / 1e9, 1),
                               "frac_of_peak": round(step_bytes / elapsed * args.steps / 1e9 / HBM_PEAK_GBS, 4), "peak_gbytes_per_s": HBM_PEAK_GBS,
                               "note": "whole step: PMC bytes of one steady step (FETCH_SIZE x 2 + WRITE_SIZE) / this run's ms_per_step"}
-            with open(os.path.join(ROOT, "profiles", f"r04_rocprofv3_kernel_summary{sfx}.json")) as fh:
+            with open(newest("rocprofv3_kernel_summary")) as fh:
                 rp = json.load(fh)
             if rp.get("csrc_sha") == sha and rp.get("config") == tag:
                 out["roofline"]["avg_launch_us_rocprofv3"] = rp["conv_igemm_all"]["avg_us"]
                 out["roofline"]["achieved_rocprofv3"] = round(d["flops"] / (rp["conv_igemm_all"]["us_per_step"] * 1e-6) / 1e12, 2)
-            with open(os.path.join(ROOT, "profiles", f"r04_pmc_mfma_util{sfx}.json")) as fh:
+            with open(newest("pmc_mfma_util")) as fh:
                 mu = json.load(fh)
             if mu.get("csrc_sha") == sha and mu.get("config") == tag:
                 out["roofline"]["mfma_busy_frac_pmc"] = mu["conv_igemm_all"]["mfma_util"]

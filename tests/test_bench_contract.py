@@ -29,7 +29,12 @@ def test_default_command_prints_the_contract_line_with_every_leg():
     assert "RT-DETR-R50 640x640 bs=8" in d["config"]["workload"] and "model" not in d["config"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert 0.03 < rf["frac"] < 0.4 and ("traffic" in rf)
+    assert 0.03 < rf["frac"] < 0.4
+    # the committed PMC / rocprofv3 summaries must belong to THESE kernel sources (tools/refresh_profiles.sh + commit_profiles.sh after the
+    # last kernel change of a round): bench.py attaches them only when their csrc stamp matches
+    assert rf["traffic"] is not None and rf["traffic"] > 10 and "avg_launch_us_rocprofv3" in rf and "mfma_busy_frac_pmc" in rf, rf
+    assert abs(rf["avg_launch_us_rocprofv3"] - rf["avg_launch_us"]) / rf["avg_launch_us"] < 0.15      # HIP-event and rocprofv3 durations agree
+    assert d["hbm"]["gbytes_per_step_pmc"] > 5
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "frames/s" and "sample" in cb
     assert d["cpu_baseline_r18_bs1"]["p50"] > 0 and d["cpu_baseline_r18_bs1"]["kind"] == "port"
