@@ -318,3 +318,11 @@ def test_packed_blob_cache_is_keyed_by_source_and_survives_a_torn_file(tmp_path,
     assert W.blob_cache_key(arch, str(f)) != k1 != W.blob_cache_key(ARCHS["tinyb"], str(f))
     monkeypatch.setenv("RTD_BLOB_CACHE", "0")
     assert W.cached_blob(arch, "synthetic:tiny:1", make(1)) == a and calls[-1] == 1 and len(calls) == 4
+
+
+def test_two_rank_launch_and_gather_rehearsal_on_cpu():
+    """The launch + rendezvous + gather of tests/shard_ws2_child.py (the GPU box runs it with real engines) rehearsed here without a GPU:
+    torch.distributed.run on 127.0.0.1 with a port of our choosing, gloo, camera k -> rank k mod 2."""
+    from tests.test_rccl_collate import run_two_ranks
+    out = run_two_ranks({"SHARD_DRY": "1"}, 240)
+    assert out["world"] == 2 and out["dry"] is True and out["bit_exact"] is True and out["cameras"] == {"0": [0, 2], "1": [1, 3]}
