@@ -171,6 +171,17 @@ def test_the_engines_call_sequence_on_the_real_detector():
         assert a["class_id"] == b["class_id"] and a["class_name"] == b["class_name"] and abs(a["confidence"] - b["confidence"]) <= 1e-3
         assert all(abs(a["bbox"][k] - b["bbox"][k]) <= 1e-2 for k in ("x1", "y1", "x2", "y2")) and isinstance(a["bbox"]["area"], int)
 
+    # 2b. hot-reload of the settings while serving (update_settings, :672-685): the engine WRITES detector.conf_threshold / nms_threshold;
+    #     the next detect filters at the new threshold (a prefix of the old answer: rows are in descending score order), NMS has no meaning here
+    scores = [d["confidence"] for d in first]
+    cut = float(np.median(scores))
+    det.conf_threshold = cut                                          # :678
+    det.nms_threshold = 0.45                                          # :684
+    hot = eng.run_inference(small)
+    assert hot == [d for d in first if d["confidence"] >= cut] and 0 < len(hot) < len(first) and det.nms_threshold == 0.45
+    det.conf_threshold = kw["conf_threshold"]
+    assert eng.run_inference(small) == first
+
     # 3. a 4K frame arrives while the rest of the process (torch's cache) holds the GPU: the frame's staging buffers cannot be
     #    allocated -> RTD_E_OOM -> torch.cuda.OutOfMemoryError out of detect (:607) -> empty_cache, degrade writes, ONE retry (:609-620)
     big = scene_frame(12, 2160, 3840)
