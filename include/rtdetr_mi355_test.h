@@ -48,7 +48,7 @@ int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int3
  * Plan building:
  *   sc_fold [1] projection shortcut folded into the block's last conv | up_fold [1] FPN upsample folded into the CSP's first conv |
  *   c1_fuse [1] a block's reduce conv computed inside the previous block's expand conv (bf16: stage 0/1; f16x3: stage 0 and the first block
- *   of stage 1) | attn_split [2] self-attention on fp16-pair MFMAs (bit 0 AIFI, bit 1 decoder) |
+ *   of stage 1) | attn_split [3] self-attention on fp16-pair MFMAs (bit 0 the fused AIFI layer, bit 1 decoder) |
  *   arena_reuse [1] | stem_fused_split [1] (f16x3): stem.0 straight from the uint8 frames | stem_pool_fuse [1] (f16x3): stem.2 and the 3x3/s2
  *   max-pool in one pass | avg_fuse [1] (f16x3): a stage's last expand conv also writes the next stage's vd-shortcut average |
  *   dead_out [1] (f16x3): the stage-0 output is not written when its only readers are that launch's fused follower conv and fused average |

@@ -27,10 +27,11 @@ struct PlanOpts {
   int dec_split = 1;    // bf16 / f16x3 engines run the fused decoder / AIFI linears as bf16 hi/lo splits (0: fp32 MFMA, 2: bf16 filters)
   int sc_fold = 1;      // fold a block's projection shortcut into its last conv (ConvArgs::x2)
   int c1_fuse = 1;      // bf16 plans run a stage-0 block's reduce conv inside the previous block's last conv
-  // self-attention on hi/lo fp16 MFMAs - bit 0 AIFI, bit 1 decoder.  Default: decoder only (logits agree with the fp32-MFMA attention
-  // to 1e-6).  In AIFI the softmax arguments reach tens (measured with round 2's bf16 pairs: a 2^-16 product error became 1.7e-4 on the
-  // layer output): that layer stays on fp32 MFMAs (10 us per step)
-  int attn_split = 2;
+  // self-attention on hi/lo fp16 MFMAs - bit 0 the fused AIFI layer, bit 1 decoder.  Both since round 5: with round 2's bf16 pairs AIFI's
+  // softmax arguments (tens) turned a 2^-16 product error into 1.7e-4 on the layer output and the layer stayed on fp32 MFMAs; with fp16
+  // pairs (2^-22) every x3_check case keeps its rows and its worst errors (R50 640 bs 8: 1.4e-6 / 4.9e-4 px either way), and the layer
+  // takes 52 instead of 61 us.  The un-fused AIFI attention of encoders wider than 256 channels (k_attention_mfma_f32) is fp32 as before.
+  int attn_split = 3;
   int up_fold = 1;      // read the FPN's upsampled lateral straight from the half-size tensor (ConvArgs::x_up2)
   int arena_reuse = 1;  // backbone stages recycle their activation buffers
   int stem_fused_split = 1;   // f16x3 engine: backbone.stem.0 straight from the uint8 frames (hi/lo pairs made on the fly from the bytes)

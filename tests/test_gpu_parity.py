@@ -358,7 +358,7 @@ def test_split_bf16_self_attention_matches_fp32_mfma_attention():
         got[v] = dict(aifi=e.debug_tensor("aifi_out").astype(np.float64).copy(), logits=e.debug_tensor("logits").astype(np.float64).copy(),
                       boxes=np.asarray(raw[1], np.float64), scores=np.asarray(raw[2], np.float64))
         e.close()
-    _capi.debug_option("attn_split", 2)
+    _capi.debug_option("reset", 0)
     rel = lambda x, y: np.linalg.norm(x - y) / np.linalg.norm(x)
     e_aifi = rel(got[0]["aifi"], got[1]["aifi"])
     e_log = rel(got[0]["logits"], got[2]["logits"])
