@@ -51,6 +51,7 @@ int rtd_profile(rtd_handle h, int32_t n, int32_t reps, rtd_layer_time* out, int3
  *   of stage 1) | attn_split [3] self-attention on fp16-pair MFMAs (bit 0 the fused AIFI layer, bit 1 decoder) |
  *   arena_reuse [1] | stem_fused_split [1] (f16x3): stem.0 straight from the uint8 frames | stem_pool_fuse [1] (f16x3): stem.2 and the 3x3/s2
  *   max-pool in one pass | avg_fuse [1] (f16x3): a stage's last expand conv also writes the next stage's vd-shortcut average |
+ *   post_fused [1] sigmoid + top-k + box decode of the post-processor in one launch |
  *   dead_out [1] (f16x3): the stage-0 output is not written when its only readers are that launch's fused follower conv and fused average |
  *   aifi_pair [1] (f16x3): the un-fused AIFI's linears on the pair kernels | side_stream [7: bit 0 query
  *   selection on a second stream beside the value projection, bit 1 decoder input projections beside the PAN path, bit 2 encoder input

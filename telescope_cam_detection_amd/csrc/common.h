@@ -238,6 +238,7 @@ void launch_msdeform(const Tensor& value, int value_coff, const Tensor& offaw, c
                      hipStream_t s);
 void launch_box_refine(const Tensor& delta, float* ref8, hipStream_t s);
 void launch_postprocess_scores(const Tensor& logits, float* scores, hipStream_t s);
+bool launch_postprocess_fused(const Tensor& logits, const float* ref8, const float* scale_wh, int B, int Q, float* block6, hipStream_t s);
 void launch_postprocess_gather(const float* topv, const int32_t* topi, const float* ref8, const float* scale_wh,
                                int B, int Q, int C, float* block6, hipStream_t s);
 // per-call frame arguments travel as KERNEL ARGUMENTS (captured at launch): an async host->device copy of them would read the

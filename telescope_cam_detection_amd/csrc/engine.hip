@@ -1087,11 +1087,19 @@ void build_graph(rtd_engine* e, Builder& B, int n) {
   plan->scale_wh = (float*)B.alloc((size_t)n * 2 * 4);
   {
     float* block6 = plan->block6; float* scale = plan->scale_wh;
+    // one launch when the shape allows (every decoder here: dense [n * Q, C] fp32 logits, Q * C <= 32768), else sigmoid -> top-k -> gather
+    const bool fused_ok = e->opts.post_fused && logits.dt == F32 && logits.ld == C && (int64_t)Q * C <= 32768 && Q <= 1024 && logits.pixels() == (int64_t)n * Q;
+    if (fused_ok) {
+      B.push("post.fused", "topk", (double)n * Q * C, (double)n * Q * C * 4 + (double)n * Q * 64, [logits, ref8, scale, n, Q, block6](hipStream_t s) {
+        RTD_CHECK(launch_postprocess_fused(logits, ref8, scale, n, Q, block6, s), 1, "post-processor: fused launch refused a shape the plan accepted");
+      });
+    } else {
     B.push("post.sigmoid", "postprocess", (double)n * Q * C, 2.0 * n * Q * C * 4, [logits, scores](hipStream_t s) { launch_postprocess_scores(logits, scores, s); });
     B.push("post.topk", "topk", 0.0, (double)n * Q * C * 4 * 6, [scores, n, Q, C, topi, topv](hipStream_t s) { launch_topk(scores, n, Q * C, Q, topi, topv, s); });
     B.push("post.gather", "postprocess", 0.0, (double)n * Q * 64, [topv, topi, ref8, scale, n, Q, C, block6](hipStream_t s) {
       launch_postprocess_gather(topv, topi, ref8, scale, n, Q, C, block6, s);
     });
+    }
   }
   B.finish_workspace();
 }

@@ -36,6 +36,7 @@ struct PlanOpts {
   int arena_reuse = 1;  // backbone stages recycle their activation buffers
   int stem_fused_split = 1;   // f16x3 engine: backbone.stem.0 straight from the uint8 frames (hi/lo pairs made on the fly from the bytes)
   int aifi_pair = 1;          // f16x3 engine, un-fused AIFI (encoders wider than 256 channels): its linears on the pair kernels instead of fp32 MFMAs
+  int post_fused = 1;         // sigmoid + top-k + box decode of the post-processor in one launch (ops.hip TopkPost)
   int dead_out = 1;           // f16x3 engine: a stage output whose only readers are fused into the launch that produces it is not written (ConvArgs::y_dead)
   int avg_fuse = 1;           // f16x3 engine: a stage's last expand conv also writes the 2 x 2 average the next stage's vd shortcut reads (ConvArgs::avg_y)
   int stem_pool_fuse = 1;     // f16x3 engine: backbone.stem.2 and the 3x3 / stride-2 max-pool in one pass (the conv rows are never written)

@@ -734,9 +734,44 @@ __device__ __forceinline__ float key2f(unsigned k) {
 
 // REG = true: every thread keeps its <= 32 keys in registers (N <= 32768), so the four radix passes and the
 // compaction touch global memory once; REG = false re-reads the keys from global (any N).
-template <bool REG>
+// POST (REG only): the whole post-processor of HF:rt_detr/image_processing_rt_detr.py:510-533 in this launch - the keys are
+// sigmoid(logits[q][c]) made while they are loaded (index = q * C + c) and a winner is written as its finished row [label, score, x1, y1,
+// x2, y2] (label = index % C, query = index / C, cxcywh -> xyxy, scaled to the original frame): the score tensor, the index / value
+// vectors and two launches (k_pp_scores, k_pp_gather) disappear.  Same keys, same tie rule, same arithmetic per row as the three-launch form.
+struct TopkPost {
+  const float* ref8;       // [B][Q][8] cxcywh boxes of the last decoder layer
+  const float* scale_wh;   // [B][2] original frame (w, h)
+  float* block6;           // [B][K][6]
+  int C, Q;
+};
+__device__ __forceinline__ float topk_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }   // == sigmoidf_ below (k_pp_scores)
+template <bool REG, bool POST = false>
 __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ keys, int N, int K, int32_t* __restrict__ idx_out,
-                                                float* __restrict__ val_out) {
+                                                float* __restrict__ val_out, const TopkPost pa) {
+  static_assert(!POST || REG, "the fused post-processor keeps its keys in registers");
+  auto emit = [&](unsigned r, unsigned long long e) {            // rank r of this image: composite (key << 32 | ~index)
+    const int idx = (int)(0xffffffffu - (unsigned)(e & 0xffffffffu));
+    const float val = key2f((unsigned)(e >> 32));
+    if (POST) {
+      const int bimg = blockIdx.x;
+      const int label = idx % pa.C;
+      int q = idx / pa.C;
+      q = min(max(q, 0), pa.Q - 1);
+      const float* rr = pa.ref8 + ((int64_t)bimg * pa.Q + q) * 8;
+      const float cx = rr[0], cy = rr[1], w = rr[2], h = rr[3];
+      const float sw = pa.scale_wh[bimg * 2 + 0], sh = pa.scale_wh[bimg * 2 + 1];
+      float* o = pa.block6 + ((int64_t)bimg * K + r) * 6;
+      o[0] = (float)label;
+      o[1] = val;
+      o[2] = (cx - 0.5f * w) * sw;
+      o[3] = (cy - 0.5f * h) * sh;
+      o[4] = (cx + 0.5f * w) * sw;
+      o[5] = (cy + 0.5f * h) * sh;
+    } else {
+      idx_out[(int64_t)blockIdx.x * K + r] = idx;
+      if (val_out) val_out[(int64_t)blockIdx.x * K + r] = val;
+    }
+  };
   constexpr int MAXPT = 32;
   // one histogram per wave: scores of one image share their high key bits, so a block-wide histogram serialises ~N LDS atomics on a
   // handful of addresses per pass (24000 keys: ~10 us per pass); per wave the same-address adds of one instruction cost ~64 cycles
@@ -753,7 +788,7 @@ __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ keys, i
 #pragma unroll
     for (int j = 0; j < MAXPT; ++j) {
       const int i = tid + j * 1024;
-      kreg[j] = (j < npt && i < N) ? f2key(kb[i]) : 0u;         // slots beyond N are never counted (guarded by i < N)
+      kreg[j] = (j < npt && i < N) ? f2key(POST ? topk_sigmoid(kb[i]) : kb[i]) : 0u;         // slots beyond N are never counted (guarded by i < N)
     }
   }
   // ---- fast path (round 5): bound the candidates before any pass over all the keys ----------------------------------------------
@@ -859,10 +894,7 @@ __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ keys, i
         const unsigned long long my = sel[tid];
         unsigned r = 0;
         for (unsigned j = 0; j < C; ++j) r += sel[j] > my ? 1u : 0u;
-        if (r < (unsigned)K) {
-          idx_out[(int64_t)blockIdx.x * K + r] = (int32_t)(0xffffffffu - (unsigned)(my & 0xffffffffu));
-          if (val_out) val_out[(int64_t)blockIdx.x * K + r] = key2f((unsigned)(my >> 32));
-        }
+        if (r < (unsigned)K) emit(r, my);
       }
       return;
     }
@@ -1018,17 +1050,23 @@ __global__ __launch_bounds__(1024) void k_topk(const float* __restrict__ keys, i
     }
   }
   __syncthreads();
-  if (tid < K) {
-    const unsigned long long e = sel[tid];
-    idx_out[(int64_t)blockIdx.x * K + tid] = (int32_t)(0xffffffffu - (unsigned)(e & 0xffffffffu));
-    if (val_out) val_out[(int64_t)blockIdx.x * K + tid] = key2f((unsigned)(e >> 32));
-  }
+  if (tid < K) emit((unsigned)tid, sel[tid]);
 }
 void launch_topk(const float* keys, int B, int N, int K, int32_t* idx, float* vals, hipStream_t s) {
   RTD_CHECK(K >= 1 && K <= 1024 && K <= N, 1, "topk: K must be in [1, min(1024, N)]");
-  if (N <= 32768) rtd_launch(k_topk<true>, dim3(B), dim3(1024), 0, s, keys, N, K, idx, vals);
-  else rtd_launch(k_topk<false>, dim3(B), dim3(1024), 0, s, keys, N, K, idx, vals);
+  const TopkPost none = {nullptr, nullptr, nullptr, 0, 0};
+  if (N <= 32768) rtd_launch((k_topk<true, false>), dim3(B), dim3(1024), 0, s, keys, N, K, idx, vals, none);
+  else rtd_launch((k_topk<false, false>), dim3(B), dim3(1024), 0, s, keys, N, K, idx, vals, none);
   HIP_CHECK(hipGetLastError());
+}
+// the post-processor in one launch (TopkPost); false when the shape needs the three-launch form (dense logits rows, Q * C keys in registers)
+bool launch_postprocess_fused(const Tensor& logits, const float* ref8, const float* scale_wh, int B, int Q, float* block6, hipStream_t s) {
+  const int C = logits.c;
+  if (logits.dt != F32 || logits.ld != C || (int64_t)Q * C > 32768 || Q > 1024 || logits.pixels() != (int64_t)B * Q) return false;
+  const TopkPost pa = {ref8, scale_wh, block6, C, Q};
+  rtd_launch((k_topk<true, true>), dim3(B), dim3(1024), 0, s, (const float*)logits.p, Q * C, Q, (int32_t*)nullptr, (float*)nullptr, pa);
+  HIP_CHECK(hipGetLastError());
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------ gather rows

@@ -201,7 +201,7 @@ int rtd_debug_option(const char* name, int value) {
   // created afterwards (and the kernel-level rtd_op_* / rtd_bench_* entry points), never a live handle
   const struct { const char* n; int* p; } plan_opts[] = {
       {"dec_stamps", &g_opts.dec_stamps}, {"dec_fused", &g_opts.dec_fused}, {"side_stream", &g_opts.side_stream}, {"sel_fused", &g_opts.sel_fused},
-      {"stem_fused_split", &g_opts.stem_fused_split}, {"stem_pool_fuse", &g_opts.stem_pool_fuse}, {"avg_fuse", &g_opts.avg_fuse}, {"dead_out", &g_opts.dead_out}, {"aifi_pair", &g_opts.aifi_pair}, {"sc_fold", &g_opts.sc_fold}, {"arena_reuse", &g_opts.arena_reuse},
+      {"stem_fused_split", &g_opts.stem_fused_split}, {"stem_pool_fuse", &g_opts.stem_pool_fuse}, {"avg_fuse", &g_opts.avg_fuse}, {"dead_out", &g_opts.dead_out}, {"post_fused", &g_opts.post_fused}, {"aifi_pair", &g_opts.aifi_pair}, {"sc_fold", &g_opts.sc_fold}, {"arena_reuse", &g_opts.arena_reuse},
       {"up_fold", &g_opts.up_fold}, {"attn_split", &g_opts.attn_split}, {"c1_fuse", &g_opts.c1_fuse}, {"dec_split", &g_opts.dec_split},
       {"profile_twice", &g_profile_twice}, {"bench_rewarm", &g_bench_rewarm},
   };

@@ -727,6 +727,35 @@ def test_f16x3_unwritten_stage0_output_changes_nothing(aname, size, bs):
         np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("aname,prec,size,bs", [("r50", "f16x3", (640, 640), 3), ("r18", "fp32", (320, 416), 2), ("tinyc", "bf16", (160, 224), 2)])
+def test_fused_post_processor_equals_sigmoid_topk_gather(aname, prec, size, bs):
+    """The post-processor (HF:image_processing_rt_detr.py:510-533) as ONE launch - sigmoid while the keys are loaded, top-k, the winners written
+    as finished [label, score, x1, y1, x2, y2] rows (ops.hip TopkPost, round 5) - against the three-launch form: raw rows and the filtered
+    `rtd_infer` rows bit for bit, graph replay included, frames of other sizes than the network's (the (w, h) scale differs per frame)."""
+    from telescope_cam_detection_amd import _capi
+    from telescope_cam_detection_amd.arch import ARCHS
+    from telescope_cam_detection_amd.synth import noise_frame, scene_frame
+    arch = ARCHS[aname]
+    w = weights_for(arch, 2)
+    frames = [scene_frame(30 + i, size[0] + 40 * i, size[1] - 16 * i) if i % 2 == 0 else noise_frame(30 + i, size[0], size[1]) for i in range(bs)]
+    got = {}
+    for fused in (0, 1):
+        _capi.debug_option("post_fused", fused)
+        eng = make_engine(arch, w, frames, size, prec, use_graph=True)
+        for _ in range(3):
+            raw = eng.infer_raw(frames)
+        rows = eng.infer(frames, 0.0, False)
+        names = [p["name"] for p in eng.profile(bs, 1)]
+        assert ("post.fused" in names) == bool(fused) and ("post.topk" in names) != bool(fused), names
+        got[fused] = (raw, rows)
+        eng.close()
+    _capi.debug_option("reset", 0)
+    for x, y in zip(got[0][0], got[1][0]):
+        np.testing.assert_array_equal(x, y)
+    for x, y in zip(got[0][1], got[1][1]):
+        assert len(x) == arch.num_queries and (x == y).all()
+
+
 def test_non_square_input_with_partial_tiles_bf16_and_fp32():
     """416 x 736 (multiples of 32, but 208 x 368 and 104 x 184 are not multiples of the 8 x 32 / 128-pixel tiles): every conv
     kernel family meets ragged tiles.  fp32 engine vs oracle at the north-star tolerance, bf16 engine vs fp32 engine to bf16 noise."""
