@@ -204,7 +204,17 @@ class RTDETRDetector:
             return pack_blob(fold_weights(other["arch"], other["state"])), other["arch"]
 
     def _verified(self, engine, blob) -> bool:
-        rep = engine.self_check(blob)
+        import torch
+
+        try:
+            rep = engine.self_check(blob)
+        except torch.cuda.OutOfMemoryError as e:
+            # the check needs two temporary bs-1 engines beside this one: when they do not fit, the detector is served unverified - loudly -
+            # rather than refused (its own arenas are allocated; the caller's OOM handling covers what happens later)
+            logger.warning("RT-DETR (MI355X): load-time self check of %s SKIPPED, not enough device memory for the two temporary engines (%s)",
+                           self.model_path, str(e)[:160])
+            self.last_check = None
+            return True
         self.last_check = rep
         share = rep["rows_matched"] / max(1, rep["rows"])
         line = ("%d of %d rows of the fp32 engine matched within %.0e / %.0e px (worst %.1e / %.1e px), %d activations at the fp16 pair "
